@@ -1,0 +1,43 @@
+"""Test helpers shared by CPU and GPU tests."""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+from safetensors.torch import load_file
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name: str):
+    t = load_file(os.path.join(GOLDEN, f"{name}.safetensors"))
+    with open(os.path.join(GOLDEN, f"{name}.json")) as fh:
+        meta = json.load(fh)
+    return t, meta
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max|a-b| / max|b| over finite entries; non-finite patterns must match exactly."""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin), "non-finite pattern differs"
+    if not fin.any():
+        return 0.0
+    return float((a[fin] - b[fin]).abs().max() / b[fin].abs().max().clamp_min(1e-20))
+
+
+def argmax_disagreement(logits: torch.Tensor, ref_argmax: torch.Tensor, ref_logits: torch.Tensor = None,
+                        margin_rel: float = 0.0):
+    """(#pixels whose argmax differs, #of those where the reference top-2 margin exceeds margin_rel*max|logit|)."""
+    am = logits.argmax(dim=1).cpu()
+    diff = am != ref_argmax.cpu().long()
+    n_diff = int(diff.sum())
+    if ref_logits is None or n_diff == 0:
+        return n_diff, n_diff
+    rl = ref_logits.float().cpu()
+    top2 = rl.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    scale = float(rl[torch.isfinite(rl)].abs().max())
+    return n_diff, int((diff & (margin > margin_rel * scale)).sum())

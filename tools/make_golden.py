@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Generate golden vectors by importing the REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--only NAME] [--full]
+
+For each case: seeded weights (labelanything_amd.weights.init_state_dict) are loaded into the
+reference model (strict), a seeded synthetic episode is pushed through the reference's
+``Lam.forward`` on CPU/fp32, the oracle (oracle/lam_oracle.py) is checked against it, and the
+reference's outputs are written to tests/golden/<case>.safetensors (+ .json metadata).
+
+Nothing of the reference travels: fixtures hold inputs' seeds and expected outputs only.
+/root/reference is imported with stub modules for its off-path dependencies.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+import importlib.abc
+import importlib.machinery
+from functools import partial
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+# real imports FIRST (a fake torchvision breaks transformers' lazy imports)
+import torch
+from transformers import ViTModel, AutoModel, AutoBackbone, get_scheduler, ViTConfig  # noqa: F401
+from transformers.configuration_utils import PretrainedConfig  # noqa: F401
+import transformers.utils.constants  # noqa: F401
+import accelerate, huggingface_hub, safetensors.torch  # noqa: F401,E401
+
+_STUB_ROOTS = {"ruamel", "torchvision", "pycocotools", "torchmetrics", "wandb", "easydict", "cv2", "timm",
+               "dropblock", "lovely_tensors", "captum", "optuna", "wget", "nicegui", "streamlit", "colorlog",
+               "skimage", "kornia", "streamlit_drawable_canvas", "sklearn"}
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return type(k, (object,), {"__init__": lambda s, *a, **kw: None, "__call__": lambda s, *a, **kw: None,
+                                   "__getattr__": lambda s, k: (lambda *a, **kw: None)})
+
+
+class _Loader(importlib.abc.Loader):
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in _STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(name, _Loader(), is_package=True)
+
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.meta_path.insert(0, _Finder())
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+import label_anything.models as RM                      # noqa: E402  (the reference)
+from label_anything.models.image_encoder import ImageEncoderViT   # noqa: E402
+from label_anything.models.build_encoder import ViTModelWrapper    # noqa: E402
+from label_anything.models.build_lam import _build_lam             # noqa: E402
+
+# our own package shadows nothing: it is named labelanything_amd
+from labelanything_amd.config import EncoderSpec, LamConfig, ENCODER_SPECS, register_encoder  # noqa: E402
+from labelanything_amd.weights import init_state_dict                                        # noqa: E402
+from labelanything_amd.episodes import make_episode                                          # noqa: E402
+from tests.cases import CASES, geometry_for                                                  # noqa: E402
+from oracle import lam_oracle as O                                                           # noqa: E402
+from safetensors.torch import save_file                                                      # noqa: E402
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def _hf_4x_to_local(sd, model):
+    """Map transformers-4.x ViT key names (ours) onto whatever this container's transformers uses."""
+    local = set(model.state_dict().keys())
+    out = {}
+    for k, v in sd.items():
+        cands = [k]
+        k5 = (k.replace("encoder.layer.", "layers.")
+               .replace("attention.attention.query", "attention.q_proj")
+               .replace("attention.attention.key", "attention.k_proj")
+               .replace("attention.attention.value", "attention.v_proj")
+               .replace("attention.output.dense", "attention.o_proj")
+               .replace("intermediate.dense", "mlp.fc1")
+               .replace("output.dense", "mlp.fc2"))
+        cands.append(k5)
+        cands.append(k5.replace("layers.", "encoder.layers."))
+        hit = [c for c in cands if c in local]
+        if not hit:
+            raise KeyError(f"cannot map {k}; e.g. local keys: {sorted(local)[:12]}")
+        out[hit[0]] = v
+    return out
+
+
+def build_reference(case):
+    cfg: LamConfig = case["cfg"]
+    spec = cfg.encoder_spec
+    vit = None
+    if spec is not None and spec.kind == "sam":
+        vit = ImageEncoderViT(
+            img_size=spec.img_size, patch_size=spec.patch, embed_dim=spec.dim, depth=spec.depth,
+            num_heads=spec.heads, mlp_ratio=spec.mlp / spec.dim, out_chans=spec.out_chans, qkv_bias=True,
+            norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), use_rel_pos=True,
+            global_attn_indexes=spec.global_idx, window_size=spec.window,
+            project_last_hidden=cfg.use_vit_sam_neck)
+    elif spec is not None and spec.kind == "hf":
+        vit = ViTModelWrapper(ViTConfig(
+            hidden_size=spec.dim, num_hidden_layers=spec.depth, num_attention_heads=spec.heads,
+            intermediate_size=spec.mlp, patch_size=spec.patch, image_size=spec.img_size,
+            layer_norm_eps=1e-12, qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0),
+            add_pooling_layer=False)
+    lam = _build_lam(
+        build_vit=(lambda project_last_hidden=True: vit), use_vit=vit is not None,
+        use_vit_sam_neck=cfg.use_vit_sam_neck, image_embed_dim=cfg.image_embed_dim, embed_dim=cfg.embed_dim,
+        image_size=cfg.image_size, class_attention=cfg.class_attention, example_attention=cfg.example_attention,
+        example_class_attention=cfg.example_class_attention, spatial_convs=cfg.spatial_convs,
+        class_encoder=dict(cfg.class_encoder) if cfg.class_encoder else None,
+        custom_preprocess=cfg.custom_preprocess)
+    lam.eval()
+    sd = init_state_dict(cfg, case["weight_seed"])
+    if spec is not None and spec.kind == "hf":
+        enc = {k[len("image_encoder."):]: v for k, v in sd.items() if k.startswith("image_encoder.")}
+        enc = _hf_4x_to_local(enc, lam.image_encoder)
+        missing, unexpected = lam.image_encoder.load_state_dict(enc, strict=False)
+        missing = [k for k in missing if "pooler" not in k]
+        assert not missing and not unexpected, (missing, unexpected)
+        rest = {k: v for k, v in sd.items() if not k.startswith("image_encoder.")}
+        res = lam.load_state_dict(rest, strict=False)
+        assert all(k.startswith("image_encoder.") for k in res.missing_keys) and not res.unexpected_keys, res
+    else:
+        res = lam.load_state_dict(sd, strict=True)
+    return lam, sd
+
+
+def run_case(name, case, write=True):
+    t0 = time.time()
+    cfg: LamConfig = case["cfg"]
+    lam, sd = build_reference(case)
+    batch = make_episode(**case["episode"])
+    rows = None
+    if cfg.bank_size:
+        c = batch["flag_examples"].shape[2]
+        gr = torch.Generator().manual_seed(case["weight_seed"] + 7)
+        rows = torch.cat([torch.zeros(1, dtype=torch.long),
+                          torch.randperm(cfg.bank_size - 1, generator=gr)[: c - 1] + 1])
+        lam.prompt_encoder.class_encoder.sample_rows = lambda C, device, _r=rows: _r.to(device)
+    with torch.no_grad():
+        emb_q, emb_s = lam.prepare_query_example_embeddings(batch)
+        ref = lam(batch)
+        seg_low, pe_result = lam._forward(batch)
+    t_ref = time.time() - t0
+
+    geo = geometry_for(cfg)
+    stages = {}
+    t1 = time.time()
+    with torch.no_grad():
+        ours = O.lam_forward(sd, geo, batch, selected_rows=rows, stages=stages)
+    t_or = time.time() - t1
+
+    def rel(a, b):
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), fin)
+        return float((a[fin] - b[fin]).abs().max() / b[fin].abs().max().clamp_min(1e-12))
+
+    errs = {
+        "embeddings": rel(stages["embeddings"][:, 0], emb_q),
+        "class_embeddings": rel(stages["class_embeddings"], pe_result["class_embeddings"]),
+        "low_res_logits": rel(stages["low_res_logits"], seg_low),
+        "logits": rel(ours["logits"], ref["logits"]),
+        "class_examples_embeddings": rel(ours["class_examples_embeddings"], ref["class_examples_embeddings"]),
+    }
+    am_ref = ref["logits"].argmax(dim=1)
+    am_or = ours["logits"].argmax(dim=1)
+    # argmax may legitimately differ only where the reference's own top-2 margin is at rounding level
+    top2 = ref["logits"].topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    scale = float(ref["logits"][torch.isfinite(ref["logits"])].abs().max())
+    errs["argmax_mismatch"] = int(((am_ref != am_or) & (margin > 1e-4 * scale)).sum())
+    errs["argmax_ties"] = int((am_ref != am_or).sum())
+    print(f"[{name}] reference {t_ref:.1f}s oracle {t_or:.1f}s  oracle-vs-reference: "
+          + ", ".join(f"{k}={v:.2e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()))
+    tol = case.get("oracle_tol", 2e-5)
+    for k, v in errs.items():
+        if not k.startswith("argmax"):
+            assert v <= tol, f"oracle disagrees with reference on {k}: {v}"
+    assert errs["argmax_mismatch"] == 0
+
+    if write:
+        os.makedirs(GOLDEN, exist_ok=True)
+        tensors = {
+            "query_embedding": emb_q.contiguous(),
+            "class_embeddings": pe_result["class_embeddings"].contiguous(),
+            "class_examples_embeddings": ref["class_examples_embeddings"].contiguous(),
+            "low_res_logits": seg_low.contiguous(),
+            "argmax": am_ref.to(torch.uint8).contiguous(),
+        }
+        if case.get("store_full_logits", True):
+            tensors["logits"] = ref["logits"].contiguous()
+        if case.get("store_query_embedding", True) is False:
+            tensors.pop("query_embedding")
+            # keep a strided sample so encoder parity is still pinned
+            tensors["query_embedding_sample"] = emb_q[:, ::8, ::4, ::4].contiguous()
+        if rows is not None:
+            tensors["selected_rows"] = rows
+        save_file(tensors, os.path.join(GOLDEN, f"{name}.safetensors"))
+        meta = {"case": name, "weight_seed": case["weight_seed"], "episode": case["episode"],
+                "oracle_vs_reference": errs, "reference_seconds": round(t_ref, 2),
+                "torch": torch.__version__, "generated_by": "tools/make_golden.py"}
+        with open(os.path.join(GOLDEN, f"{name}.json"), "w") as fh:
+            json.dump(meta, fh, indent=1, default=list)
+    return errs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--full", action="store_true", help="also run the slow full-geometry cases")
+    ap.add_argument("--no-write", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    for name, case in CASES.items():
+        if a.only and a.only != name:
+            continue
+        if case.get("slow") and not (a.full or a.only == name):
+            continue
+        run_case(name, case, write=not a.no_write)
+
+
+if __name__ == "__main__":
+    main()
