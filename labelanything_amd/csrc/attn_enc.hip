@@ -1,0 +1,390 @@
+// Encoder attention for gfx950: decomposed rel-pos terms + flash attention (head_dim 64).
+//
+// la_attn_fwd   one workgroup = 4 waves = 128 query rows of one (image|window, head); each wave owns 32 query
+//               rows.  Scores are computed TRANSPOSED, S^T = K . Q^T with MFMA 32x32x16 (A = K tile from LDS,
+//               B = Q held in registers), so that every lane holds 32 of the 64 scores of ONE query row:
+//               the online-softmax state (m, l, alpha) is lane-local and the row max needs a single
+//               cross-lane exchange (lane ^ 32).  P is converted to 16 bit in registers and redistributed
+//               with v_permlane32_swap into the B operand of O^T = V^T . P^T (A = V^T tile from LDS), so the
+//               output accumulator is again one query row per lane.  V arrives pre-transposed ([hd][T], written
+//               by the qkv GEMM epilogue), K/V tiles of 64 keys are double buffered in LDS (register staged,
+//               XOR swizzled).  The T x T matrix never exists.  The SAM decomposed relative position bias
+//               (image_encoder.py:340-376) enters as the INITIAL VALUE of the score accumulator:
+//                 fast path (G == 64): a 64-key tile is exactly one key row, so the bias is
+//                   relw[q][0..63] (held in registers for the whole kernel) + relh[q][tile] (one LDS read);
+//                 generic path (windows, other grids): per-wave LDS tables indexed by (key / G, key % G).
+// la_relpos_terms  one wave per (batch, head, query row y): relh = Q_y . Rh_y^T and U = Q_y . Rw^T on MFMA
+//               straight from global memory, U scattered to relw[q][qx - r + G - 1].
+#include "la_common.h"
+#include "../../include/la_hip.h"
+
+namespace la {
+
+constexpr int HD = 64;
+constexpr int KV_STAGE = 2 * 64 * HD * 2;  // K tile + V^T tile, 16 KiB
+constexpr float NEG_BIG = -1.0e30f;
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, int B, int heads, int G, int E,
+                                                     const T* __restrict__ tabh, const T* __restrict__ tabw,
+                                                     float* __restrict__ relh, float* __restrict__ relw) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= B * heads * G) return;
+  const int lane = threadIdx.x & 63, fr = lane & 31, fh = lane >> 5;
+  const int y = w % G, bh = w / G, h = bh % heads, b = bh / heads;
+  const int T_ = G * G;
+  const int ntx = (G + 31) >> 5;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+
+  uint4 af[2][4];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int x = ti * 32 + fr;
+    const bool ok = (ti < ntx) && (x < G);
+    const T* p = qkv + ((size_t)b * T_ + (size_t)y * G + (ok ? x : 0)) * (3 * E) + h * HD + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) af[ti][ks] = ok ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+  }
+  const size_t obase = ((size_t)bh * T_ + (size_t)y * G) * G;
+
+  // relh[x][kh] = q_x . Rh[y - kh + G - 1]
+  for (int tj = 0; tj < ntx; ++tj) {
+    const int j = tj * 32 + fr;
+    const bool okj = j < G;
+    const T* p = tabh + (size_t)(okj ? (y - j + G - 1) : 0) * HD + fh * 8;
+    uint4 wf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = okj ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (ti >= ntx) continue;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (x < G && okj) relh[obase + (size_t)x * G + j] = acc[r];
+      }
+    }
+  }
+  // U[x][r'] = q_x . Rw[r'];  relw[x][kw] = U[x][x - kw + G - 1]
+  const int nrel = 2 * G - 1;
+  const int ntr = (nrel + 31) >> 5;
+  for (int tj = 0; tj < ntr; ++tj) {
+    const int rp = tj * 32 + fr;
+    const bool okr = rp < nrel;
+    const T* p = tabw + (size_t)(okr ? rp : 0) * HD + fh * 8;
+    uint4 wf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = okr ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (ti >= ntx) continue;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int kw = x + G - 1 - rp;
+        if (x < G && okr && kw >= 0 && kw < G) relw[obase + (size_t)x * G + kw] = acc[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const void* qkv;
+  const void* vt;
+  void* out;
+  const float* relh;
+  const float* relw;
+  int B, heads, T, Tpad, G, E;
+  float scale;
+};
+
+// MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables).  MODE 2: rel-pos, G == 64 (tile == key row).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int BH = a.B * a.heads;
+  const int bh = blockIdx.x % BH, qblk = blockIdx.x / BH;  // same (image, head) -> same XCD when BH % 8 == 0
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int T_ = a.T, E3 = 3 * a.E;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* vt = reinterpret_cast<const T*>(a.vt);
+  const int q0 = qblk * 128 + wave * 32;
+  const int q = q0 + fr;
+  const int qc = min(q, T_ - 1);
+  const float inv_scale = 1.0f / a.scale;
+  const float c2 = a.scale * 1.44269504088896340736f;  // logits -> log2 domain
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + fh*8 .. +8] -----------------
+  uint4 qf[4];
+  {
+    const T* p = qkv + ((size_t)b * T_ + qc) * E3 + h * HD + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
+  }
+
+  // ---- bias staging ---------------------------------------------------------------------------------
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * KV_STAGE);
+  float rw[2][16];
+  float* my_bh = nullptr;
+  float* my_bw = nullptr;
+  const int* keyinfo = nullptr;
+  if (MODE == 2) {
+    my_bh = bias_lds + wave * 32 * 65;
+    for (int i = 0; i < 32; ++i) {
+      const int qi = min(q0 + i, T_ - 1);
+      my_bh[i * 65 + lane] = a.relh[((size_t)bh * T_ + qi) * 64 + lane] * inv_scale;
+    }
+    const float* p = a.relw + ((size_t)bh * T_ + qc) * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + t * 32 + 8 * g4 + 4 * fh);
+        rw[t][g4 * 4 + 0] = v.x * inv_scale;
+        rw[t][g4 * 4 + 1] = v.y * inv_scale;
+        rw[t][g4 * 4 + 2] = v.z * inv_scale;
+        rw[t][g4 * 4 + 3] = v.w * inv_scale;
+      }
+  } else if (MODE == 1) {
+    const int G = a.G, GS = G + 1;
+    my_bh = bias_lds + wave * 2 * 32 * GS;
+    my_bw = my_bh + 32 * GS;
+    for (int idx = lane; idx < 32 * G; idx += 64) {
+      const int i = idx / G, k = idx % G;
+      const size_t src = ((size_t)bh * T_ + min(q0 + i, T_ - 1)) * G + k;
+      my_bh[i * GS + k] = a.relh[src] * inv_scale;
+      my_bw[i * GS + k] = a.relw[src] * inv_scale;
+    }
+    int* ki = reinterpret_cast<int*>(bias_lds + 4 * 2 * 32 * GS);
+    for (int k = tid; k < a.Tpad; k += 256) ki[k] = ((k / G) << 16) | (k % G);
+    keyinfo = ki;
+  }
+
+  // ---- K / V^T tile staging ----------------------------------------------------------------------------
+  const int lc = tid & 7, lr = tid >> 3;  // chunk, row (rows lr and lr + 32)
+  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * HD + lc * 8;
+  const T* vbase = vt + ((size_t)bh * HD) * a.Tpad + lc * 8;
+  uint4 rk[2], rv[2];
+  auto gload = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = lr + 32 * i;
+      const int key = min(j * 64 + row, T_ - 1);
+      rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * E3);
+      rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * a.Tpad + j * 64);
+    }
+  };
+  auto swrite = [&](int stage) {
+    char* sk = smem + stage * KV_STAGE;
+    char* sv = sk + 64 * HD * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = lr + 32 * i;
+      *reinterpret_cast<uint4*>(sk + swz_off(row, lc)) = rk[i];
+      *reinterpret_cast<uint4*>(sv + swz_off(row, lc)) = rv[i];
+    }
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  const int ntiles = (T_ + 63) >> 6;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    if (j + 1 < ntiles) gload(j + 1);
+    const char* sk = smem + (j & 1) * KV_STAGE;
+    const char* sv = sk + 64 * HD * 2;
+
+    // ---- S^T tile: 64 keys x 32 queries, accumulator initialised with the positional bias -------------
+    f32x16 s[2];
+    if (MODE == 2) {
+      const float rh = my_bh[fr * 65 + j];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = rw[t][r] + rh;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
+        s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
+      }
+    }
+    if (MODE == 1) {
+      const int GS = a.G + 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int info = keyinfo[key];
+          s[t][r] += my_bh[fr * GS + (info >> 16)] + my_bw[fr * GS + (info & 0xffff)];
+        }
+    }
+    if (j * 64 + 64 > T_) {  // tail tile: mask keys >= T (wave-uniform branch)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (key >= T_) s[t][r] = NEG_BIG;
+        }
+    }
+
+    // ---- online softmax, one query row per lane pair (lane, lane ^ 32) -----------------------------------
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (!__all(m_new == m_run)) {
+      const float alpha = exp2f((m_run - m_new) * c2);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c2;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(fmaf(s[t][r], c2, -mc));
+        s[t][r] = p;
+        psum += p;
+      }
+    l_run += psum;
+
+    // ---- P^T fragments: lane (q, fh) needs keys ks*16 + fh*8 .. +8 -------------------------------------------
+    uint4 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int t = ks >> 1, g0 = (ks & 1) * 8;  // register group base (4 regs per group)
+      const uint32_t x0 = pack2<T>(s[t][g0 + 0], s[t][g0 + 1]);
+      const uint32_t x1 = pack2<T>(s[t][g0 + 2], s[t][g0 + 3]);
+      const uint32_t y0 = pack2<T>(s[t][g0 + 4], s[t][g0 + 5]);
+      const uint32_t y1 = pack2<T>(s[t][g0 + 6], s[t][g0 + 7]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      pf[ks] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+
+    // ---- O^T += V^T P^T -----------------------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(d * 32 + fr, ks * 2 + fh));
+        oacc[d] = Half16<T>::mfma32(vf, pf[ks], oacc[d]);
+      }
+    }
+
+    if (j + 1 < ntiles) swrite((j + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (q < T_) {
+    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HD;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 v;
+        v.x = pack2<T>(oacc[d][g4 * 4 + 0] * inv_l, oacc[d][g4 * 4 + 1] * inv_l);
+        v.y = pack2<T>(oacc[d][g4 * 4 + 2] * inv_l, oacc[d][g4 * 4 + 3] * inv_l);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
+      }
+  }
+}
+
+template <typename T, int MODE>
+static void launch_attn(const AttnArgs& a, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nq = (a.T + 127) / 128;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
+}
+
+}  // namespace la
+
+extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void* tabh, const void* tabw, float* relh,
+                               float* relw, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && tabh && tabw && relh && relw, "la_relpos_terms: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * la::HD, "la_relpos_terms: needs head_dim 64 and G <= 64 (G=%d E=%d heads=%d)",
+               G, E, heads);
+  const int waves = B * heads * G;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dt == LA_F16)
+    hipLaunchKernelGGL(la::relpos_kernel<la::f16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const la::f16_t*)qkv, B, heads, G, E,
+                       (const la::f16_t*)tabh, (const la::f16_t*)tabw, relh, relw);
+  else if (dt == LA_BF16)
+    hipLaunchKernelGGL(la::relpos_kernel<la::bf16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const la::bf16_t*)qkv, B, heads, G, E,
+                       (const la::bf16_t*)tabh, (const la::bf16_t*)tabw, relh, relw);
+  else LA_CHECK_ARG(false, "la_relpos_terms: bad dtype %d", dt);
+  LA_CHECK_LAUNCH("la_relpos_terms");
+  return 0;
+}
+
+extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, int B, int heads, int T,
+                           int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && vt && out16, "la_attn_fwd: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * la::HD, "la_attn_fwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd: bad dtype %d", dt);
+  la::AttnArgs a{qkv, vt, out16, relh, relw, B, heads, T, Tpad, G, E, scale};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t kv = 2 * la::KV_STAGE;
+  if (mode == LA_ATTN_PLAIN) {
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, kv, st);
+    else la::launch_attn<la::bf16_t, 0>(a, kv, st);
+  } else if (mode == LA_ATTN_RELPOS) {
+    LA_CHECK_ARG(relh && relw && G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
+    if (G == 64) {
+      const size_t lds = kv + 4 * 32 * 65 * sizeof(float);
+      if (dt == LA_F16) la::launch_attn<la::f16_t, 2>(a, lds, st);
+      else la::launch_attn<la::bf16_t, 2>(a, lds, st);
+    } else {
+      const size_t lds = kv + 4 * 2 * 32 * (G + 1) * sizeof(float) + (size_t)Tpad * sizeof(int);
+      if (dt == LA_F16) la::launch_attn<la::f16_t, 1>(a, lds, st);
+      else la::launch_attn<la::bf16_t, 1>(a, lds, st);
+    }
+  } else {
+    LA_CHECK_ARG(false, "la_attn_fwd: bad mode %d", mode);
+  }
+  LA_CHECK_LAUNCH("la_attn_fwd");
+  return 0;
+}

@@ -1,0 +1,257 @@
+"""GPU: every C-ABI kernel against a plain torch fp32 reference of the same op.
+
+Inputs are rounded to the 16-bit operand type first, so the only differences left are the
+accumulation order and the 16-bit rounding of outputs: tolerances are 2e-3 (f16) / 1.6e-2 (bf16)
+relative to the output's max magnitude for 16-bit outputs and 1e-3 / 2e-3 for fp32 outputs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import lam_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL16 = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}
+TOL32 = {torch.float16: 1e-3, torch.bfloat16: 4e-3}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from labelanything_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 200, 768), (128, 128, 64), (1024, 2304, 768), (77, 40, 288), (5, 256, 256)])
+def test_gemm_bias_act_residual(L, dt, mnk):
+    m, n, k = mnk
+    a = rnd(m, k, seed=1).to(dt)
+    w = (rnd(n, k, seed=2) / math.sqrt(k)).to(dt)
+    bias = rnd(n, seed=3)
+    res = rnd(m, n, seed=4)
+    ref = F.gelu(a.float() @ w.float().t() + bias) + res
+    o32 = torch.empty(m, n, device="cuda")
+    o16 = torch.empty(m, n, device="cuda", dtype=dt)
+    L.gemm(a, w, bias=bias, res=res, out32=o32, out16=o16, act=L.ACT_GELU)
+    torch.cuda.synchronize()
+    assert rel_err(o32, ref) < TOL32[dt]
+    assert rel_err(o16, ref) < TOL16[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_relu_and_res_mod(L, dt):
+    m, n, k = 4 * 196, 128, 768
+    a = rnd(m, k, seed=5).to(dt)
+    w = (rnd(n, k, seed=6) / math.sqrt(k)).to(dt)
+    pos = rnd(196, n, seed=7)
+    ref = torch.relu(a.float() @ w.float().t()) + pos.repeat(4, 1)
+    o32 = torch.empty(m, n, device="cuda")
+    L.gemm(a, w, res=pos, res_mod=196, out32=o32, act=L.ACT_RELU)
+    torch.cuda.synchronize()
+    assert rel_err(o32, ref) < TOL32[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_group_map_cls_gap(L, dt):
+    """HF ViT patch embedding: rows land after a CLS slot, pos-embed added by (dst_row % (hw+1))."""
+    bn, hw, n, k = 3, 25, 128, 768
+    a = rnd(bn * hw, k, seed=8).to(dt)
+    w = (rnd(n, k, seed=9) / math.sqrt(k)).to(dt)
+    pos = rnd(hw + 1, n, seed=10)
+    out = torch.zeros(bn * (hw + 1), n, device="cuda")
+    L.gemm(a, w, res=pos, res_mod=hw + 1, out32=out, map=L.MAP_GROUP, p=(hw, hw + 1, 1, 0, 0))
+    torch.cuda.synchronize()
+    ref = torch.zeros(bn, hw + 1, n, device="cuda")
+    ref[:, 1:] = (a.float() @ w.float().t()).view(bn, hw, n) + pos[1:]
+    assert rel_err(out.view(bn, hw + 1, n)[:, 1:], ref[:, 1:]) < TOL32[dt]
+    assert float(out.view(bn, hw + 1, n)[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_window_merge(L, dt):
+    """proj GEMM over window-partitioned rows + un-partition + shortcut add (image_encoder.py:189-194)."""
+    b, h, w_, ws, e = 2, 14, 14, 8, 128
+    xw_tokens = rnd(b * 4 * ws * ws, e, seed=11).to(dt)        # 2x2 windows of 8x8 per image
+    wt = (rnd(e, e, seed=12) / math.sqrt(e)).to(dt)
+    bias = rnd(e, seed=13)
+    shortcut = rnd(b * h * w_, e, seed=14)
+    out = torch.empty(b * h * w_, e, device="cuda")
+    L.gemm(xw_tokens, wt, bias=bias, res=shortcut, out32=out, map=L.MAP_WINDOW_MERGE, p=(ws, 2, 2, h, w_))
+    torch.cuda.synchronize()
+    y = (xw_tokens.float() @ wt.float().t() + bias).view(b * 4, ws, ws, e)
+    ref = O.window_merge(y.cpu(), ws, (16, 16), (h, w_)).reshape(b * h * w_, e).cuda() + shortcut
+    assert rel_err(out, ref) < TOL32[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cin,cout", [(256, 64), (64, 32), (64, 16)])
+def test_gemm_conv_transpose_pixel_shuffle(L, dt, cin, cout):
+    b, g = 2, 12
+    x = rnd(b, cin, g, g, seed=15).to(dt)
+    wt = (rnd(cin, cout, 2, 2, seed=16) / math.sqrt(cin)).to(dt)
+    bias = rnd(cout, seed=17)
+    ref = F.conv_transpose2d(x.float(), wt.float(), bias, stride=2).permute(0, 2, 3, 1).reshape(-1, cout)
+    a = x.permute(0, 2, 3, 1).reshape(b * g * g, cin).contiguous()
+    wg = wt.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous()       # rows (ky, kx, cout)
+    out = torch.empty(b * 4 * g * g, cout, device="cuda")
+    L.gemm(a, wg, bias=bias, out32=out, map=L.MAP_CONVT2X2, p=(g, g, cout, 0, 0))
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < TOL32[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("T", [196, 901])
+def test_gemm_v_transposed_epilogue(L, dt, T):
+    b, heads, e = 2, 2, 128
+    tpad = (T + 63) // 64 * 64
+    a = rnd(b * T, e, seed=18).to(dt)
+    w = (rnd(3 * e, e, seed=19) / math.sqrt(e)).to(dt)
+    bias = rnd(3 * e, seed=20)
+    qkv = torch.zeros(b * T, 3 * e, device="cuda", dtype=dt)
+    vt = torch.zeros(b * heads, 64, tpad, device="cuda", dtype=dt)
+    L.gemm(a, w, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=T, vt_Tpad=tpad, vt_hd=64, vt_heads=heads)
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().t() + bias
+    assert rel_err(qkv[:, : 2 * e], ref[:, : 2 * e]) < TOL16[dt]
+    v = ref[:, 2 * e:].view(b, T, heads, 64).permute(0, 2, 3, 1).reshape(b * heads, 64, T)
+    assert rel_err(vt[:, :, :T], v) < TOL16[dt]
+    assert float(vt[:, :, T:].float().abs().max()) == 0.0 if tpad > T else True
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("e", [768, 256, 128, 64, 32, 1024, 16, 8])
+def test_layernorm_variants(L, dt, e):
+    rows = 1000
+    x = rnd(rows, e, seed=21, scale=3.0) + 0.5
+    x2 = rnd(rows, e, seed=22)
+    g_, b_ = rnd(e, seed=23) * 0.1 + 1.0, rnd(e, seed=24) * 0.1
+    pe = rnd(250, e, seed=25)
+    ref = F.gelu(F.layer_norm(x + x2, (e,), g_, b_, 1e-6))
+    o32 = torch.empty(rows, e, device="cuda")
+    o16 = torch.empty(rows, e, device="cuda", dtype=dt)
+    o16pe = torch.empty(rows, e, device="cuda", dtype=dt)
+    L.layernorm(x, g_, b_, 1e-6, x2=x2, gelu=True, out32=o32, out16=o16, out16_pe=o16pe, pe=pe, pe_mod=250, dt=L._DT[dt])
+    torch.cuda.synchronize()
+    assert rel_err(o32, ref) < 1e-5
+    assert rel_err(o16, ref) < TOL16[dt]
+    assert rel_err(o16pe, ref + pe.repeat(4, 1)) < TOL16[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_layernorm_window_partition(L, dt):
+    b, h, w_, ws, e = 2, 14, 14, 8, 128
+    x = rnd(b * h * w_, e, seed=26)
+    g_, b_ = rnd(e, seed=27) * 0.1 + 1.0, rnd(e, seed=28) * 0.1
+    out = torch.zeros(b * 4 * ws * ws, e, device="cuda", dtype=dt)
+    L.layernorm(x, g_, b_, 1e-6, out16=out, window=ws, H=h, W=w_, dt=L._DT[dt])
+    torch.cuda.synchronize()
+    y = F.layer_norm(x, (e,), g_, b_, 1e-6).view(b, h, w_, e).cpu()
+    ref, _ = O.window_split(y, ws)
+    assert rel_err(out.view(-1, ws, ws, e), ref) < TOL16[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_patch_embed_as_gemm(L, dt):
+    bn, s, p, e = 2, 64, 16, 128
+    img = rnd(bn, 3, s, s, seed=29)
+    wt = (rnd(e, 3, p, p, seed=30) / math.sqrt(3 * p * p)).to(dt)
+    bias = rnd(e, seed=31)
+    g = s // p
+    a = torch.empty(bn * g * g, 3 * p * p, device="cuda", dtype=dt)
+    L.im2col_patch(img, p, a)
+    out = torch.empty(bn * g * g, e, device="cuda")
+    L.gemm(a, wt.reshape(e, -1), bias=bias, out32=out)
+    torch.cuda.synchronize()
+    ref = F.conv2d(img.to(dt).float(), wt.float(), bias, stride=p).permute(0, 2, 3, 1).reshape(-1, e)
+    assert rel_err(out, ref) < TOL32[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,co", [(256, 256), (32, 32), (8, 8)])
+def test_conv3x3_as_gemm(L, dt, c, co):
+    b, h, w_ = 2, 10, 12
+    x = rnd(b, c, h, w_, seed=32).to(dt)
+    wt = (rnd(co, c, 3, 3, seed=33) / math.sqrt(9 * c)).to(dt)
+    bias = rnd(co, seed=34)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    a = torch.empty(b * h * w_, 9 * c, device="cuda", dtype=dt)
+    L.im2col_3x3(xn, b, h, w_, c, a)
+    out = torch.empty(b * h * w_, co, device="cuda")
+    L.gemm(a, wt.permute(0, 2, 3, 1).reshape(co, 9 * c).contiguous(), bias=bias, out32=out)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float(), wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, co)
+    assert rel_err(out, ref) < TOL32[dt]
+
+
+def _attn_inputs(b, heads, t, dt, seed):
+    e = heads * 64
+    qkv = (rnd(b * t, 3 * e, seed=seed)).to(dt)
+    tpad = (t + 63) // 64 * 64
+    v = qkv[:, 2 * e:].view(b, t, heads, 64).permute(0, 2, 3, 1)           # (b, heads, 64, t)
+    vt = torch.zeros(b * heads, 64, tpad, device="cuda", dtype=dt)
+    vt[:, :, :t] = v.reshape(b * heads, 64, t)
+    return qkv, vt, e, tpad
+
+
+def _attn_ref(qkv, b, heads, t, bias=None):
+    e = heads * 64
+    q, k, v = [z.view(b, t, heads, 64).transpose(1, 2).float() for z in qkv.float().split(e, dim=1)]
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b * t, e)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("t", [901, 196, 64, 1000])
+def test_attention_plain(L, dt, t):
+    b, heads = 2, 2
+    qkv, vt, e, tpad = _attn_inputs(b, heads, t, dt, 40)
+    out = torch.empty(b * t, e, device="cuda", dtype=dt)
+    L.attn_fwd(qkv, vt, out, None, None, b, heads, t, tpad, 0, e, 0.125, L.ATTN_PLAIN)
+    torch.cuda.synchronize()
+    assert rel_err(out, _attn_ref(qkv, b, heads, t)) < TOL16[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("g", [64, 14, 8, 30])
+def test_relpos_terms_and_attention(L, dt, g):
+    b, heads = (2, 2) if g == 64 else (3, 2)
+    t = g * g
+    qkv, vt, e, tpad = _attn_inputs(b, heads, t, dt, 41)
+    tabh = (rnd(2 * g - 1, 64, seed=42) * 0.3).to(dt)
+    tabw = (rnd(2 * g - 1, 64, seed=43) * 0.3).to(dt)
+    relh = torch.zeros(b * heads, t, g, device="cuda")
+    relw = torch.zeros(b * heads, t, g, device="cuda")
+    L.relpos_terms(qkv, b, heads, g, e, tabh, tabw, relh, relw)
+    torch.cuda.synchronize()
+    q = qkv[:, :e].float().view(b, t, heads, 64).transpose(1, 2).reshape(b * heads, g, g, 64)
+    rh = O.rel_pos_table(g, g, tabh.float().cpu()).cuda()
+    rw = O.rel_pos_table(g, g, tabw.float().cpu()).cuda()
+    ref_h = torch.einsum("nyxc,ykc->nyxk", q, rh).reshape(b * heads, t, g)
+    ref_w = torch.einsum("nyxc,xkc->nyxk", q, rw).reshape(b * heads, t, g)
+    assert rel_err(relh, ref_h) < 1e-3
+    assert rel_err(relw, ref_w) < 1e-3
+    bias = (ref_h.view(b, heads, t, g, 1) + ref_w.view(b, heads, t, 1, g)).reshape(b, heads, t, t)
+    out = torch.empty(b * t, e, device="cuda", dtype=dt)
+    L.attn_fwd(qkv, vt, out, relh, relw, b, heads, t, tpad, g, e, 0.125, L.ATTN_RELPOS)
+    torch.cuda.synchronize()
+    assert rel_err(out, _attn_ref(qkv, b, heads, t, bias)) < TOL16[dt]
+
+
+def test_bad_arguments_raise(L):
+    a = torch.zeros(4, 12, device="cuda", dtype=torch.float16)
+    w = torch.zeros(4, 12, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        L.gemm(a, w, out32=torch.zeros(4, 4, device="cuda"))
