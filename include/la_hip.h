@@ -96,6 +96,61 @@ int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void*
 int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw,
                 int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, int dt, void* stream);
 
+/* ---- decoder side (prompt encoder + mask decoder) ------------------------------------------------------------- */
+
+/* Dense positional encoding of a g x g grid: out fp32 [g*g, D], channels [sin | cos]
+ * (PositionEmbeddingRandom.forward, prompt_encoder.py:213-224).  gauss: fp32 [2, D/2]. */
+int la_dense_pe(const float* gauss, int g, int D, float* out, void* stream);
+
+/* Sparse prompt tokens (points / box corners), prompt_encoder.py:83-114,599-611,648-669.
+ * xy fp32 [n,2] in input-image pixels; kind[n]: 0 NULL -> not_a_point_embed, 1 negative point, 2 positive point,
+ * 3 / 4 box corners, 5 the "no sparse prompt" token; shift[n] != 0 adds the half-pixel offset.
+ * type_emb fp32 [4, D] = point_embeddings.{0..3}.weight.  out32 fp32 [n, D]. */
+int la_point_embed(const float* xy, const int* kind, const int* shift, int n, int D, int image_size, const float* gauss,
+                   const float* type_emb, const float* not_a_point, const float* no_sparse, float* out32, void* stream);
+
+/* Fused dense-prompt path: mask_downscaling (2x conv2x2s2 + LN2d + GELU, conv1x1), bilinear 64->g, not_a_mask /
+ * no_mask replacement, + support features + class encoding (prompt_encoder.py:516-540,787-814, :250-262).
+ * masks fp32 [P, Hm, Hm] or NULL (no mask prompts); flags int32 [P] or NULL; P = B*M*C pairs, class = p % C,
+ * support image = p / C.  w: 12 device pointers {conv0.w, conv0.b, ln1.w, ln1.b, conv3.w, conv3.b, ln4.w, ln4.b,
+ * conv6.w [D,16], conv6.b, not_a_mask [D], no_mask [D]}.  support fp32 [P/C, g*g, D] (NHWC) or NULL;
+ * class_enc fp32 [C, D] or NULL; pe fp32 [g*g, D].  Outputs [P*g*g, D]: src32 (fp32 stream), src16, srcpe16 = src+pe. */
+int la_mask_embed(const float* masks, const int* flags, int P, int C, int Hm, int g, int D, const float* const* w,
+                  const float* support, const float* class_enc, const float* pe, float* src32, void* src16, void* srcpe16,
+                  int dt, void* stream);
+
+/* Decoder attention core after the q/k/v projections (common.py:126-144): softmax(q k^T / sqrt(hd)) v in fp32.
+ * q [B,Nq,ldq], k/v [B,Nk,ld*] fp32, head h at column h*hd; hd in {4,8,16,32,64}.  Output [B,Nq,ldo] 16-bit and/or fp32. */
+int la_attn_small(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int B, int Nq, int Nk, int heads,
+                  int hd, void* out16, float* out32, int ldo, int dt, void* stream);
+
+/* Mean over the hw rows of each [hw, D] slab: x fp32 [P, hw, D] -> out fp32 [P, D] (prompt_encoder.py:735-736). */
+int la_colmean(const float* x, int P, int hw, int D, float* out, void* stream);
+
+/* Class prototypes: masked mean over supports, divisor clamped to >= 1 (prompt_encoder.py:738-745).
+ * emb fp32 [B,M,C,D], flags u8 [B,M,C] -> out fp32 [B,C,D]. */
+int la_class_mean(const float* emb, const unsigned char* flags, int B, int M, int C, int D, float* out, void* stream);
+
+/* seg[b][c][pix] = protos[b][c] . feat[b][pix]; feat fp32 NHWC [B,Npix,Cf], protos fp32 [B,C,Cf], seg fp32 [B,C,Npix]
+ * (mask_decoder.py:299-314). Cf in {8,16,32,64}. */
+int la_classify(const float* feat, const float* protos, int B, int Npix, int C, int Cf, float* seg, void* stream);
+
+/* out = x + y[row % ymod] (y optional) as fp32 and/or 16-bit, contiguous [rows, D] (q = tokens + pe, transformer.py:305-326). */
+int la_add_cast(const float* x, const float* y, int ymod, long rows, int D, float* out32, void* out16, int dt, void* stream);
+
+/* Layout shuffles at the module boundary: NCHW fp32 <-> NHWC (the kernels work on [pixels, channels]). */
+int la_nchw_to_nhwc(const float* in, int N, int C, int HW, float* out32, void* out16, int dt, void* stream);
+int la_nhwc_to_nchw(const float* in, int N, int C, int HW, float* out, void* stream);
+
+/* F.interpolate(mode="bilinear", align_corners=False) on fp32 planes [N,h,w] -> [N,H,W] (lam.py:408-413). */
+int la_bilinear(const float* in, int N, int h, int w, int H, int W, float* out, void* stream);
+
+/* Second half of Lam.postprocess_masks + flag_gts masking + argmax (lam.py:415-453,92-93; run.py:697).
+ * big fp32 [B,C,S,S]; sizes int32 [B,4] = (orig_h, orig_w, crop_h, crop_w); flag_gts u8 [B,C] or NULL.
+ * logits fp32 [B,C,Hmax,Wmax] and/or argmax int64 [B,Hmax,Wmax]. */
+int la_post_final(const float* big, int B, int C, int S, const int* sizes, const unsigned char* flag_gts, int Hmax, int Wmax,
+                  float* logits, long long* argmax, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,8 @@ def lib() -> C.CDLL:
 # every symbol include/la_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
+    "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
+    "la_classify", "la_add_cast", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
 ]
 
 
@@ -141,3 +143,76 @@ def attn_fwd(qkv, vt, out16, relh, relw, b: int, heads: int, t: int, tpad: int, 
     _check(lib().la_attn_fwd(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), C.c_int(b), C.c_int(heads), C.c_int(t),
                              C.c_int(tpad), C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(mode), C.c_int(dt_of(qkv)),
                              _stream()), "la_attn_fwd")
+
+
+# ---- decoder side ---------------------------------------------------------------------------------
+def dense_pe(gauss: torch.Tensor, g: int, d: int, out: torch.Tensor) -> None:
+    _dev(gauss)
+    _check(lib().la_dense_pe(_ptr(gauss), C.c_int(g), C.c_int(d), _ptr(out), _stream()), "la_dense_pe")
+
+
+def point_embed(xy, kind, shift, d: int, image_size: int, gauss, type_emb, not_a_point, no_sparse, out32) -> None:
+    _dev(xy)
+    _check(lib().la_point_embed(_ptr(xy), _ptr(kind), _ptr(shift), C.c_int(kind.numel()), C.c_int(d), C.c_int(image_size),
+                                _ptr(gauss), _ptr(type_emb), _ptr(not_a_point), _ptr(no_sparse), _ptr(out32), _stream()),
+           "la_point_embed")
+
+
+def mask_embed(masks, flags, p: int, c: int, hm: int, g: int, d: int, wlist, support, class_enc, pe, src32, src16, srcpe16,
+               dt: int) -> None:
+    arr = (C.c_void_p * 12)(*[w.data_ptr() for w in wlist])
+    _check(lib().la_mask_embed(_ptr(masks), _ptr(flags), C.c_int(p), C.c_int(c), C.c_int(hm), C.c_int(g), C.c_int(d), arr,
+                               _ptr(support), _ptr(class_enc), _ptr(pe), _ptr(src32), _ptr(src16), _ptr(srcpe16), C.c_int(dt),
+                               _stream()), "la_mask_embed")
+
+
+def attn_small(q, k, v, b: int, nq: int, nk: int, heads: int, hd: int, *, out16=None, out32=None, dt: int = LA_F16) -> None:
+    """q/k/v: fp32 2-D views [rows, ld] (row stride = ld, head h at column h*hd)."""
+    _dev(q)
+    o = out16 if out16 is not None else out32
+    _check(lib().la_attn_small(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), _ptr(v), C.c_int(v.stride(0)),
+                               C.c_int(b), C.c_int(nq), C.c_int(nk), C.c_int(heads), C.c_int(hd), _ptr(out16), _ptr(out32),
+                               C.c_int(o.stride(0)), C.c_int(dt), _stream()), "la_attn_small")
+
+
+def colmean(x, p: int, hw: int, d: int, out) -> None:
+    _check(lib().la_colmean(_ptr(x), C.c_int(p), C.c_int(hw), C.c_int(d), _ptr(out), _stream()), "la_colmean")
+
+
+def class_mean(emb, flags_u8, b: int, m: int, c: int, d: int, out) -> None:
+    _check(lib().la_class_mean(_ptr(emb), _ptr(flags_u8), C.c_int(b), C.c_int(m), C.c_int(c), C.c_int(d), _ptr(out), _stream()),
+           "la_class_mean")
+
+
+def classify(feat, protos, b: int, npix: int, c: int, cf: int, seg) -> None:
+    _check(lib().la_classify(_ptr(feat), _ptr(protos), C.c_int(b), C.c_int(npix), C.c_int(c), C.c_int(cf), _ptr(seg), _stream()),
+           "la_classify")
+
+
+def add_cast(x, y=None, ymod: int = 0, *, out32=None, out16=None, dt: int = LA_F16) -> None:
+    _dev(x)
+    rows, d = x.shape[0], x.shape[1]
+    _check(lib().la_add_cast(_ptr(x), _ptr(y), C.c_int(ymod), C.c_long(rows), C.c_int(d), _ptr(out32), _ptr(out16), C.c_int(dt),
+                             _stream()), "la_add_cast")
+
+
+def nchw_to_nhwc(x, n: int, c: int, hw: int, *, out32=None, out16=None, dt: int = LA_F16) -> None:
+    _dev(x)
+    _check(lib().la_nchw_to_nhwc(_ptr(x), C.c_int(n), C.c_int(c), C.c_int(hw), _ptr(out32), _ptr(out16), C.c_int(dt), _stream()),
+           "la_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(x, n: int, c: int, hw: int, out) -> None:
+    _dev(x)
+    _check(lib().la_nhwc_to_nchw(_ptr(x), C.c_int(n), C.c_int(c), C.c_int(hw), _ptr(out), _stream()), "la_nhwc_to_nchw")
+
+
+def bilinear(x, n: int, h: int, w: int, oh: int, ow: int, out) -> None:
+    _dev(x)
+    _check(lib().la_bilinear(_ptr(x), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(oh), C.c_int(ow), _ptr(out), _stream()),
+           "la_bilinear")
+
+
+def post_final(big, b: int, c: int, s: int, sizes_i32, flag_gts_u8, hmax: int, wmax: int, logits, argmax) -> None:
+    _check(lib().la_post_final(_ptr(big), C.c_int(b), C.c_int(c), C.c_int(s), _ptr(sizes_i32), _ptr(flag_gts_u8), C.c_int(hmax),
+                               C.c_int(wmax), _ptr(logits), _ptr(argmax), _stream()), "la_post_final")

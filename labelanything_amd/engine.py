@@ -1,0 +1,620 @@
+"""LamEngine: composes the libla_hip.so kernels into the LabelAnything inference path.
+
+Data layout in HBM (all device-resident, reused across calls through a shape-keyed arena):
+  * activations are row-major [pixels | tokens, channels] (NHWC); the fp32 residual stream is kept in fp32,
+    every GEMM operand is a 16-bit copy written by the producing kernel's epilogue;
+  * weights are repacked once per (device, dtype): nn.Linear layout [N, K] in 16 bit, conv weights flattened
+    to the im2col column order, ConvTranspose2d(k2,s2) as [(ky,kx,cout), cin], q/k/v projections concatenated;
+  * the SAM V operand is written pre-transposed ([b*heads, 64, Tpad]) by the qkv GEMM epilogue.
+
+Each method cites the reference code it replaces (/root/reference/label_anything/...).
+PyTorch is used for device memory, views/copies and the host-side prompt bookkeeping only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from .config import LamConfig, EncoderSpec
+
+Tensor = torch.Tensor
+
+
+def _ceil(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Arena:
+    """Shape-keyed cache of device buffers (no allocation in steady state; zero-filled buffers keep their padding)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.bufs: Dict[tuple, Tensor] = {}
+
+    def get(self, name: str, shape, dtype, zero: bool = False) -> Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            try:
+                t = (torch.zeros if zero else torch.empty)(tuple(shape), device=self.device, dtype=dtype)
+            except RuntimeError as e:  # keep the substring the reference's OOM handler looks for (run.py:339-340)
+                raise RuntimeError(f"HIP out of memory allocating {name}{tuple(shape)}: {e}") from e
+            self.bufs[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class LamEngine:
+    def __init__(self, cfg: LamConfig, weights: Dict[str, Tensor], device: torch.device, dtype: torch.dtype = torch.float16):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+        L.lib()  # fail loudly if the HIP extension is missing
+        self.cfg = cfg
+        self.dev = device
+        self.dt = dtype
+        self.dti = L._DT[dtype]
+        self.arena = Arena(device)
+        self.w32: Dict[str, Tensor] = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in weights.items()}
+        self.p: Dict[str, Tensor] = {}
+        self._pe_cache: Dict[int, Tensor] = {}
+        self._hfpos_cache: Dict[int, Tensor] = {}
+        self._pack()
+
+    # ------------------------------------------------------------------------------------------------
+    # weight packing (one-time layout transforms)
+    # ------------------------------------------------------------------------------------------------
+    def _h(self, t: Tensor) -> Tensor:
+        return t.to(self.dt).contiguous()
+
+    def _pack_attn(self, pre: str, fuse: str) -> None:
+        """decoder Attention (common.py:57-148).  fuse: 'qkv' (same input), 'qk' (q,k share input), 'none'."""
+        w, p = self.w32, self.p
+        if fuse == "qkv":
+            p[pre + ".qkv.w"] = self._h(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"], w[pre + ".v_proj.weight"]]))
+            p[pre + ".qkv.b"] = torch.cat([w[pre + ".q_proj.bias"], w[pre + ".k_proj.bias"], w[pre + ".v_proj.bias"]]).contiguous()
+        if fuse == "qk":
+            p[pre + ".qk.w"] = self._h(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"]]))
+            p[pre + ".qk.b"] = torch.cat([w[pre + ".q_proj.bias"], w[pre + ".k_proj.bias"]]).contiguous()
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            p[f"{pre}.{n}.w"] = self._h(w[f"{pre}.{n}.weight"])
+
+    def _pack_mlp(self, pre: str) -> None:
+        self.p[pre + ".lin1.w"] = self._h(self.w32[pre + ".lin1.weight"])
+        self.p[pre + ".lin2.w"] = self._h(self.w32[pre + ".lin2.weight"])
+
+    def _pack_two_way(self, pre: str) -> None:
+        for l in range(2):
+            lp = f"{pre}.layers.{l}"
+            self._pack_attn(lp + ".self_attn", "qkv" if l == 0 else "qk")
+            self._pack_attn(lp + ".cross_attn_token_to_image", "none")
+            self._pack_attn(lp + ".cross_attn_image_to_token", "none")
+            self._pack_mlp(lp + ".mlp")
+        self._pack_attn(pre + ".final_attn_token_to_image", "none")
+
+    def _pack_conv_neck(self, pre: str) -> None:
+        w = self.w32
+        self.p[pre + ".0.w"] = self._h(w[pre + ".0.weight"].flatten(1))
+        self.p[pre + ".2.w"] = self._h(w[pre + ".2.weight"].permute(0, 2, 3, 1).flatten(1))   # [Cout, (ky,kx,cin)]
+
+    def _pack(self) -> None:
+        cfg, w, p = self.cfg, self.w32, self.p
+        spec = cfg.encoder_spec
+        if spec is not None and spec.kind == "sam":
+            pre = "image_encoder"
+            p[pre + ".patch.w"] = self._h(w[pre + ".patch_embed.proj.weight"].flatten(1))
+            p[pre + ".pos"] = w[pre + ".pos_embed"].reshape(-1, spec.dim).contiguous()
+            g = spec.img_size // spec.patch
+            for i in range(spec.depth):
+                bp = f"{pre}.blocks.{i}"
+                p[bp + ".qkv.w"] = self._h(w[bp + ".attn.qkv.weight"])
+                p[bp + ".proj.w"] = self._h(w[bp + ".attn.proj.weight"])
+                p[bp + ".lin1.w"] = self._h(w[bp + ".mlp.lin1.weight"])
+                p[bp + ".lin2.w"] = self._h(w[bp + ".mlp.lin2.weight"])
+                size = g if i in spec.global_idx else spec.window
+                for ax in ("h", "w"):
+                    tab = w[f"{bp}.attn.rel_pos_{ax}"]
+                    if tab.shape[0] != 2 * size - 1:   # get_rel_pos linear resampling (image_encoder.py:321-330), constant per model
+                        tab = F.interpolate(tab.t().unsqueeze(0), size=2 * size - 1, mode="linear")[0].t()
+                    p[f"{bp}.tab{ax}"] = self._h(tab)
+            self._pack_conv_neck(pre + ".neck")
+        elif spec is not None and spec.kind == "hf":
+            pre = "image_encoder"
+            p[pre + ".patch.w"] = self._h(w[pre + ".embeddings.patch_embeddings.projection.weight"].flatten(1))
+            for i in range(spec.depth):
+                lp = f"{pre}.encoder.layer.{i}"
+                p[lp + ".qkv.w"] = self._h(torch.cat([w[lp + ".attention.attention.query.weight"],
+                                                      w[lp + ".attention.attention.key.weight"],
+                                                      w[lp + ".attention.attention.value.weight"]]))
+                p[lp + ".qkv.b"] = torch.cat([w[lp + ".attention.attention.query.bias"], w[lp + ".attention.attention.key.bias"],
+                                              w[lp + ".attention.attention.value.bias"]]).contiguous()
+                p[lp + ".o.w"] = self._h(w[lp + ".attention.output.dense.weight"])
+                p[lp + ".fc1.w"] = self._h(w[lp + ".intermediate.dense.weight"])
+                p[lp + ".fc2.w"] = self._h(w[lp + ".output.dense.weight"])
+        if cfg.lam_neck:
+            self._pack_conv_neck("neck")
+        pe = "prompt_encoder"
+        p[pe + ".type_emb"] = torch.cat([w[f"{pe}.point_embeddings.{i}.weight"] for i in range(4)]).contiguous()
+        p[pe + ".mask_w"] = [w[pe + ".mask_downscaling.0.weight"].contiguous(), w[pe + ".mask_downscaling.0.bias"],
+                             w[pe + ".mask_downscaling.1.weight"], w[pe + ".mask_downscaling.1.bias"],
+                             w[pe + ".mask_downscaling.3.weight"].contiguous(), w[pe + ".mask_downscaling.3.bias"],
+                             w[pe + ".mask_downscaling.4.weight"], w[pe + ".mask_downscaling.4.bias"],
+                             w[pe + ".mask_downscaling.6.weight"].flatten(1).contiguous(), w[pe + ".mask_downscaling.6.bias"],
+                             w[pe + ".not_a_mask_embed.weight"].flatten().contiguous(), w[pe + ".no_mask_embed.weight"].flatten().contiguous()]
+        self._pack_two_way(pe + ".transformer")
+        for blk in ("sparse_embedding_attention", "class_attention", "class_example_attention", "example_attention"):
+            if f"{pe}.{blk}.norm.weight" in w:
+                self._pack_attn(f"{pe}.{blk}.attn", "qkv")
+                self._pack_mlp(f"{pe}.{blk}.mlp")
+        md = "mask_decoder"
+        self._pack_two_way(md + ".transformer")
+        for i in range(3):
+            p[f"{md}.class_mlp.{i}.w"] = self._h(w[f"{md}.class_mlp.layers.{i}.weight"])
+        # ConvTranspose2d weight (Cin, Cout, 2, 2) -> GEMM weight [(ky, kx, cout), cin]
+        p[md + ".up0.w"] = self._h(w[md + ".output_upscaling.0.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+        p[md + ".up3.w"] = self._h(w[md + ".output_upscaling.3.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+        if cfg.spatial_convs:
+            for i in range(cfg.spatial_convs):
+                p[f"{md}.sc{i}.w"] = self._h(w[f"{md}.spatial_convs.{3 * i}.weight"].permute(0, 2, 3, 1).flatten(1))
+
+    # ------------------------------------------------------------------------------------------------
+    # small helpers
+    # ------------------------------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=None, zero=False) -> Tensor:
+        return self.arena.get(name, shape, self.dt if dtype is None else dtype, zero)
+
+    def f32(self, name, shape, zero=False) -> Tensor:
+        return self.arena.get(name, shape, torch.float32, zero)
+
+    def dense_pe(self, g: int) -> Tensor:
+        """[g*g, D] fp32, cached per grid (input independent; prompt_encoder.py:213-224)."""
+        t = self._pe_cache.get(g)
+        if t is None:
+            t = torch.empty(g * g, self.cfg.embed_dim, device=self.dev, dtype=torch.float32)
+            L.dense_pe(self.w32["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"], g, self.cfg.embed_dim, t)
+            self._pe_cache[g] = t
+        return t
+
+    def ln(self, x, name, eps, **kw):
+        L.layernorm(x, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
+
+    # ------------------------------------------------------------------------------------------------
+    # conv neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d on NHWC rows (image_encoder.py:92-108, build_lam.py:150-171)
+    # ------------------------------------------------------------------------------------------------
+    def conv_neck(self, pre: str, x16: Tensor, bn: int, g: int, tag: str) -> Tensor:
+        cout = self.p[pre + ".0.w"].shape[0]
+        rows = bn * g * g
+        a = self.f32(tag + ".n0", (rows, cout))
+        L.gemm(x16, self.p[pre + ".0.w"], out32=a)
+        a16 = self.buf(tag + ".n1", (rows, cout))
+        self.ln(a, pre + ".1", 1e-6, out16=a16)
+        col = self.buf(tag + ".col", (rows, 9 * cout))
+        L.im2col_3x3(a16, bn, g, g, cout, col)
+        L.gemm(col, self.p[pre + ".2.w"], out32=a)
+        out = self.f32(tag + ".out", (rows, cout))
+        self.ln(a, pre + ".3", 1e-6, out32=out)
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    # SAM ViTDet encoder (image_encoder.py:110-131,179-197,200-255)
+    # ------------------------------------------------------------------------------------------------
+    def sam_encoder(self, images: Tensor, want_last_block: bool = False):
+        spec: EncoderSpec = self.cfg.encoder_spec
+        pre = "image_encoder"
+        bn, _, s, _ = images.shape
+        if s != spec.img_size:
+            raise ValueError(f"SAM encoder expects {spec.img_size}x{spec.img_size} inputs, got {s}")
+        e, heads, g, ws = spec.dim, spec.heads, s // spec.patch, spec.window
+        hw = g * g
+        rows = bn * hw
+        scale = spec.head_dim ** -0.5
+        w, p = self.w32, self.p
+        images = images.contiguous()
+        a = self.buf("enc.patchA", (rows, 3 * spec.patch * spec.patch))
+        L.im2col_patch(images, spec.patch, a)
+        res = self.f32("enc.res", (rows, e))
+        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res)
+        nwy = (g + ws - 1) // ws
+        x16 = self.buf("enc.x16", (rows, e))
+        last16 = None
+        for i in range(spec.depth):
+            bp = f"{pre}.blocks.{i}"
+            is_global = i in spec.global_idx
+            if is_global:
+                nb, t, gg, arows = bn, hw, g, rows
+                xin = x16
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin)
+            else:
+                nb, t, gg = bn * nwy * nwy, ws * ws, ws
+                arows = nb * t
+                xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g)
+            tpad = _ceil(t, 64)
+            tag = "g" if is_global else "w"
+            qkv = self.buf("enc.qkv." + tag, (arows, 3 * e))
+            vt = self.buf("enc.vt." + tag, (nb * heads, 64, tpad), zero=True)
+            L.gemm(xin, p[bp + ".qkv.w"], bias=w[bp + ".attn.qkv.bias"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t,
+                   vt_Tpad=tpad, vt_hd=64, vt_heads=heads)
+            relh = self.f32("enc.relh." + tag, (nb * heads, t, gg))
+            relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
+            L.relpos_terms(qkv, nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
+            ao = self.buf("enc.ao." + tag, (arows, e))
+            L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS)
+            if is_global:
+                L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
+            else:
+                L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res,
+                       map=L.MAP_WINDOW_MERGE, p=(ws, nwy, nwy, g, g))
+            self.ln(res, bp + ".norm2", 1e-6, out16=x16)
+            hbuf = self.buf("enc.mlp", (rows, spec.mlp))
+            L.gemm(x16, p[bp + ".lin1.w"], bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
+            if i == spec.depth - 1:
+                last16 = self.buf("enc.last16", (rows, e))
+                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=last16)
+            else:
+                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
+        if not self.cfg.use_vit_sam_neck:
+            return (res, last16, e) if not want_last_block else ((res, last16, e), res)
+        out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck")
+        if want_last_block:
+            return (out, None, spec.out_chans), res
+        return out, None, spec.out_chans
+
+    # ------------------------------------------------------------------------------------------------
+    # HuggingFace plain ViT encoder (transformers ViTModel maths; build_encoder.py:83-100)
+    # ------------------------------------------------------------------------------------------------
+    def _hf_pos(self, g: int) -> Tensor:
+        t = self._hfpos_cache.get(g)
+        if t is None:
+            spec = self.cfg.encoder_spec
+            pos = self.w32["image_encoder.embeddings.position_embeddings"]
+            if g != spec.pos_grid:  # bicubic resample of the patch positions (constant per resolution)
+                e = pos.shape[-1]
+                grid = pos[:, 1:].reshape(1, spec.pos_grid, spec.pos_grid, e).permute(0, 3, 1, 2)
+                grid = F.interpolate(grid, size=(g, g), mode="bicubic", align_corners=False)
+                pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, g * g, e)], dim=1)
+            t = pos[0].contiguous()
+            cls_row = (self.w32["image_encoder.embeddings.cls_token"][0, 0] + t[0]).contiguous()
+            self._hfpos_cache[g] = t
+            self._hfpos_cache[-g] = cls_row
+        return t
+
+    def hf_encoder(self, images: Tensor):
+        spec: EncoderSpec = self.cfg.encoder_spec
+        pre = "image_encoder"
+        bn, _, s, _ = images.shape
+        e, heads, g = spec.dim, spec.heads, s // spec.patch
+        hw = g * g
+        t = hw + 1
+        rows = bn * t
+        w, p = self.w32, self.p
+        pos = self._hf_pos(g)
+        cls_row = self._hfpos_cache[-g]
+        images = images.contiguous()
+        a = self.buf("hf.patchA", (bn * hw, 3 * spec.patch * spec.patch))
+        L.im2col_patch(images, spec.patch, a)
+        res = self.f32("hf.res", (rows, e))
+        res.view(bn, t, e)[:, 0].copy_(cls_row)      # CLS row = cls_token + pos[0] (weights only; plain copy)
+        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".embeddings.patch_embeddings.projection.bias"], res=pos, res_mod=t,
+               out32=res, map=L.MAP_GROUP, p=(hw, t, 1, 0, 0))
+        tpad = _ceil(t, 64)
+        x16 = self.buf("hf.x16", (rows, e))
+        qkv = self.buf("hf.qkv", (rows, 3 * e))
+        vt = self.buf("hf.vt", (bn * heads, 64, tpad), zero=True)
+        ao = self.buf("hf.ao", (rows, e))
+        hbuf = self.buf("hf.mlp", (rows, spec.mlp))
+        scale = spec.head_dim ** -0.5
+        for i in range(spec.depth):
+            lp = f"{pre}.encoder.layer.{i}"
+            self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
+            L.gemm(x16, p[lp + ".qkv.w"], bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=tpad,
+                   vt_hd=64, vt_heads=heads)
+            L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, e, scale, L.ATTN_PLAIN)
+            L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
+            self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
+            L.gemm(x16, p[lp + ".fc1.w"], bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)
+            L.gemm(hbuf, p[lp + ".fc2.w"], bias=w[lp + ".output.dense.bias"], res=res, out32=res)
+        fin = self.f32("hf.final", (rows, e))
+        fin16 = self.buf("hf.final16", (rows, e))
+        self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16)
+        out32 = self.f32("hf.out32", (bn * hw, e))
+        out16 = self.buf("hf.out16", (bn * hw, e))
+        out32.view(bn, hw, e).copy_(fin.view(bn, t, e)[:, 1:])          # drop CLS (plain strided copy)
+        out16.view(bn, hw, e).copy_(fin16.view(bn, t, e)[:, 1:])
+        return out32, out16, e
+
+    def encode_images(self, images: Tensor):
+        """(Bn,3,S,S) fp32 -> (emb32 [Bn*hw, C] NHWC fp32, emb16 or None, C, g)."""
+        spec = self.cfg.encoder_spec
+        if spec is None:
+            raise ValueError("this model was built without an image encoder (use_vit=False)")
+        if spec.kind == "sam":
+            out32, out16, c = self.sam_encoder(images)
+        else:
+            out32, out16, c = self.hf_encoder(images)
+        return out32, out16, c, images.shape[-1] // spec.patch
+
+    def lam_neck(self, emb32: Tensor, emb16: Optional[Tensor], bn: int, g: int) -> Tensor:
+        if emb16 is None:
+            emb16 = self.buf("neck.in16", tuple(emb32.shape))
+            L.add_cast(emb32, out16=emb16, dt=self.dti)
+        return self.conv_neck("neck", emb16, bn, g, "lamneck")
+
+    # ------------------------------------------------------------------------------------------------
+    # decoder attention building blocks
+    # ------------------------------------------------------------------------------------------------
+    def _attn_core(self, q32, k32, v32, groups, nq, nk, internal, tag) -> Tensor:
+        heads = self.cfg.dec_heads
+        o16 = self.buf(tag + ".o16", (groups * nq, internal))
+        L.attn_small(q32, k32, v32, groups, nq, nk, heads, internal // heads, out16=o16, dt=self.dti)
+        return o16
+
+    def attention_mlp_block(self, pre: str, x32: Tensor, groups: int, n: int, tag: str) -> Tensor:
+        """AttentionMLPBlock (common.py:151-184): y = LN(attn(x)+x); out = LN(mlp(y)+y), one shared LayerNorm, GELU."""
+        w, p = self.w32, self.p
+        rows, d = x32.shape
+        internal = p[pre + ".attn.q_proj.w"].shape[0]
+        x16 = self.buf(tag + ".x16", (rows, d))
+        L.add_cast(x32, out16=x16, dt=self.dti)
+        qkv = self.f32(tag + ".qkv", (rows, 3 * internal))
+        L.gemm(x16, p[pre + ".attn.qkv.w"], bias=p[pre + ".attn.qkv.b"], out32=qkv)
+        o16 = self._attn_core(qkv[:, :internal], qkv[:, internal:2 * internal], qkv[:, 2 * internal:], groups, n, n, internal, tag)
+        y = self.f32(tag + ".y", (rows, d))
+        L.gemm(o16, p[pre + ".attn.out_proj.w"], bias=w[pre + ".attn.out_proj.bias"], res=x32, out32=y)
+        y16 = self.buf(tag + ".y16", (rows, d))
+        self.ln(y, pre + ".norm", 1e-5, out32=y, out16=y16)
+        hbuf = self.buf(tag + ".h", (rows, self.cfg.dec_mlp))
+        L.gemm(y16, p[pre + ".mlp.lin1.w"], bias=w[pre + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
+        z = self.f32(tag + ".z", (rows, d))
+        L.gemm(hbuf, p[pre + ".mlp.lin2.w"], bias=w[pre + ".mlp.lin2.bias"], res=y, out32=z)
+        self.ln(z, pre + ".norm", 1e-5, out32=z)
+        return z
+
+    def two_way(self, pre: str, tok32: Tensor, groups: int, nt: int, img32: Tensor, img16: Tensor, imgpe16: Tensor, hw: int,
+                pe32: Tensor, tag: str, want_tokens: bool):
+        """TwoWayTransformer (transformer.py:206-329).  tok32 [groups*nt, D] fp32 (also the token PE); image side
+        [groups*hw, D] as fp32 stream + 16-bit copies (x and x+pe), updated in place.  Returns (tokens32, tokens16)."""
+        w, p, cfg = self.w32, self.p, self.cfg
+        d = cfg.embed_dim
+        di = d // 2
+        r = groups * nt
+        ri = groups * hw
+        tpe = tok32
+        t32 = self.f32(tag + ".t32", (r, d))
+        t16 = self.buf(tag + ".t16", (r, d))
+        tq16 = self.buf(tag + ".tq16", (r, d))
+        tnew = self.f32(tag + ".tnew", (r, d))
+        for l in range(2):
+            lp = f"{pre}.layers.{l}"
+            sa = lp + ".self_attn"
+            if l == 0:
+                L.add_cast(tok32, out16=t16, dt=self.dti)
+                qkv = self.f32(tag + ".sa_qkv", (r, 3 * d))
+                L.gemm(t16, p[sa + ".qkv.w"], bias=p[sa + ".qkv.b"], out32=qkv)
+                o16 = self._attn_core(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], groups, nt, nt, d, tag + ".sa")
+                L.gemm(o16, p[sa + ".out_proj.w"], bias=w[sa + ".out_proj.bias"], out32=tnew)      # replaces the tokens
+            else:
+                qk = self.f32(tag + ".sa_qk", (r, 2 * d))
+                L.gemm(tq16, p[sa + ".qk.w"], bias=p[sa + ".qk.b"], out32=qk)
+                v = self.f32(tag + ".sa_v", (r, d))
+                L.gemm(t16, p[sa + ".v_proj.w"], bias=w[sa + ".v_proj.bias"], out32=v)
+                o16 = self._attn_core(qk[:, :d], qk[:, d:], v, groups, nt, nt, d, tag + ".sa")
+                L.gemm(o16, p[sa + ".out_proj.w"], bias=w[sa + ".out_proj.bias"], res=t32, out32=tnew)
+            self.ln(tnew, lp + ".norm1", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
+            # tokens -> image
+            ca = lp + ".cross_attn_token_to_image"
+            q = self.f32(tag + ".tq", (r, di))
+            L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
+            k = self.f32(tag + ".ik", (ri, di))
+            v = self.f32(tag + ".iv", (ri, di))
+            L.gemm(imgpe16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=k)
+            L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
+            o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
+            L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
+            self.ln(tnew, lp + ".norm2", 1e-5, out32=t32, out16=t16)
+            # MLP (ReLU)
+            hbuf = self.buf(tag + ".mlp", (r, cfg.dec_mlp))
+            L.gemm(t16, p[lp + ".mlp.lin1.w"], bias=w[lp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_RELU)
+            L.gemm(hbuf, p[lp + ".mlp.lin2.w"], bias=w[lp + ".mlp.lin2.bias"], res=t32, out32=tnew)
+            self.ln(tnew, lp + ".norm3", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
+            # image -> tokens
+            ca = lp + ".cross_attn_image_to_token"
+            qi = self.f32(tag + ".iq", (ri, di))
+            L.gemm(imgpe16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=qi)
+            kt = self.f32(tag + ".tk", (r, di))
+            vtok = self.f32(tag + ".tv", (r, di))
+            L.gemm(tq16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=kt)
+            L.gemm(t16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=vtok)
+            oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t")
+            L.gemm(oi16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
+            self.ln(img32, lp + ".norm4", 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32, pe_mod=hw)
+        if not want_tokens:
+            return None, None
+        ca = pre + ".final_attn_token_to_image"
+        q = self.f32(tag + ".tq", (r, di))
+        L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
+        k = self.f32(tag + ".ik", (ri, di))
+        v = self.f32(tag + ".iv", (ri, di))
+        L.gemm(imgpe16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=k)
+        L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
+        o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
+        L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
+        self.ln(tnew, pre + ".norm_final_attn", 1e-5, out32=t32, out16=t16)
+        return t32, t16
+
+    # ------------------------------------------------------------------------------------------------
+    # prompt encoder (prompt_encoder.py:564-827)
+    # ------------------------------------------------------------------------------------------------
+    def _sparse_tokens(self, b, m, c, points, boxes) -> Tuple[Tensor, int]:
+        """Host-side bookkeeping of the sparse prompt tokens -> (xy, kind, shift) device arrays (index work only)."""
+        dev = self.dev
+        pcount = b * m * c
+        parts_xy, parts_kind, parts_shift = [], [], []
+        if points is not None:
+            xy, lab = points
+            xy = xy.reshape(pcount, -1, 2).to(dev, torch.float32)
+            lab = lab.reshape(pcount, -1).to(dev)
+            kind = torch.where(lab == 0, 0, torch.where(lab < 0, 1, 2)).to(torch.int32)
+            shift = torch.ones_like(kind)
+            if boxes is None:   # extra token at (0,0), label -1 == NEGATIVE in this code base, not shifted (prompt_encoder.py:91-95)
+                xy = torch.cat([xy, torch.zeros(pcount, 1, 2, device=dev)], dim=1)
+                kind = torch.cat([kind, torch.ones(pcount, 1, dtype=torch.int32, device=dev)], dim=1)
+                shift = torch.cat([shift, torch.zeros(pcount, 1, dtype=torch.int32, device=dev)], dim=1)
+            parts_xy.append(xy); parts_kind.append(kind); parts_shift.append(shift)
+        if boxes is not None:
+            bx, bf = boxes
+            nb = bx.shape[3]
+            corners = bx.reshape(pcount, nb * 2, 2).to(dev, torch.float32)
+            kind = torch.tensor([3, 4], dtype=torch.int32, device=dev).repeat(nb).expand(pcount, -1)
+            flags2 = bf.reshape(pcount, nb).to(dev).repeat(1, 2)            # tiled flags vs interleaved corners (:661-667)
+            kind = torch.where(flags2 == 0, 0, kind).to(torch.int32)
+            parts_xy.append(corners); parts_kind.append(kind); parts_shift.append(torch.ones_like(kind))
+        if not parts_xy:
+            xy = torch.zeros(pcount, 1, 2, device=dev)
+            kind = torch.full((pcount, 1), 5, dtype=torch.int32, device=dev)
+            shift = torch.zeros_like(kind)
+        else:
+            xy, kind, shift = torch.cat(parts_xy, 1), torch.cat(parts_kind, 1), torch.cat(parts_shift, 1)
+        ns = kind.shape[1]
+        return (xy.contiguous(), kind.contiguous(), shift.contiguous()), ns
+
+    def prompt_encoder(self, support32: Tensor, b: int, m: int, g: int, points, boxes, masks, flag_examples: Tensor,
+                       selected_rows: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """support32: [B*M*hw, D] NHWC fp32.  Returns class_embeddings (B,C,D), class_examples_embeddings (B,M,C,D),
+        class_examples_src (P, hw, D) NHWC."""
+        cfg, w, p = self.cfg, self.w32, self.p
+        pe_ = "prompt_encoder"
+        d = cfg.embed_dim
+        first = points[0] if points is not None else boxes[0] if boxes is not None else masks[0] if masks is not None else None
+        if first is None:
+            raise ValueError("No prompts provided")
+        c = first.shape[2]
+        pcount = b * m * c
+        hw = g * g
+        # sparse tokens
+        (xy, kind, shift), ns = self._sparse_tokens(b, m, c, points, boxes)
+        sp = self.f32("pe.sparse0", (pcount * ns, d))
+        L.point_embed(xy, kind, shift, d, cfg.image_size, w[pe_ + ".pe_layer.positional_encoding_gaussian_matrix"],
+                      p[pe_ + ".type_emb"], w[pe_ + ".not_a_point_embed.weight"], w[pe_ + ".no_sparse_embedding.weight"], sp)
+        sp = self.attention_mlp_block(pe_ + ".sparse_embedding_attention", sp, b * m, c * ns, "pe.sea")
+        class_enc = None
+        if cfg.bank_size:
+            if selected_rows is None:   # RandomMatrixEncoder draws a fresh permutation every forward, also in eval (:245-248)
+                selected_rows = torch.cat([torch.zeros(1, dtype=torch.long),
+                                           torch.randperm(cfg.bank_size - 1)[: c - 1] + 1])
+            class_enc = w[pe_ + ".class_encoder.pos_embedding"][0, 0].index_select(0, selected_rows.to(self.dev)).contiguous()
+            ce_rows = class_enc.repeat_interleave(ns, dim=0).contiguous()       # rows ordered (c, n)
+            sp2 = self.f32("pe.sparse_ce", (pcount * ns, d))
+            L.add_cast(sp, ce_rows, c * ns, out32=sp2, dt=self.dti)
+            sp = sp2
+        # dense stream
+        pe32 = self.dense_pe(g)
+        src32 = self.f32("pe.src32", (pcount * hw, d))
+        src16 = self.buf("pe.src16", (pcount * hw, d))
+        srcpe16 = self.buf("pe.srcpe16", (pcount * hw, d))
+        if masks is not None:
+            mk, mf = masks
+            mk = mk.to(self.dev, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
+            if mk.shape[-1] != mk.shape[-2]:
+                raise ValueError("prompt masks must be square")
+            mf = mf.to(self.dev).reshape(pcount).to(torch.int32).contiguous()
+            L.mask_embed(mk, mf, pcount, c, mk.shape[-1], g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16,
+                         srcpe16, self.dti)
+        else:
+            L.mask_embed(None, None, pcount, c, 0, g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16, srcpe16,
+                         self.dti)
+        self.two_way(pe_ + ".transformer", sp, pcount, ns, src32, src16, srcpe16, hw, pe32, "pe.tw", want_tokens=False)
+        emb = self.f32("pe.emb", (pcount, d))
+        L.colmean(src32, pcount, hw, d, emb)
+        if cfg.class_attention:
+            emb = self.attention_mlp_block(pe_ + ".class_attention", emb, b * m, c, "pe.ca")
+        if cfg.example_attention:
+            e2 = emb.view(b, m, c, d).permute(0, 2, 1, 3).contiguous().view(b * c * m, d)
+            e2 = self.attention_mlp_block(pe_ + ".example_attention", e2, b * c, m, "pe.ea")
+            emb = e2.view(b, c, m, d).permute(0, 2, 1, 3).contiguous().view(pcount, d)
+        if cfg.example_class_attention:
+            emb = self.attention_mlp_block(pe_ + ".class_example_attention", emb, b, m * c, "pe.cea")
+        fe = flag_examples.to(self.dev).reshape(b, m, c).to(torch.uint8).contiguous()
+        cls = torch.empty(b, c, d, device=self.dev, dtype=torch.float32)
+        L.class_mean(emb, fe, b, m, c, d, cls)
+        return {"flag_examples": flag_examples, "class_embeddings": cls,
+                "class_examples_embeddings": emb.view(b, m, c, d).clone(), "class_examples_src": src32.view(pcount, hw, d)}
+
+    # ------------------------------------------------------------------------------------------------
+    # mask decoder (mask_decoder.py:316-363)
+    # ------------------------------------------------------------------------------------------------
+    def mask_decoder(self, query32: Tensor, b: int, g: int, class_emb: Tensor) -> Tensor:
+        """query32 [B*hw, D] NHWC fp32, class_emb (B,C,D) fp32 -> low-res logits (B, C, 4g, 4g) fp32."""
+        cfg, w, p = self.cfg, self.w32, self.p
+        md = "mask_decoder"
+        d = cfg.embed_dim
+        hw = g * g
+        c = class_emb.shape[1]
+        pe32 = self.dense_pe(g)
+        img32 = self.f32("md.img32", (b * hw, d))
+        img16 = self.buf("md.img16", (b * hw, d))
+        imgpe16 = self.buf("md.imgpe16", (b * hw, d))
+        L.add_cast(query32, out32=img32, out16=img16, dt=self.dti)
+        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.dti)
+        tok = class_emb.to(self.dev, torch.float32).reshape(b * c, d).contiguous()
+        t32, t16 = self.two_way(md + ".transformer", tok, b, c, img32, img16, imgpe16, hw, pe32, "md.tw", want_tokens=True)
+        # class_mlp (3 x Linear, ReLU between) -> prototypes
+        h1 = self.buf("md.cm1", (b * c, d))
+        L.gemm(t16, p[md + ".class_mlp.0.w"], bias=w[md + ".class_mlp.layers.0.bias"], out16=h1, act=L.ACT_RELU)
+        h2 = self.buf("md.cm2", (b * c, d))
+        L.gemm(h1, p[md + ".class_mlp.1.w"], bias=w[md + ".class_mlp.layers.1.bias"], out16=h2, act=L.ACT_RELU)
+        cf = d // 8
+        protos = self.f32("md.protos", (b * c, cf))
+        L.gemm(h2, p[md + ".class_mlp.2.w"], bias=w[md + ".class_mlp.layers.2.bias"], out32=protos)
+        # output_upscaling: ConvT(k2,s2) -> LN2d -> GELU -> ConvT(k2,s2), both as pixel-shuffle GEMMs
+        c1 = d // 4
+        up1 = self.f32("md.up1", (b * 4 * hw, c1))
+        L.gemm(img16, p[md + ".up0.w"], bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
+        up1h = self.buf("md.up1h", (b * 4 * hw, c1))
+        self.ln(up1, md + ".output_upscaling.1", 1e-6, gelu=True, out16=up1h)
+        npix = 16 * hw
+        feat32 = self.f32("md.feat32", (b * npix, cf))
+        feat16 = self.buf("md.feat16", (b * npix, cf))
+        L.gemm(up1h, p[md + ".up3.w"], bias=w[md + ".output_upscaling.3.bias"], out32=feat32, out16=feat16, map=L.MAP_CONVT2X2,
+               p=(2 * g, 2 * g, cf, 0, 0))
+        if cfg.spatial_convs:
+            col = self.buf("md.col", (b * npix, 9 * cf))
+            for i in range(cfg.spatial_convs):
+                L.im2col_3x3(feat16, b, 4 * g, 4 * g, cf, col)
+                L.gemm(col, p[f"{md}.sc{i}.w"], bias=w[f"{md}.spatial_convs.{3 * i}.bias"], out32=feat32)
+                if i < cfg.spatial_convs - 1:
+                    self.ln(feat32, f"{md}.spatial_convs.{3 * i + 1}", 1e-6, gelu=True, out16=feat16)
+        seg = torch.empty(b, c, 4 * g, 4 * g, device=self.dev, dtype=torch.float32)
+        L.classify(feat32, protos, b, npix, c, cf, seg)
+        return seg
+
+    # ------------------------------------------------------------------------------------------------
+    # post-processing (lam.py:383-453, 92-93)
+    # ------------------------------------------------------------------------------------------------
+    def postprocess(self, seg: Tensor, dims: Tensor, flag_gts: Optional[Tensor] = None, want_argmax: bool = False):
+        cfg = self.cfg
+        b, c, h, wd = seg.shape
+        s = cfg.image_size
+        dims_h = dims.detach().to("cpu", torch.int64)
+        hmax, wmax = [int(v) for v in dims_h.reshape(-1, 2).max(dim=0).values.tolist()]
+        sizes = []
+        for oh, ow in dims_h[:, 0, :].tolist():
+            if cfg.custom_preprocess:
+                sc = s * 1.0 / max(oh, ow)
+                ph, pw = int(oh * sc + 0.5), int(ow * sc + 0.5)
+            else:
+                ph, pw = s, s
+            sizes.append([int(oh), int(ow), ph, pw])
+        sizes_d = torch.tensor(sizes, dtype=torch.int32).to(self.dev, non_blocking=True)
+        big = self.f32("post.big", (b * c, s, s))
+        L.bilinear(seg, b * c, h, wd, s, s, big)
+        logits = torch.empty(b, c, hmax, wmax, device=self.dev, dtype=torch.float32)
+        am = torch.empty(b, hmax, wmax, device=self.dev, dtype=torch.int64) if want_argmax else None
+        fg = flag_gts.to(self.dev).to(torch.uint8).contiguous() if flag_gts is not None else None
+        L.post_final(big, b, c, s, sizes_d, fg, hmax, wmax, logits, am)
+        return (logits, am) if want_argmax else logits

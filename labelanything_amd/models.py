@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's model API on top of LamEngine.
+
+  reference                                            here
+  label_anything.models.lam.Lam                        Lam
+  label_anything.models.build_lam.LabelAnything        LabelAnything   (+ from_pretrained / save_pretrained)
+  label_anything.models.build_lam.build_lam*           build_lam, build_lam_no_vit, build_lam_vit_b, ...
+
+Same constructor kwargs, same ``state_dict()`` key layout (``model.image_encoder.*``, ``model.neck.*``,
+``model.prompt_encoder.*``, ``model.mask_decoder.*``), same batch dictionary in, same result dictionary out.
+Inference only: parameters are plain tensors held in a module tree; all arithmetic runs in libla_hip.so.
+"""
+from __future__ import annotations
+
+import inspect
+import json
+import os
+from typing import Any, Dict, Optional
+
+import torch
+from torch import nn
+
+from .config import LamConfig, ENCODER_SPECS, config_from_kwargs
+from .engine import LamEngine
+from .weights import model_shapes, init_state_dict
+from . import _lib as L
+
+try:  # the reference mixes in huggingface_hub.PyTorchModelHubMixin (models/hfhub.py:27-47)
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:  # pragma: no cover
+    class PyTorchModelHubMixin:  # type: ignore
+        pass
+
+_BUFFERS = ("positional_encoding_gaussian_matrix",)
+
+
+class _Tree(nn.Module):
+    """Bare container: child modules and parameters are attached by dotted name."""
+
+
+def _attach(root: nn.Module, name: str, tensor: torch.Tensor) -> None:
+    parts = name.split(".")
+    mod = root
+    for pth in parts[:-1]:
+        if pth not in mod._modules:
+            mod.add_module(pth, _Tree())
+        mod = mod._modules[pth]
+    if parts[-1] in _BUFFERS:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class _EncoderHandle(_Tree):
+    """``lam.image_encoder(images)`` like the reference's encoder modules: (Bn,3,S,S) -> (Bn,C,g,g)."""
+
+    def forward(self, x, return_last_block_state: bool = False):
+        owner = self.__dict__["_owner_ref"]()
+        return owner.encode_images_nchw(x, return_last_block_state=return_last_block_state)
+
+
+class Lam(nn.Module):
+    mask_threshold: float = 0.0
+    image_format: str = "RGB"
+
+    def __init__(self, cfg: LamConfig, seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float16):
+        super().__init__()
+        self.cfg = cfg
+        self.image_size = cfg.image_size
+        self.custom_preprocess = cfg.custom_preprocess
+        self.compute_dtype = compute_dtype
+        self.class_embeddings = None
+        sd = init_state_dict(cfg, 0 if seed is None else seed)
+        for k, v in sd.items():
+            _attach(self, k, v)
+        if "image_encoder" not in self._modules:
+            self.image_encoder = None
+        else:
+            import weakref
+            self.image_encoder.__class__ = _EncoderHandle
+            self.image_encoder.__dict__["_owner_ref"] = weakref.ref(self)
+        if "neck" not in self._modules:
+            self.neck = None
+        self._engine: Optional[LamEngine] = None
+        self._engine_key = None
+        self.selected_rows: Optional[torch.Tensor] = None   # fix the RandomMatrixEncoder rows (parity / reproducibility)
+
+    # -- engine management --------------------------------------------------------------------------
+    def _device(self) -> torch.device:
+        return self.prompt_encoder.no_mask_embed.weight.device
+
+    def engine(self) -> LamEngine:
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("labelanything_amd runs on an MI355X only: move the model to 'cuda' (no CPU fallback)")
+        key = (dev, self.compute_dtype, tuple(p._version for p in self.parameters()))
+        if self._engine is None or self._engine_key != key:
+            self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype)
+            self._engine_key = key
+        return self._engine
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = dict(state_dict)
+        # tolerate accelerate / DDP wrappers like the reference's loader (utils/utils.py:119-142)
+        if sd and all(k.startswith("model.") for k in sd):
+            sd = {k[len("model."):]: v for k, v in sd.items()}
+        if sd and all(k.startswith("module.") for k in sd):
+            sd = {k[len("module."):]: v for k, v in sd.items()}
+        sd = _hf5_to_hf4(sd)
+        out = super().load_state_dict(sd, strict=strict)
+        self._engine = None
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        self._engine = None
+        return super()._apply(fn, *a, **kw)
+
+    # -- reference API --------------------------------------------------------------------------------
+    def get_dense_pe(self) -> torch.Tensor:
+        eng = self.engine()
+        g = self.cfg.grid
+        out = torch.empty(1, self.cfg.embed_dim, g, g, device=eng.dev)
+        L.nhwc_to_nchw(eng.dense_pe(g), 1, self.cfg.embed_dim, g * g, out)
+        return out
+
+    def _embeddings_nhwc(self, batched_input: Dict[str, Any], apply_neck_to_embeddings: bool):
+        """-> (emb32 [B*N*hw, D] NHWC fp32, B, N, g).  lam.py:138-170 / :187-212."""
+        eng = self.engine()
+        cfg = self.cfg
+        if "embeddings" in batched_input:
+            emb = batched_input["embeddings"]
+            if isinstance(emb, dict):
+                raise NotImplementedError("feature pyramids are an off-path ablation of the reference")
+            b, n, c, h, w = emb.shape
+            g = h
+            x = emb.to(eng.dev, torch.float32).reshape(b * n, c, h * w).contiguous()
+            need_neck = cfg.lam_neck and apply_neck_to_embeddings
+            e32 = eng.f32("in.emb32", (b * n * h * w, c))
+            e16 = eng.buf("in.emb16", (b * n * h * w, c)) if need_neck else None
+            L.nchw_to_nhwc(x, b * n, c, h * w, out32=e32, out16=e16, dt=eng.dti)
+            if need_neck:
+                e32 = eng.lam_neck(e32, e16, b * n, g)
+            return e32, b, n, g
+        if "images" in batched_input:
+            im = batched_input["images"]
+            b, n = im.shape[:2]
+            x = im.to(eng.dev, torch.float32).flatten(0, 1)
+            e32, e16, c, g = eng.encode_images(x)
+            if cfg.lam_neck:
+                e32 = eng.lam_neck(e32, e16, b * n, g)
+            return e32, b, n, g
+        raise ValueError("Either 'images' or 'embeddings' must be provided.")
+
+    def prepare_prompts(self, batched_input):
+        """A prompt type is dropped entirely when all its flags are zero (host sync, lam.py:214-239)."""
+        points = boxes = masks = None
+        if "prompt_points" in batched_input and bool((batched_input["flag_points"] != 0).any()):
+            points = (batched_input["prompt_points"], batched_input["flag_points"])
+        if "prompt_bboxes" in batched_input and bool((batched_input["flag_bboxes"] != 0).any()):
+            boxes = (batched_input["prompt_bboxes"], batched_input["flag_bboxes"])
+        if "prompt_masks" in batched_input and bool((batched_input["flag_masks"] != 0).any()):
+            masks = (batched_input["prompt_masks"], batched_input["flag_masks"])
+        return points, boxes, masks, batched_input["flag_examples"]
+
+    @torch.no_grad()
+    def _forward(self, batched_input):
+        eng = self.engine()
+        d = self.cfg.embed_dim
+        e32, b, n, g = self._embeddings_nhwc(batched_input, apply_neck_to_embeddings=True)
+        hw = g * g
+        ev = e32.view(b, n, hw, d)
+        query = ev[:, 0].contiguous().view(b * hw, d)
+        support = ev[:, 1:].contiguous().view(b * (n - 1) * hw, d)
+        points, boxes, masks, flag_examples = self.prepare_prompts(batched_input)
+        pe_result = eng.prompt_encoder(support, b, n - 1, g, points, boxes, masks, flag_examples, self.selected_rows)
+        seg = eng.mask_decoder(query, b, g, pe_result["class_embeddings"])
+        return seg, pe_result
+
+    @torch.no_grad()
+    def forward(self, batched_input: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+        seg, pe_result = self._forward(batched_input)
+        logits = self.engine().postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"))
+        return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"]}
+
+    @torch.no_grad()
+    def forward_argmax(self, batched_input: Dict[str, Any]):
+        """forward + the caller's ``logits.argmax(dim=1)`` (experiment/run.py:697) fused into the last kernel."""
+        seg, pe_result = self._forward(batched_input)
+        logits, am = self.engine().postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"), want_argmax=True)
+        return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"], "argmax": am}
+
+    def postprocess_masks(self, masks: torch.Tensor, original_sizes: torch.Tensor) -> torch.Tensor:
+        return self.engine().postprocess(masks.to(self._device(), torch.float32).contiguous(), original_sizes)
+
+    @torch.no_grad()
+    def generate_class_embeddings(self, example_dict, chunk_size=None):
+        """Supports only: every image of the dict is a support (lam.py:349-360).  chunk_size is accepted and ignored
+        (the kernels never materialise the tensors the reference chunks for)."""
+        eng = self.engine()
+        e32, b, n, g = self._embeddings_nhwc(example_dict, apply_neck_to_embeddings=False)
+        points, boxes, masks, flag_examples = self.prepare_prompts(example_dict)
+        res = eng.prompt_encoder(e32, b, n, g, points, boxes, masks, flag_examples, self.selected_rows)
+        pcount, hw, d = res["class_examples_src"].shape
+        src = torch.empty(pcount, d, g, g, device=eng.dev)
+        L.nhwc_to_nchw(res["class_examples_src"].contiguous(), pcount, d, hw, src)
+        res["class_examples_src"] = src
+        return res
+
+    @torch.no_grad()
+    def predict(self, batched_input, class_embeddings=None):
+        """Query-only encode + decode against cached prototypes (lam.py:362-381)."""
+        if class_embeddings is None and self.class_embeddings is None:
+            return self.forward(batched_input)
+        if class_embeddings is None:
+            class_embeddings = self.class_embeddings
+        eng = self.engine()
+        d = self.cfg.embed_dim
+        e32, b, n, g = self._embeddings_nhwc(batched_input, apply_neck_to_embeddings=False)
+        query = e32.view(b, n, g * g, d)[:, 0].contiguous().view(b * g * g, d)
+        seg = eng.mask_decoder(query, b, g, class_embeddings["class_embeddings"])
+        return eng.postprocess(seg, batched_input["dims"].unsqueeze(1))
+
+    @torch.no_grad()
+    def encode_images_nchw(self, images: torch.Tensor, return_last_block_state: bool = False):
+        """``model.image_encoder(images)`` of the reference: (Bn,3,S,S) -> (Bn,C,g,g) fp32
+        (image_encoder.py:110-131, build_encoder.py:83-100)."""
+        eng = self.engine()
+        x = images.to(eng.dev, torch.float32)
+        spec = self.cfg.encoder_spec
+        if return_last_block_state and spec.kind == "sam":
+            (e32, _, c), last = eng.sam_encoder(x, want_last_block=True)
+            g = x.shape[-1] // spec.patch
+            out = torch.empty(x.shape[0], c, g, g, device=eng.dev)
+            L.nhwc_to_nchw(e32, x.shape[0], c, g * g, out)
+            lb = torch.empty(x.shape[0], spec.dim, g, g, device=eng.dev)
+            L.nhwc_to_nchw(last, x.shape[0], spec.dim, g * g, lb)
+            return {"last_hidden_state": out, "last_block_state": lb}
+        e32, _, c, g = eng.encode_images(x)
+        out = torch.empty(x.shape[0], c, g, g, device=eng.dev)
+        L.nhwc_to_nchw(e32, x.shape[0], c, g * g, out)
+        return out
+
+    def get_learnable_params(self, training_params: dict) -> list:
+        """lam.py:321-347 (parameter grouping only; this build is inference-only)."""
+        def not_enc(kv):
+            return "image_encoder" not in kv[0]
+        freeze = training_params.get("freeze_backbone", False)
+        if freeze and "backbone_lr" in training_params:
+            raise ValueError("Cannot freeze the backbone and set a learning rate for it at the same time.")
+        named = list(self.named_parameters())
+        if freeze:
+            return [p for _, p in filter(not_enc, named)]
+        if "backbone_lr" in training_params:
+            return [{"params": [p for k, p in named if "image_encoder" in k], "lr": training_params["backbone_lr"]},
+                    {"params": [p for _, p in filter(not_enc, named)]}]
+        return [p for _, p in named]
+
+
+def _hf5_to_hf4(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Accept transformers-5.x ViT key names for the HF encoder and map them to the 4.x layout."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("image_encoder.") and (".layers." in k and "encoder.layer." not in k):
+            k = (k.replace("image_encoder.encoder.layers.", "image_encoder.encoder.layer.")
+                  .replace("image_encoder.layers.", "image_encoder.encoder.layer.")
+                  .replace("attention.q_proj", "attention.attention.query")
+                  .replace("attention.k_proj", "attention.attention.key")
+                  .replace("attention.v_proj", "attention.attention.value")
+                  .replace("attention.o_proj", "attention.output.dense")
+                  .replace("mlp.fc1", "intermediate.dense")
+                  .replace("mlp.fc2", "output.dense"))
+        if "pooler" in k:
+            continue
+        out[k] = v
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+def has_config(func):
+    """Capture constructor kwargs as ``self.config`` (models/hfhub.py:50-67)."""
+    signature = inspect.signature(func)
+
+    def wrapper(self, *args, **kwargs):
+        if "config" in kwargs:
+            config = kwargs.pop("config")
+            kwargs.update(**config)
+        self.config = {k: (v.default if (i - 1) >= len(args) else args[i - 1])
+                       for i, (k, v) in enumerate(signature.parameters.items()) if v.default is not inspect.Parameter.empty}
+        self.config.update(**kwargs)
+        func(self, *args, **kwargs)
+    return wrapper
+
+
+def build_lam(encoder: Optional[str] = "vit_b", seed: Optional[int] = None, compute_dtype=torch.float16,
+              checkpoint: Optional[str] = None, **kwargs) -> Lam:
+    cfg = config_from_kwargs(encoder=encoder, **kwargs)
+    lam = Lam(cfg, seed=seed, compute_dtype=compute_dtype)
+    lam.eval()
+    if checkpoint is not None:
+        lam.load_state_dict(_load_any(checkpoint))
+    return lam
+
+
+def build_lam_no_vit(**kw) -> Lam:
+    return build_lam(encoder=None, use_vit=False, **kw)
+
+
+def build_lam_vit_b(**kw) -> Lam:
+    return build_lam(encoder="vit_b", **kw)
+
+
+def build_lam_vit_l(**kw) -> Lam:
+    return build_lam(encoder="vit_l", **kw)
+
+
+def build_lam_vit_mae_b(**kw) -> Lam:
+    return build_lam(encoder="vit_b_mae", **kw)
+
+
+def _load_any(path: str) -> Dict[str, torch.Tensor]:
+    """.pth/.pt/.bin via torch.load, .safetensors via safetensors (utils/utils.py:91-108)."""
+    if path.endswith((".pth", ".pt", ".bin")):
+        return torch.load(path, map_location="cpu")
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    raise ValueError("File extension not supported")
+
+
+class LabelAnything(nn.Module, PyTorchModelHubMixin):
+    """``label_anything.models.LabelAnything`` (build_lam.py:467-508): ``.model`` is a Lam, ``.config`` a dict of the
+    constructor arguments; ``from_pretrained(dir)`` reads config.json + model.safetensors with ``model.``-prefixed keys."""
+
+    @has_config
+    def __init__(self, encoder="vit_b", checkpoint=None, use_sam_checkpoint=False, use_vit_sam_neck=True, use_vit=True,
+                 image_embed_dim=256, embed_dim=256, image_size=1024, vit_patch_size=16, class_attention=False,
+                 example_attention=False, example_class_attention=True, class_embedding_dim=None, spatial_convs=None,
+                 encoder_attention_downsample_rate: int = 2, decoder_attention_downsample_rate: int = 2,
+                 classification_layer_downsample_rate: int = 8, use_support_features_in_prompt_encoder: bool = True,
+                 fusion_transformer="TwoWayTransformer", few_type="Prototype", class_fusion="sum",
+                 transformer_keys_are_images=True, transformer_feature_size=None, class_encoder=None,
+                 segment_example_logits=False, dropout: float = 0.0, binary=False, custom_preprocess=True):
+        super().__init__()
+        cfg = dict(self.config)
+        enc = cfg.pop("encoder")
+        if enc is not None and enc not in ENCODER_SPECS:
+            raise KeyError(f"unknown encoder {enc!r}; available: {sorted(ENCODER_SPECS)}")
+        self.model = build_lam(encoder=enc if cfg.get("use_vit", True) else None, **cfg)
+
+    def forward(self, *args, **kwargs):
+        return self.model(*args, **kwargs)
+
+    # PyTorchModelHubMixin in recent huggingface_hub versions handles config.json + model.safetensors itself;
+    # these two helpers give the same on-disk format without it (and are what the tests exercise offline).
+    def save_local(self, directory: str) -> None:
+        from safetensors.torch import save_file
+        os.makedirs(directory, exist_ok=True)
+        sig = inspect.signature(type(self).__init__.__wrapped__) if hasattr(type(self).__init__, "__wrapped__") else None
+        with open(os.path.join(directory, "config.json"), "w") as fh:
+            json.dump(self.config, fh, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(directory, "model.safetensors"))
+
+    @classmethod
+    def from_local(cls, directory: str, **overrides) -> "LabelAnything":
+        from safetensors.torch import load_file
+        with open(os.path.join(directory, "config.json")) as fh:
+            config = json.load(fh)
+        config.update(overrides)
+        obj = cls(**config)
+        sd = load_file(os.path.join(directory, "model.safetensors"))
+        obj.model.load_state_dict({k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()})
+        return obj

@@ -1,0 +1,99 @@
+"""CPU: host logic, C-ABI surface and the model's parameter / config I/O (no kernels are launched)."""
+import ctypes
+import os
+import re
+import tempfile
+
+import pytest
+import torch
+
+from labelanything_amd import _lib
+from labelanything_amd.config import LamConfig, config_from_kwargs
+from labelanything_amd.episodes import make_episode
+from labelanything_amd.weights import init_state_dict, model_shapes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "la_hip.h")).read()
+    declared = set(re.findall(r"\b(la_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libla_hip.so does not export {name}"
+    assert declared == set(_lib.EXPORTS) | {"la_last_error", "la_version"}
+    assert lib.la_version() >= 1
+
+
+def test_state_dict_layout_matches_reference_inventory():
+    """LabelAnything(encoder='vit_b', D=256, class encoder on) = 411 tensors, 99.03 M params."""
+    cfg = LamConfig(encoder="vit_b", spatial_convs=3, class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256})
+    shapes = model_shapes(cfg)
+    n_params = sum(int(torch.Size(s).numel()) for s in shapes.values())
+    assert len(shapes) == 411
+    assert abs(n_params / 1e6 - 99.03) < 0.02
+    assert shapes["image_encoder.blocks.2.attn.rel_pos_h"] == (127, 64)
+    assert shapes["image_encoder.blocks.0.attn.rel_pos_h"] == (27, 64)
+    assert shapes["mask_decoder.output_upscaling.0.weight"] == (256, 64, 2, 2)
+    # decoder-only MAE-480 geometry: 10.14 M trainable params
+    cfg2 = LamConfig(encoder=None, use_vit=False, image_embed_dim=768, embed_dim=256, image_size=480, spatial_convs=3,
+                     class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256})
+    n2 = sum(int(torch.Size(s).numel()) for s in model_shapes(cfg2).values())
+    assert abs(n2 / 1e6 - 10.14) < 0.02
+
+
+def test_label_anything_config_roundtrip_and_hub_format():
+    from label_anything.models import LabelAnything
+    m = LabelAnything(encoder=None, use_vit=False, image_size=256, embed_dim=64, image_embed_dim=96, spatial_convs=3)
+    assert m.config["embed_dim"] == 64 and m.config["encoder"] is None
+    assert all(k.startswith("model.") for k in m.state_dict())
+    with tempfile.TemporaryDirectory() as d:
+        m.save_pretrained(d)
+        assert {"config.json", "model.safetensors"} <= set(os.listdir(d))
+        m2 = LabelAnything.from_pretrained(d)
+    a, b = m.state_dict(), m2.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_off_path_switches_are_rejected():
+    with pytest.raises(NotImplementedError):
+        config_from_kwargs(encoder="vit_b", few_type="Affinity")
+    with pytest.raises(NotImplementedError):
+        config_from_kwargs(encoder="vit_b", fusion_transformer="OneWayTransformer")
+    with pytest.raises(TypeError):
+        config_from_kwargs(encoder="vit_b", not_an_argument=1)
+
+
+def test_model_refuses_to_run_without_gpu_or_library(monkeypatch):
+    from labelanything_amd.models import Lam
+    lam = Lam(LamConfig(encoder=None, use_vit=False, image_size=64, embed_dim=64, image_embed_dim=64, spatial_convs=3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lam({"embeddings": torch.zeros(1, 2, 64, 4, 4)})
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libla_hip.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="HIP extension .* is missing"):
+        _lib.lib()
+
+
+def test_synthetic_episode_schema():
+    b = make_episode(batch=2, n_ways=2, k_shots=2, image_size=64, seed=3, prompts=("mask", "point", "box"))
+    assert b["images"].shape == (2, 5, 3, 64, 64)
+    assert b["prompt_masks"].shape == (2, 4, 3, 256, 256) and b["flag_masks"].shape == (2, 4, 3)
+    assert b["prompt_points"].shape[-1] == 2 and b["prompt_bboxes"].shape[-1] == 4
+    assert bool((b["flag_examples"][:, :, 0] == 1).all())           # background always present
+    assert b["dims"].shape == (2, 5, 2) and b["flag_gts"].shape == (2, 3)
+    b2 = make_episode(batch=2, n_ways=2, k_shots=2, image_size=64, seed=3, prompts=("mask", "point", "box"))
+    assert all(torch.equal(b[k], b2[k]) for k in b)
+
+
+def test_hf_key_renaming_from_transformers5():
+    from labelanything_amd.models import _hf5_to_hf4
+    sd = {"image_encoder.layers.3.attention.q_proj.weight": torch.zeros(1),
+          "image_encoder.layers.3.mlp.fc2.bias": torch.zeros(1), "image_encoder.pooler.dense.weight": torch.zeros(1)}
+    out = _hf5_to_hf4(sd)
+    assert set(out) == {"image_encoder.encoder.layer.3.attention.attention.query.weight",
+                        "image_encoder.encoder.layer.3.output.dense.bias"}

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Per-stage parity of the HIP path against the golden fixtures (GPU box).  Prints max-rel errors."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from labelanything_amd.models import Lam
+from labelanything_amd.episodes import make_episode
+from tests.cases import CASES
+from tests.helpers import load_golden, rel_err
+
+
+def main():
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    for dt in (torch.float16, torch.bfloat16):
+        for name, case in CASES.items():
+            if only and name not in only:
+                continue
+            gold, meta = load_golden(name)
+            lam = Lam(case["cfg"], seed=case["weight_seed"], compute_dtype=dt).cuda()
+            lam.selected_rows = gold.get("selected_rows")
+            batch = make_episode(**case["episode"])
+            t0 = time.time()
+            try:
+                seg, pe = lam._forward(batch)
+                out = lam.forward_argmax(batch)
+                torch.cuda.synchronize()
+            except Exception as e:
+                print(f"[{name} {dt}] FAILED: {type(e).__name__}: {e}")
+                import traceback; traceback.print_exc()
+                continue
+            t1 = time.time() - t0
+            d = lam.cfg.embed_dim
+            errs = {}
+            eng = lam.engine()
+            if "query_embedding" in gold or "query_embedding_sample" in gold:
+                e32, b, n, g = lam._embeddings_nhwc(batch, True)
+                q = e32.view(b, n, g * g, d)[:, 0].permute(0, 2, 1).reshape(b, d, g, g)
+                if "query_embedding" in gold:
+                    errs["query_emb"] = rel_err(q, gold["query_embedding"])
+                else:
+                    errs["query_emb"] = rel_err(q[:, ::8, ::4, ::4], gold["query_embedding_sample"])
+            errs["class_emb"] = rel_err(pe["class_embeddings"], gold["class_embeddings"])
+            errs["cls_ex_emb"] = rel_err(pe["class_examples_embeddings"], gold["class_examples_embeddings"])
+            errs["low_res"] = rel_err(seg, gold["low_res_logits"])
+            if "logits" in gold:
+                errs["logits"] = rel_err(out["logits"], gold["logits"])
+            am = out["argmax"].cpu()
+            ref_am = gold["argmax"].long()
+            mism = int((am != ref_am).sum())
+            errs["argmax_mismatch_frac"] = mism / ref_am.numel()
+            am2 = out["logits"].argmax(1).cpu()
+            errs["fused_argmax_vs_torch"] = int((am2 != am).sum())
+            print(f"[{name} {str(dt)[6:]}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
+            del lam
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
