@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""bench.py - BASELINE metric: episodes/sec (query+support forward), SAM ViT-B 1024 px, 1-way 1-shot, on N MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one ``Lam.forward`` over a batch of ``--episodes`` synthetic 1-way 1-shot episodes (BASELINE cfg2: encoder on
+query + support image, prompt encoder, mask decoder, post-processed full-resolution logits).  Episodes are independent,
+so for N > 1 every rank runs its own batch (weak scaling, no data-path collective); the timed region is bracketed by a
+barrier + device sync and the MAX over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (la_gemm: every Linear / conv of the path) timed live with HIP events on the launch
+                stream in a separate instrumented step: algorithmic FLOPs of all its launches / their summed duration,
+                against the gfx950 dense fp16/bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/lam_oracle.py, a checked restatement of the reference's torch path) timed on this
+                box's host cores for ONE episode of the same workload (N=1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_TFLOPS = 2500.0      # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def build_model(dtype):
+    from labelanything_amd.config import LamConfig
+    from labelanything_amd.models import Lam
+    cfg = LamConfig(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3,
+                    custom_preprocess=False)
+    return Lam(cfg, seed=2, compute_dtype=dtype), cfg
+
+
+def make_inputs(episodes: int, seed: int, device):
+    from labelanything_amd.episodes import make_episode
+    batch = make_episode(batch=episodes, n_ways=1, k_shots=1, image_size=1024, seed=seed, prompts=("mask",))
+    dev_keys = ("images", "prompt_masks")
+    return {k: (v.to(device) if k in dev_keys else v) for k, v in batch.items()}
+
+
+class KernelTimer:
+    """Wraps labelanything_amd._lib launch functions with HIP events on the current (launch) stream."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        from labelanything_amd import _lib as L
+        self.L = L
+        self.saved = {}
+        names = ["gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
+                 "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc"]
+        for n in names:
+            fn = getattr(L, n)
+            self.saved[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                _fn(*a, **kw)
+                e.record()
+                flops = 0.0
+                if _n == "gemm":
+                    m = kw.get("M") or a[0].shape[0]
+                    flops = 2.0 * m * a[1].shape[0] * a[1].shape[1]
+                elif _n == "attn_fwd":
+                    b, heads, t = a[5], a[6], a[7]
+                    flops = 4.0 * b * heads * t * t * 64
+                self.records.append((_n, flops, s, e))
+            setattr(L, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for n, fn in self.saved.items():
+            setattr(self.L, n, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for n, fl, s, e in self.records:
+            d = agg.setdefault(n, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += fl
+        return agg
+
+
+def cpu_baseline(cfg, episodes_sample: int = 1):
+    """Time the CPU oracle on one episode of the same workload (host cores of this box)."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    sd = init_state_dict(cfg, 2)
+    batch = make_episode(batch=episodes_sample, n_ways=1, k_shots=1, image_size=1024, seed=1234, prompts=("mask",))
+    geo = geometry_for(cfg)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.lam_forward(sd, geo, batch)
+        dt = time.perf_counter() - t0
+    return {"value": round(episodes_sample / dt, 5), "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": f"{episodes_sample} episode (2 images 1024x1024) of the bench workload, fp32 torch CPU oracle, {dt:.1f} s, no warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--episodes", type=int, default=4, help="episodes per step per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
+    lam, cfg = build_model(dtype)
+    lam = lam.to(dev)
+    batch = make_inputs(a.episodes, 1234 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        lam(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = lam(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out["logits"]).all()
+
+    # instrumented step: per-kernel HIP-event timing (outside the timed region)
+    roof = None
+    kernels = None
+    if rank == 0:
+        with KernelTimer() as kt:
+            lam(batch)
+        agg = kt.summary()
+        g = agg.get("gemm")
+        tot = sum(v[1] for v in agg.values())
+        kernels = {n: {"launches": v[0], "ms": round(v[1] * 1e3, 3)} for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        if g:
+            ach = g[2] / g[1] / 1e12
+            roof = {"kernel": "gemm_nt_kernel (la_gemm)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
+                    "share_of_kernel_time": round(g[1] / tot, 3)}
+
+    if rank == 0:
+        eps = a.episodes * world * a.steps / elapsed
+        line = {
+            "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot", "value": round(eps, 3), "unit": "episodes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes "
+                                   "(2 images each), random-init weights, full-resolution logits",
+                       "episodes_per_step_per_gpu": a.episodes, "images_per_sec": round(eps * 2, 2),
+                       "parallelism": f"episode-sharded x{world}, no collective"},
+            "roofline": roof, "kernels_ms_per_step": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
