@@ -6,6 +6,7 @@
 // ONE barrier per K-step: the next tile's global loads are issued before the MFMAs of the current one and
 // written to the other LDS stage after them.  Tiles are handed to XCDs in contiguous chunks (xcd_remap) so
 // the workgroups sharing an A row-panel / the whole W hit the same L2.
+#include <cstdlib>
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
@@ -173,6 +174,235 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
   }
 }
 
+
+// =================================================================================================================
+// v2 fast path (K % 64 == 0, N % 8 == 0, 16-byte aligned rows): operand tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass; the XOR swizzle is applied to the per-lane SOURCE
+// address because the DMA destination is lane-linear), and the epilogue is staged through LDS so that every lane
+// handles 8 consecutive output columns (16-byte stores, float4 residual / bias loads).  Tile BM x BN with one
+// 64 x 64 sub-tile per wave: 128x128 (4 waves, 2 blocks/CU) or 256x128 (8 waves).
+// =================================================================================================================
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int EPI_LD = BN + 4;                      // fp32 row stride of the staged output tile
+constexpr int EPI_BYTES = 128 * EPI_LD * 4;         // one 128-row chunk
+
+template <int BM_>
+constexpr int fast_lds_bytes() {
+  return (2 * (BM_ + BN) * BK * 2) > EPI_BYTES ? (2 * (BM_ + BN) * BK * 2) : EPI_BYTES;
+}
+
+template <typename T, int BM_>
+__global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                               int M, int N, int K, LaGemmEpilogue e) {
+  constexpr int NW = (BM_ / 64) * 2;               // waves: (BM_/64) x 2
+  constexpr int NT = NW * 64;
+  constexpr int STAGE = (BM_ + BN) * BK * 2;       // bytes
+  constexpr int NDMA = (BM_ + BN) / 8 / NW;        // wave-level DMA instructions per k-tile (8 rows each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN;
+
+  // ---- DMA plan: instruction i of this wave moves 8 tile rows (1 KiB); lane -> (row lane/8, slot lane%8) --------
+  const T* src[NDMA];
+  int ldsoff[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int grp = i * NW + wave;                 // row group index over [A rows | W rows]
+    const int trow = grp * 8 + (lane >> 3);        // tile row in the concatenated (BM_ + BN) row space
+    const int slot = lane & 7;
+    if (grp < BM_ / 8) {
+      const int r = trow;
+      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
+    } else {
+      const int r = trow - BM_;
+      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+    }
+    ldsoff[i] = grp * 1024;                        // A tile occupies [0, BM_*128), W tile follows: same linear space
+  }
+  auto dma = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * BK), (lptr_t)(smem + stage * STAGE + ldsoff[i]), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
+    const char* sa = smem + (kt & 1) * STAGE;
+    const char* sw = sa + BM_ * BK * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const uint4*>(sa + swz_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
+        wf[i] = *reinterpret_cast<const uint4*>(sw + swz_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[i], wf[j], acc[i][j]);
+    }
+    __syncthreads();   // drains this wave's DMA (vmcnt) and orders the stage swap
+  }
+
+  // ---- epilogue through LDS, 128 rows at a time ----------------------------------------------------------------
+  float* epi = reinterpret_cast<float*>(smem);
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  T* out16 = reinterpret_cast<T*>(e.out16);
+  T* vt = reinterpret_cast<T*>(e.vt);
+  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < BM_ / 128; ++chunk) {
+    if (chunk > 0) __syncthreads();
+    if ((wm >> 1) == chunk) {
+      const int rbase = (wm & 1) * 64;
+      if (!vt_tile) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              epi[(rbase + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + wn * 64 + tj * 32 + fr] = acc[ti][tj][r];
+      } else {  // transposed staging [col][row] so that rows (tokens) are contiguous
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
+              *reinterpret_cast<float4*>(&epi[(wn * 64 + tj * 32 + fr) * EPI_LD + rbase + ti * 32 + 8 * g4 + 4 * fh]) = v;
+            }
+      }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + chunk * 128;
+    if (vt_tile) {
+      // items: (col c, 4-row group rg); rg fastest so a wave writes contiguous tokens
+      for (int it = tid; it < BN * 32; it += NT) {
+        const int rg = it & 31, c = it >> 5;
+        const int col = n0 + c, row = mrow0 + rg * 4;
+        if (col >= N || row >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&epi[c * EPI_LD + rg * 4]);
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const int cv = col - e.vt_col0;
+        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
+        const int b = row / e.vt_T, t = row % e.vt_T;
+        T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + t;
+        if ((e.vt_T & 3) == 0 && row + 3 < M) {
+          uint2 o;
+          o.x = pack2<T>(v.x + bias, v.y + bias);
+          o.y = pack2<T>(v.z + bias, v.w + bias);
+          *reinterpret_cast<uint2*>(dst) = o;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4; ++j) {
+            const int rj = row + j;
+            if (rj >= M) break;
+            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
+            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + tj2] = (T)(vv[j] + bias);
+          }
+        }
+      }
+      continue;
+    }
+    constexpr int CG = BN / 8;
+    for (int it = tid; it < 128 * CG; it += NT) {
+      const int cg = it % CG, r = it / CG;
+      const int row = mrow0 + r, col0 = n0 + cg * 8;
+      if (row >= M || col0 >= N) continue;
+      float v[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * EPI_LD + cg * 8]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * EPI_LD + cg * 8 + 4]);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      }
+      int dcol = col0, row_add = 0, bcol = col0;
+      if (e.map == LA_MAP_CONVT2X2) {
+        const int kyx = col0 / e.p2;
+        dcol = col0 % e.p2;
+        bcol = dcol;
+        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+      }
+      if (e.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (e.act == LA_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+      } else if (e.act == LA_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      int drow = map_row(rm, row);
+      if (drow < 0) continue;
+      drow += row_add;
+      if (e.res) {
+        const int rr = e.res_mod ? drow % e.res_mod : drow;
+        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
+        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (e.out32) {
+        float4* o = reinterpret_cast<float4*>(e.out32 + (size_t)drow * e.ld32 + dcol);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (out16) {
+        uint4 o;
+        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
+        *reinterpret_cast<uint4*>(out16 + (size_t)drow * e.ld16 + dcol) = o;
+      }
+    }
+  }
+}
+
+template <typename T, int BM_>
+static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = fast_lds_bytes<BM_>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<T, BM_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int ntm = (M + BM_ - 1) / BM_, ntn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_dma_kernel<T, BM_>), dim3(ntm * ntn), dim3(BM_ * 2), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e);
+}
+
+static bool fast_ok(const void* A, int lda, const void* W, int ldw, int N, int K, const LaGemmEpilogue& e) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if ((K % 64) != 0 || (N % 8) != 0) return false;
+  if (!al16(A) || !al16(W)) return false;
+  if (e.bias && !al16(e.bias)) return false;
+  if (e.res && (!al16(e.res) || (e.ldr % 4) != 0)) return false;
+  if (e.out32 && (!al16(e.out32) || (e.ld32 % 4) != 0)) return false;
+  if (e.out16 && (!al16(e.out16) || (e.ld16 % 8) != 0)) return false;
+  if (e.map == LA_MAP_CONVT2X2 && (e.p2 % 8) != 0) return false;
+  if (e.vt && ((e.vt_col0 % BN) != 0 || (e.vt_Tpad % 4) != 0 || !al16(e.vt))) return false;
+  return true;
+}
+
 template <typename T>
 static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e,
                        hipStream_t st) {
@@ -199,8 +429,20 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   LA_CHECK_ARG(epi->out32 || epi->out16 || epi->vt, "la_gemm: no output");
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_gemm: bad dtype %d", dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dt == LA_F16) la::launch_gemm<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
-  else la::launch_gemm<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1", "128", "256"
+  bool fast = la::fast_ok(A, lda, W, ldw, N, K, *epi) && !(force && force[0] == 'v');
+  if (fast) {
+    const long tiles256 = (long)((M + 255) / 256) * ((N + la::BN - 1) / la::BN);
+    bool big = false;   // 256x128 measured 5-10% slower than 128x128 on every SAM ViT-B shape (profiles/r01_gemm_v2.log)
+    (void)tiles256;
+    if (force && force[0] == '1') big = false;
+    if (force && force[0] == '2') big = true;
+    if (dt == LA_F16) big ? la::launch_fast<la::f16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::f16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+    else big ? la::launch_fast<la::bf16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::bf16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+  } else {
+    if (dt == LA_F16) la::launch_gemm<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    else la::launch_gemm<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+  }
   LA_CHECK_LAUNCH("la_gemm");
   return 0;
 }

@@ -165,6 +165,14 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------------
+    def h2d(self, t: Tensor, dtype=None) -> Tensor:
+        """Small host tensor -> device without stalling the launch queue (pinned staging + async copy)."""
+        if t.is_cuda:
+            return t.to(self.dev, dtype) if dtype is not None else t.to(self.dev)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous().pin_memory().to(self.dev, non_blocking=True)
+
     def buf(self, name, shape, dtype=None, zero=False) -> Tensor:
         return self.arena.get(name, shape, self.dt if dtype is None else dtype, zero)
 
@@ -457,8 +465,8 @@ class LamEngine:
         parts_xy, parts_kind, parts_shift = [], [], []
         if points is not None:
             xy, lab = points
-            xy = xy.reshape(pcount, -1, 2).to(dev, torch.float32)
-            lab = lab.reshape(pcount, -1).to(dev)
+            xy = self.h2d(xy.reshape(pcount, -1, 2), torch.float32)
+            lab = self.h2d(lab.reshape(pcount, -1))
             kind = torch.where(lab == 0, 0, torch.where(lab < 0, 1, 2)).to(torch.int32)
             shift = torch.ones_like(kind)
             if boxes is None:   # extra token at (0,0), label -1 == NEGATIVE in this code base, not shifted (prompt_encoder.py:91-95)
@@ -469,9 +477,9 @@ class LamEngine:
         if boxes is not None:
             bx, bf = boxes
             nb = bx.shape[3]
-            corners = bx.reshape(pcount, nb * 2, 2).to(dev, torch.float32)
+            corners = self.h2d(bx.reshape(pcount, nb * 2, 2), torch.float32)
             kind = torch.tensor([3, 4], dtype=torch.int32, device=dev).repeat(nb).expand(pcount, -1)
-            flags2 = bf.reshape(pcount, nb).to(dev).repeat(1, 2)            # tiled flags vs interleaved corners (:661-667)
+            flags2 = self.h2d(bf.reshape(pcount, nb)).repeat(1, 2)            # tiled flags vs interleaved corners (:661-667)
             kind = torch.where(flags2 == 0, 0, kind).to(torch.int32)
             parts_xy.append(corners); parts_kind.append(kind); parts_shift.append(torch.ones_like(kind))
         if not parts_xy:
@@ -507,7 +515,7 @@ class LamEngine:
             if selected_rows is None:   # RandomMatrixEncoder draws a fresh permutation every forward, also in eval (:245-248)
                 selected_rows = torch.cat([torch.zeros(1, dtype=torch.long),
                                            torch.randperm(cfg.bank_size - 1)[: c - 1] + 1])
-            class_enc = w[pe_ + ".class_encoder.pos_embedding"][0, 0].index_select(0, selected_rows.to(self.dev)).contiguous()
+            class_enc = w[pe_ + ".class_encoder.pos_embedding"][0, 0].index_select(0, self.h2d(selected_rows)).contiguous()
             ce_rows = class_enc.repeat_interleave(ns, dim=0).contiguous()       # rows ordered (c, n)
             sp2 = self.f32("pe.sparse_ce", (pcount * ns, d))
             L.add_cast(sp, ce_rows, c * ns, out32=sp2, dt=self.dti)
@@ -519,10 +527,10 @@ class LamEngine:
         srcpe16 = self.buf("pe.srcpe16", (pcount * hw, d))
         if masks is not None:
             mk, mf = masks
-            mk = mk.to(self.dev, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
+            mk = self.h2d(mk, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
             if mk.shape[-1] != mk.shape[-2]:
                 raise ValueError("prompt masks must be square")
-            mf = mf.to(self.dev).reshape(pcount).to(torch.int32).contiguous()
+            mf = self.h2d(mf.reshape(pcount), torch.int32).contiguous()
             L.mask_embed(mk, mf, pcount, c, mk.shape[-1], g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16,
                          srcpe16, self.dti)
         else:
@@ -539,7 +547,7 @@ class LamEngine:
             emb = e2.view(b, c, m, d).permute(0, 2, 1, 3).contiguous().view(pcount, d)
         if cfg.example_class_attention:
             emb = self.attention_mlp_block(pe_ + ".class_example_attention", emb, b, m * c, "pe.cea")
-        fe = flag_examples.to(self.dev).reshape(b, m, c).to(torch.uint8).contiguous()
+        fe = self.h2d(flag_examples.reshape(b, m, c), torch.uint8).contiguous()
         cls = torch.empty(b, c, d, device=self.dev, dtype=torch.float32)
         L.class_mean(emb, fe, b, m, c, d, cls)
         return {"flag_examples": flag_examples, "class_embeddings": cls,
@@ -561,7 +569,7 @@ class LamEngine:
         imgpe16 = self.buf("md.imgpe16", (b * hw, d))
         L.add_cast(query32, out32=img32, out16=img16, dt=self.dti)
         L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.dti)
-        tok = class_emb.to(self.dev, torch.float32).reshape(b * c, d).contiguous()
+        tok = self.h2d(class_emb, torch.float32).reshape(b * c, d).contiguous()
         t32, t16 = self.two_way(md + ".transformer", tok, b, c, img32, img16, imgpe16, hw, pe32, "md.tw", want_tokens=True)
         # class_mlp (3 x Linear, ReLU between) -> prototypes
         h1 = self.buf("md.cm1", (b * c, d))
@@ -610,11 +618,11 @@ class LamEngine:
             else:
                 ph, pw = s, s
             sizes.append([int(oh), int(ow), ph, pw])
-        sizes_d = torch.tensor(sizes, dtype=torch.int32).to(self.dev, non_blocking=True)
+        sizes_d = self.h2d(torch.tensor(sizes, dtype=torch.int32))
         big = self.f32("post.big", (b * c, s, s))
         L.bilinear(seg, b * c, h, wd, s, s, big)
         logits = torch.empty(b, c, hmax, wmax, device=self.dev, dtype=torch.float32)
         am = torch.empty(b, hmax, wmax, device=self.dev, dtype=torch.int64) if want_argmax else None
-        fg = flag_gts.to(self.dev).to(torch.uint8).contiguous() if flag_gts is not None else None
+        fg = self.h2d(flag_gts, torch.uint8).contiguous() if flag_gts is not None else None
         L.post_final(big, b, c, s, sizes_d, fg, hmax, wmax, logits, am)
         return (logits, am) if want_argmax else logits

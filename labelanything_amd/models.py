@@ -82,17 +82,24 @@ class Lam(nn.Module):
             self.neck = None
         self._engine: Optional[LamEngine] = None
         self._engine_key = None
+        self._plist = None
         self.selected_rows: Optional[torch.Tensor] = None   # fix the RandomMatrixEncoder rows (parity / reproducibility)
 
     # -- engine management --------------------------------------------------------------------------
     def _device(self) -> torch.device:
         return self.prompt_encoder.no_mask_embed.weight.device
 
-    def engine(self) -> LamEngine:
+    def engine(self, validate: bool = True) -> LamEngine:
+        """Packed-weight engine for the current parameters.  validate=True re-checks the parameter versions (so in-place
+        weight updates / load_state_dict through a wrapper are picked up); hot inner calls pass validate=False."""
+        if self._engine is not None and not validate:
+            return self._engine
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("labelanything_amd runs on an MI355X only: move the model to 'cuda' (no CPU fallback)")
-        key = (dev, self.compute_dtype, tuple(p._version for p in self.parameters()))
+        if self._plist is None:
+            self._plist = list(self.parameters()) + list(self.buffers())
+        key = (dev, self.compute_dtype, sum(p._version for p in self._plist))
         if self._engine is None or self._engine_key != key:
             self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype)
             self._engine_key = key
@@ -112,6 +119,7 @@ class Lam(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         self._engine = None
+        self._plist = None
         return super()._apply(fn, *a, **kw)
 
     # -- reference API --------------------------------------------------------------------------------
@@ -124,7 +132,7 @@ class Lam(nn.Module):
 
     def _embeddings_nhwc(self, batched_input: Dict[str, Any], apply_neck_to_embeddings: bool):
         """-> (emb32 [B*N*hw, D] NHWC fp32, B, N, g).  lam.py:138-170 / :187-212."""
-        eng = self.engine()
+        eng = self.engine(validate=False)
         cfg = self.cfg
         if "embeddings" in batched_input:
             emb = batched_input["embeddings"]
@@ -178,14 +186,14 @@ class Lam(nn.Module):
     @torch.no_grad()
     def forward(self, batched_input: Dict[str, Any]) -> Dict[str, torch.Tensor]:
         seg, pe_result = self._forward(batched_input)
-        logits = self.engine().postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"))
+        logits = self.engine(False).postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"))
         return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"]}
 
     @torch.no_grad()
     def forward_argmax(self, batched_input: Dict[str, Any]):
         """forward + the caller's ``logits.argmax(dim=1)`` (experiment/run.py:697) fused into the last kernel."""
         seg, pe_result = self._forward(batched_input)
-        logits, am = self.engine().postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"), want_argmax=True)
+        logits, am = self.engine(False).postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"), want_argmax=True)
         return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"], "argmax": am}
 
     def postprocess_masks(self, masks: torch.Tensor, original_sizes: torch.Tensor) -> torch.Tensor:
