@@ -32,12 +32,12 @@ import torch  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0      # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def build_model(dtype):
+def build_model(dtype, decoder_dtype=torch.float32):
     from labelanything_amd.config import LamConfig
     from labelanything_amd.models import Lam
     cfg = LamConfig(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3,
                     custom_preprocess=False)
-    return Lam(cfg, seed=2, compute_dtype=dtype), cfg
+    return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype), cfg
 
 
 def make_inputs(episodes: int, seed: int, device):
@@ -50,15 +50,17 @@ def make_inputs(episodes: int, seed: int, device):
 class KernelTimer:
     """Wraps labelanything_amd._lib launch functions with HIP events on the current (launch) stream."""
 
-    def __init__(self):
+    def __init__(self, by_shape: bool = False):
         self.records = []
+        self.by_shape = by_shape
 
     def __enter__(self):
         from labelanything_amd import _lib as L
         self.L = L
         self.saved = {}
         names = ["gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
-                 "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc"]
+                 "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
+                 "conv3x3_f32", "nhwc_to_nchw", "dense_pe"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -75,7 +77,10 @@ class KernelTimer:
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
                     flops = 4.0 * b * heads * t * t * 64
-                self.records.append((_n, flops, s, e))
+                tag = _n
+                if _n == "gemm" and self.by_shape:
+                    tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
+                self.records.append((tag, flops, s, e))
             setattr(L, n, wrapped)
         return self
 
@@ -119,7 +124,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--episodes", type=int, default=4, help="episodes per step per GPU")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--decoder", default="f32", choices=["f32", "same"], help="operand type of the decoder-side GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,8 +143,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
-    lam, cfg = build_model(dtype)
+    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None)
     lam = lam.to(dev)
+    lam.use_graphs = not a.no_graphs
     batch = make_inputs(a.episodes, 1234 + rank, dev)
 
     def barrier():
@@ -163,9 +172,16 @@ def main():
     roof = None
     kernels = None
     if rank == 0:
+        lam.use_graphs = False          # per-kernel events need eager launches
         with KernelTimer() as kt:
             lam(batch)
         agg = kt.summary()
+        if a.gemm_shapes:
+            with KernelTimer(by_shape=True) as kt2:
+                lam(batch)
+            for n, v in sorted(kt2.summary().items(), key=lambda kv: -kv[1][1]):
+                if n.startswith("gemm"):
+                    print(f"{n:44s} x{v[0]:3d}  {v[1]*1e3:8.3f} ms  {v[2]/max(v[1],1e-12)/1e12:7.1f} TF/s", file=sys.stderr)
         g = agg.get("gemm")
         tot = sum(v[1] for v in agg.values())
         kernels = {n: {"launches": v[0], "ms": round(v[1] * 1e3, 3)} for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
@@ -181,11 +197,12 @@ def main():
         line = {
             "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot", "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes "
                                    "(2 images each), random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes, "images_per_sec": round(eps * 2, 2),
-                       "parallelism": f"episode-sharded x{world}, no collective"},
+                       "parallelism": f"episode-sharded x{world}, no collective",
+                       "launch": "eager" if a.no_graphs else "hipGraph replay"},
             "roofline": roof, "kernels_ms_per_step": kernels,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -9,7 +9,8 @@
  *
  * Conventions
  *  - plain C, raw DEVICE pointers (tensor.data_ptr()), explicit sizes / leading dimensions in ELEMENTS;
- *  - `dt` selects the 16-bit storage / MFMA operand type: LA_F16 or LA_BF16 (accumulation is fp32);
+ *  - `dt` selects the storage / MFMA operand type of the "16-bit" buffers: LA_F16, LA_BF16 (accumulation is fp32)
+ *    or LA_F32 (the same buffers then hold fp32; supported by every entry point except the encoder attention pair);
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden syncs,
  *    no allocation, the caller owns every buffer and workspace;
  *  - returns 0 on success, <0 on error; la_last_error() gives the message (thread local).
@@ -20,7 +21,9 @@
 extern "C" {
 #endif
 
-enum { LA_F16 = 0, LA_BF16 = 1 };
+/* LA_F32: operands stay fp32 and la_gemm runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the 16-bit rate);
+ * used for the small decoder stages where 16-bit operand rounding would dominate the logit error. */
+enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2 };
 enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2 };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
 enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3 };
@@ -64,6 +67,12 @@ typedef struct LaGemmEpilogue {
  * build_lam.py:154-170 (neck), common.py:103-105,146 (decoder projections), mask_decoder.py:206-229. */
 int la_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
             const LaGemmEpilogue* epi, int dt, void* stream);
+
+/* 3x3 / pad 1 convolution as an IMPLICIT GEMM on the exact-fp32 MFMA (no im2col buffer): in fp32 NHWC [B,H,W,Cin]
+ * (Cin % 32 == 0), wt fp32 [Cout, (ky,kx,cin)], bias fp32 [Cout] or NULL -> out32 fp32 NHWC [B*H*W, Cout]
+ * (spatial convs of the mask decoder, mask_decoder.py:236-255). */
+int la_conv3x3_f32(const float* in, int B, int H, int W, int Cin, const float* wt, const float* bias, int Cout, float* out32,
+                   void* stream);
 
 /* Row LayerNorm over the last dim (biased variance):  y = LN(x [+ x2]) * gamma + beta  [-> GELU].
  * x, x2 fp32 [rows, E] (ldx).  Outputs (each optional): out32 fp32, out16, out16_pe = y + pe[(row % pe_mod)]

@@ -15,12 +15,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libla_hip.so")
 
-LA_F16, LA_BF16 = 0, 1
+LA_F16, LA_BF16, LA_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 MAP_NONE, MAP_GROUP, MAP_WINDOW_MERGE, MAP_CONVT2X2 = 0, 1, 2, 3
 ATTN_PLAIN, ATTN_RELPOS = 0, 1
 
-_DT = {torch.float16: LA_F16, torch.bfloat16: LA_BF16}
+_DT = {torch.float16: LA_F16, torch.bfloat16: LA_BF16, torch.float32: LA_F32}
 
 
 class LaGemmEpilogue(C.Structure):
@@ -57,7 +57,7 @@ def lib() -> C.CDLL:
 EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
-    "la_classify", "la_add_cast", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
+    "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
 ]
 
 
@@ -216,3 +216,9 @@ def bilinear(x, n: int, h: int, w: int, oh: int, ow: int, out) -> None:
 def post_final(big, b: int, c: int, s: int, sizes_i32, flag_gts_u8, hmax: int, wmax: int, logits, argmax) -> None:
     _check(lib().la_post_final(_ptr(big), C.c_int(b), C.c_int(c), C.c_int(s), _ptr(sizes_i32), _ptr(flag_gts_u8), C.c_int(hmax),
                                C.c_int(wmax), _ptr(logits), _ptr(argmax), _stream()), "la_post_final")
+
+
+def conv3x3_f32(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out32) -> None:
+    _dev(x32)
+    _check(lib().la_conv3x3_f32(_ptr(x32), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(cin), _ptr(wt), _ptr(bias), C.c_int(cout),
+                                _ptr(out32), _stream()), "la_conv3x3_f32")

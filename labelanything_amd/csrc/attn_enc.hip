@@ -174,28 +174,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     keyinfo = ki;
   }
 
-  // ---- K / V^T tile staging ----------------------------------------------------------------------------
-  const int lc = tid & 7, lr = tid >> 3;  // chunk, row (rows lr and lr + 32)
-  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * HD + lc * 8;
-  const T* vbase = vt + ((size_t)bh * HD) * a.Tpad + lc * 8;
-  uint4 rk[2], rv[2];
-  auto gload = [&](int j) {
+  // ---- K / V^T tile staging by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per wave instruction) ----------
+  // The DMA destination is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk (row = lane/8, slot = lane%8
+  // holds logical chunk slot ^ ((row>>1)&7)).  No staging registers: hipcc parked the register-staged variant in
+  // scratch and exposed the whole load latency every tile.
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const T* ksrc[2];
+  const T* vsrc[2];
+  int krow[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = lr + 32 * i;
-      const int key = min(j * 64 + row, T_ - 1);
-      rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * E3);
-      rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)row * a.Tpad + j * 64);
-    }
-  };
-  auto swrite = [&](int stage) {
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);        // tile row 0..63
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    krow[i] = row;
+    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HD + chunk * 8;
+    vsrc[i] = vt + ((size_t)bh * HD + row) * a.Tpad + chunk * 8;
+  }
+  auto dma = [&](int j, int stage) {
     char* sk = smem + stage * KV_STAGE;
     char* sv = sk + 64 * HD * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = lr + 32 * i;
-      *reinterpret_cast<uint4*>(sk + swz_off(row, lc)) = rk[i];
-      *reinterpret_cast<uint4*>(sv + swz_off(row, lc)) = rv[i];
+      const int key = min(j * 64 + krow[i], T_ - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[i] + (size_t)key * E3), (lptr_t)(sk + (i * 4 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + j * 64), (lptr_t)(sv + (i * 4 + wave) * 1024), 16, 0, 0);
     }
   };
 
@@ -207,11 +210,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   float m_run = NEG_BIG, l_run = 0.f;
 
   const int ntiles = (T_ + 63) >> 6;
-  gload(0);
-  swrite(0);
+  dma(0, 0);
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
-    if (j + 1 < ntiles) gload(j + 1);
+    if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
     const char* sk = smem + (j & 1) * KV_STAGE;
     const char* sv = sk + 64 * HD * 2;
 
@@ -311,8 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
 
-    if (j + 1 < ntiles) swrite((j + 1) & 1);
-    __syncthreads();
+    __syncthreads();   // drains this wave's DMA (vmcnt) and orders the stage swap
   }
 
   // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
@@ -334,7 +335,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
 template <typename T, int MODE>
 static void launch_attn(const AttnArgs& a, size_t lds, hipStream_t st) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t attr_lds = 0;   // raise the dynamic-LDS limit once (and again only if a larger request shows up)
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
   const int nq = (a.T + 127) / 128;
   hipLaunchKernelGGL((attn_fwd_kernel<T, MODE>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
 }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(SmallAttnArgs a) {
     if (a.out16) {
       T* op = reinterpret_cast<T*>(a.out16) + bq * a.ldo + h * HDIM;
 #pragma unroll
-      for (int d = 0; d < HDIM; d += 2) *reinterpret_cast<uint32_t*>(op + d) = pack2<T>(acc[d] * inv, acc[d + 1] * inv);
+      for (int d = 0; d < HDIM; d += 2) store2<T>(op + d, acc[d] * inv, acc[d + 1] * inv);
     }
   }
 }
@@ -488,6 +488,7 @@ extern "C" int la_mask_embed(const float* masks, const int* flags, int P, int C,
   dim3 grid((hw + ME_PIX - 1) / ME_PIX, P);
   if (dt == LA_F16) hipLaunchKernelGGL(mask_embed_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (dt == LA_BF16) hipLaunchKernelGGL(mask_embed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (dt == LA_F32) hipLaunchKernelGGL(mask_embed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else LA_CHECK_ARG(false, "la_mask_embed: bad dtype %d", dt);
   LA_CHECK_LAUNCH("la_mask_embed");
   return 0;
@@ -522,7 +523,8 @@ extern "C" int la_attn_small(const float* q, int ldq, const float* k, int ldk, c
   LA_CHECK_ARG(B > 0 && Nq > 0 && Nk > 0 && heads > 0, "la_attn_small: bad shape");
   LA_CHECK_ARG((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 2) == 0, "la_attn_small: leading dims must be multiples of 4");
   SmallAttnArgs a{q, k, v, ldq, ldk, ldv, ldo, B, Nq, Nk, heads, 1.0f / sqrtf((float)hd), out16, out32};
-  int rc = (dt == LA_BF16) ? dispatch_small<bf16_t>(a, hd, (hipStream_t)stream) : dispatch_small<f16_t>(a, hd, (hipStream_t)stream);
+  int rc = (dt == LA_BF16) ? dispatch_small<bf16_t>(a, hd, (hipStream_t)stream)
+           : (dt == LA_F32) ? dispatch_small<float>(a, hd, (hipStream_t)stream) : dispatch_small<f16_t>(a, hd, (hipStream_t)stream);
   LA_CHECK_ARG(rc == 0, "la_attn_small: unsupported head dim %d (4, 8, 16, 32, 64)", hd);
   LA_CHECK_LAUNCH("la_attn_small");
   return 0;
@@ -561,6 +563,7 @@ extern "C" int la_add_cast(const float* x, const float* y, int ymod, long rows, 
   LA_CHECK_ARG(x && (out32 || out16) && rows > 0 && D > 0, "la_add_cast: bad arguments");
   const int grid = grid_for(rows * D);
   if (dt == LA_BF16) hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (bf16_t*)out16);
+  else if (dt == LA_F32) hipLaunchKernelGGL(add_cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (float*)out16);
   else hipLaunchKernelGGL(add_cast_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (f16_t*)out16);
   LA_CHECK_LAUNCH("la_add_cast");
   return 0;
@@ -570,6 +573,7 @@ extern "C" int la_nchw_to_nhwc(const float* in, int N, int C, int HW, float* out
   LA_CHECK_ARG(in && (out32 || out16) && N > 0 && C > 0 && HW > 0, "la_nchw_to_nhwc: bad arguments");
   dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
   if (dt == LA_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, N, C, HW, out32, (bf16_t*)out16);
+  else if (dt == LA_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, in, N, C, HW, out32, (float*)out16);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, in, N, C, HW, out32, (f16_t*)out16);
   LA_CHECK_LAUNCH("la_nchw_to_nhwc");
   return 0;

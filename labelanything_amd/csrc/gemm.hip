@@ -175,6 +175,140 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
 }
 
 
+
+// -----------------------------------------------------------------------------------------------------------------
+// Shared LDS-staged epilogue.  Each wave owns TI x TJ MFMA 32x32 accumulators at (wrow0, wcol0) inside a 128-row chunk
+// of the block tile; the chunk is staged as fp32 [128][BN_ + 4] and then every thread handles 8 consecutive columns of
+// one row: float4 bias / residual loads, 16-byte (16-bit) or 2 x 16-byte (fp32) stores.  Tiles of the transposed-V
+// region are staged column-major instead so that consecutive tokens are contiguous in the V^T buffer.
+// -----------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v) {
+  uint4 o;
+  o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <typename T, int TI, int TJ, int BN_, int NT>
+__device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI][TJ], int nchunks, int my_chunk, int wrow0, int wcol0,
+                                             int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid) {
+  constexpr int LD = BN_ + 4;
+  const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  T* outT = reinterpret_cast<T*>(e.out16);
+  T* vt = reinterpret_cast<T*>(e.vt);
+  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk > 0) __syncthreads();
+    if (my_chunk == chunk) {
+      if (!vt_tile) {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              epi[(wrow0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + wcol0 + tj * 32 + fr] = acc[ti][tj][r];
+      } else {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < TJ; ++tj)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
+              *reinterpret_cast<float4*>(&epi[(wcol0 + tj * 32 + fr) * LD + wrow0 + ti * 32 + 8 * g4 + 4 * fh]) = v;
+            }
+      }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + chunk * 128;
+    if (vt_tile) {
+      for (int it = tid; it < BN_ * 32; it += NT) {
+        const int rg = it & 31, c = it >> 5;
+        const int col = n0 + c, row = mrow0 + rg * 4;
+        if (col >= N || row >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&epi[c * LD + rg * 4]);
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const int cv = col - e.vt_col0;
+        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
+        const int b = row / e.vt_T, t = row % e.vt_T;
+        T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + t;
+        if ((e.vt_T & 3) == 0 && row + 3 < M) {
+          store4v<T>(dst, v.x + bias, v.y + bias, v.z + bias, v.w + bias);
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4; ++j) {
+            const int rj = row + j;
+            if (rj >= M) break;
+            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
+            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + tj2] = (T)(vv[j] + bias);
+          }
+        }
+      }
+      continue;
+    }
+    constexpr int CG = BN_ / 8;
+    for (int it = tid; it < 128 * CG; it += NT) {
+      const int cg = it % CG, r = it / CG;
+      const int row = mrow0 + r, col0 = n0 + cg * 8;
+      if (row >= M || col0 >= N) continue;
+      float v[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8 + 4]);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      }
+      int dcol = col0, row_add = 0, bcol = col0;
+      if (e.map == LA_MAP_CONVT2X2) {
+        const int kyx = col0 / e.p2;
+        dcol = col0 % e.p2;
+        bcol = dcol;
+        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+      }
+      if (e.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (e.act == LA_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+      } else if (e.act == LA_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      int drow = map_row(rm, row);
+      if (drow < 0) continue;
+      drow += row_add;
+      if (e.res) {
+        const int rr = e.res_mod ? drow % e.res_mod : drow;
+        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
+        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
+      if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
+    }
+  }
+}
+
+static bool epi_vec_ok(int N, const LaGemmEpilogue& e, int elt_bytes) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if ((N % 8) != 0) return false;
+  if (e.bias && !al16(e.bias)) return false;
+  if (e.res && (!al16(e.res) || (e.ldr % 4) != 0)) return false;
+  if (e.out32 && (!al16(e.out32) || (e.ld32 % 4) != 0)) return false;
+  if (e.out16 && (!al16(e.out16) || (e.ld16 % (16 / elt_bytes)) != 0)) return false;
+  if (e.map == LA_MAP_CONVT2X2 && (e.p2 % 8) != 0) return false;
+  if (e.vt && ((e.vt_col0 % BN) != 0 || (e.vt_Tpad % 4) != 0 || !al16(e.vt))) return false;
+  return true;
+}
+
 // =================================================================================================================
 // v2 fast path (K % 64 == 0, N % 8 == 0, 16-byte aligned rows): operand tiles go global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass; the XOR swizzle is applied to the per-lane SOURCE
@@ -263,118 +397,7 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
   }
 
   // ---- epilogue through LDS, 128 rows at a time ----------------------------------------------------------------
-  float* epi = reinterpret_cast<float*>(smem);
-  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
-  T* out16 = reinterpret_cast<T*>(e.out16);
-  T* vt = reinterpret_cast<T*>(e.vt);
-  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
-#pragma unroll 1
-  for (int chunk = 0; chunk < BM_ / 128; ++chunk) {
-    if (chunk > 0) __syncthreads();
-    if ((wm >> 1) == chunk) {
-      const int rbase = (wm & 1) * 64;
-      if (!vt_tile) {
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              epi[(rbase + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + wn * 64 + tj * 32 + fr] = acc[ti][tj][r];
-      } else {  // transposed staging [col][row] so that rows (tokens) are contiguous
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
-              *reinterpret_cast<float4*>(&epi[(wn * 64 + tj * 32 + fr) * EPI_LD + rbase + ti * 32 + 8 * g4 + 4 * fh]) = v;
-            }
-      }
-    }
-    __syncthreads();
-    const int mrow0 = m0 + chunk * 128;
-    if (vt_tile) {
-      // items: (col c, 4-row group rg); rg fastest so a wave writes contiguous tokens
-      for (int it = tid; it < BN * 32; it += NT) {
-        const int rg = it & 31, c = it >> 5;
-        const int col = n0 + c, row = mrow0 + rg * 4;
-        if (col >= N || row >= M) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&epi[c * EPI_LD + rg * 4]);
-        const float bias = e.bias ? e.bias[col] : 0.f;
-        const int cv = col - e.vt_col0;
-        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
-        const int b = row / e.vt_T, t = row % e.vt_T;
-        T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + t;
-        if ((e.vt_T & 3) == 0 && row + 3 < M) {
-          uint2 o;
-          o.x = pack2<T>(v.x + bias, v.y + bias);
-          o.y = pack2<T>(v.z + bias, v.w + bias);
-          *reinterpret_cast<uint2*>(dst) = o;
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int j = 0; j < 4; ++j) {
-            const int rj = row + j;
-            if (rj >= M) break;
-            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
-            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + tj2] = (T)(vv[j] + bias);
-          }
-        }
-      }
-      continue;
-    }
-    constexpr int CG = BN / 8;
-    for (int it = tid; it < 128 * CG; it += NT) {
-      const int cg = it % CG, r = it / CG;
-      const int row = mrow0 + r, col0 = n0 + cg * 8;
-      if (row >= M || col0 >= N) continue;
-      float v[8];
-      {
-        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * EPI_LD + cg * 8]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * EPI_LD + cg * 8 + 4]);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-      }
-      int dcol = col0, row_add = 0, bcol = col0;
-      if (e.map == LA_MAP_CONVT2X2) {
-        const int kyx = col0 / e.p2;
-        dcol = col0 % e.p2;
-        bcol = dcol;
-        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
-      }
-      if (e.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
-        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (e.act == LA_ACT_GELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-      } else if (e.act == LA_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      int drow = map_row(rm, row);
-      if (drow < 0) continue;
-      drow += row_add;
-      if (e.res) {
-        const int rr = e.res_mod ? drow % e.res_mod : drow;
-        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
-        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-      }
-      if (e.out32) {
-        float4* o = reinterpret_cast<float4*>(e.out32 + (size_t)drow * e.ld32 + dcol);
-        o[0] = make_float4(v[0], v[1], v[2], v[3]);
-        o[1] = make_float4(v[4], v[5], v[6], v[7]);
-      }
-      if (out16) {
-        uint4 o;
-        o.x = pack2<T>(v[0], v[1]); o.y = pack2<T>(v[2], v[3]); o.z = pack2<T>(v[4], v[5]); o.w = pack2<T>(v[6], v[7]);
-        *reinterpret_cast<uint4*>(out16 + (size_t)drow * e.ld16 + dcol) = o;
-      }
-    }
-  }
+  epilogue_lds<T, 2, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, BM_ / 128, wm >> 1, (wm & 1) * 64, wn * 64, m0, n0, M, N, e, tid);
 }
 
 template <typename T, int BM_>
@@ -392,15 +415,258 @@ static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, i
 
 static bool fast_ok(const void* A, int lda, const void* W, int ldw, int N, int K, const LaGemmEpilogue& e) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  if ((K % 64) != 0 || (N % 8) != 0) return false;
+  if ((K % 64) != 0) return false;
   if (!al16(A) || !al16(W)) return false;
-  if (e.bias && !al16(e.bias)) return false;
-  if (e.res && (!al16(e.res) || (e.ldr % 4) != 0)) return false;
-  if (e.out32 && (!al16(e.out32) || (e.ld32 % 4) != 0)) return false;
-  if (e.out16 && (!al16(e.out16) || (e.ld16 % 8) != 0)) return false;
-  if (e.map == LA_MAP_CONVT2X2 && (e.p2 % 8) != 0) return false;
-  if (e.vt && ((e.vt_col0 % BN) != 0 || (e.vt_Tpad % 4) != 0 || !al16(e.vt))) return false;
-  return true;
+  return epi_vec_ok(N, e, 2);
+}
+
+
+// =================================================================================================================
+// fp32 path (dt == LA_F32): exact-fp32 MFMA v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, 157 TF/s peak).
+// Same 128 x 128 tile / 4 waves / register-staged double buffer as gemm_nt_kernel with BK = 32 floats (128-byte
+// rows, identical swizzle).  A 16-byte chunk holds k = 4c..4c+3; lane half fh consumes k = 2s + fh of MFMA step s.
+// Used for the decoder stages only (a few GFLOP per episode), so simplicity wins over the last TF/s.
+// =================================================================================================================
+constexpr int BKF = 32;
+
+// Implicit im2col for a 3x3 / pad 1 convolution over an NHWC fp32 map with Cin % 32 == 0: k-tile kt covers input
+// channels [32*(kt % cpt), +32) of tap kt / cpt (cpt = Cin / 32); A row = output pixel (b, y, x).
+struct ConvA {
+  int enabled, H, W, Cin;
+};
+
+template <int BN_>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Wt, int ldw,
+                                                          int M, int N, int K, LaGemmEpilogue e, ConvA cv, int vec_epi) {
+  // wave layout: BN_ = 128 -> 2 x 2 waves of 64 x 64; BN_ = 32 -> 4 x 1 waves of 32 x 32
+  constexpr int TI = (BN_ == 128) ? 2 : 1;   // 32-row MFMA tiles per wave
+  constexpr int TJ = (BN_ == 128) ? 2 : 1;
+  constexpr int WROWS = TI * 32, WCOLS = TJ * 32;
+  constexpr int NWR = BN_ / 32;              // W-tile 32-row groups loaded per k-tile (4 or 1)
+  constexpr int STAGE = (BM + BN_) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (BN_ == 128) ? (wave >> 1) : wave, wn = (BN_ == 128) ? (wave & 1) : 0;
+  const int ntn = (N + BN_ - 1) / BN_, ntm = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN_;
+  const int lc = tid & 7, lr = tid >> 3;
+  const float* a_ptr[4];
+  const float* w_ptr[NWR];
+  int py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = min(m0 + lr + 32 * i, M - 1);
+    if (cv.enabled) {
+      px[i] = row % cv.W;
+      py[i] = (row / cv.W) % cv.H;
+      a_ptr[i] = A + (size_t)row * cv.Cin + lc * 4;     // centre pixel
+    } else {
+      px[i] = py[i] = 0;
+      a_ptr[i] = A + (size_t)row * lda + lc * 4;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NWR; ++i) w_ptr[i] = Wt + (size_t)min(n0 + lr + 32 * i, N - 1) * ldw + lc * 4;
+  uint4 ra_[4], rw_[NWR];
+  const int cpt = cv.enabled ? cv.Cin / 32 : 1;
+  auto gload = [&](int kt) {
+    const int k0 = kt * BKF;
+    const bool ok = (k0 + lc * 4) < K;
+    if (cv.enabled) {
+      const int tap = kt / cpt, c0 = (kt % cpt) * 32;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int yy = py[i] + dy, xx = px[i] + dx;
+        const bool in = (yy >= 0) && (yy < cv.H) && (xx >= 0) && (xx < cv.W);
+        ra_[i] = in ? *reinterpret_cast<const uint4*>(a_ptr[i] + (long)(dy * cv.W + dx) * cv.Cin + c0) : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra_[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) rw_[i] = ok ? *reinterpret_cast<const uint4*>(w_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+  };
+  auto swrite = [&](int stage) {
+    char* sa = smem + stage * STAGE;
+    char* sw = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sa + swz_off(lr + 32 * i, lc)) = ra_[i];
+#pragma unroll
+    for (int i = 0; i < NWR; ++i) *reinterpret_cast<uint4*>(sw + swz_off(lr + 32 * i, lc)) = rw_[i];
+  };
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = (K + BKF - 1) / BKF;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* sa = smem + (kt & 1) * STAGE;
+    const char* sw = sa + BM * 128;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      // lane half fh owns floats {2fh, 2fh+1} of the 16-byte chunk (any k permutation is fine as long as A and W agree):
+      // one 8-byte LDS read per operand and NO runtime vector indexing (which hipcc lowers through scratch memory).
+      float2 af[TI], wf[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const float2*>(sa + swz_off(wm * WROWS + i * 32 + fr, c) + fh * 8);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) wf[j] = *reinterpret_cast<const float2*>(sw + swz_off(wn * WCOLS + j * 32 + fr, c) + fh * 8);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, wf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, wf[j].y, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) swrite((kt + 1) & 1);
+    __syncthreads();
+  }
+  if (vec_epi) {   // block-uniform: LDS-staged 16-byte epilogue (the stage buffers are free after the last barrier)
+    epilogue_lds<float, TI, TJ, BN_, 256>(reinterpret_cast<float*>(smem), acc, 1, 0, wm * WROWS, wn * WCOLS, m0, n0, M, N, e, tid);
+    return;
+  }
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  float* outT = reinterpret_cast<float*>(e.out16);
+#pragma unroll
+  for (int tj = 0; tj < TJ; ++tj) {
+    const int col = n0 + wn * WCOLS + tj * 32 + fr;
+    if (col >= N) continue;
+    int dcol = col, row_add = 0, bcol = col;
+    if (e.map == LA_MAP_CONVT2X2) {
+      const int kyx = col / e.p2;
+      dcol = col % e.p2;
+      bcol = dcol;
+      row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+    }
+    const float bias = e.bias ? e.bias[bcol] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WROWS + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row >= M) continue;
+        float v = acc[ti][tj][r] + bias;
+        if (e.act == LA_ACT_GELU) v = gelu_erf(v);
+        else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
+        int drow = map_row(rm, row);
+        if (drow < 0) continue;
+        drow += row_add;
+        if (e.res) {
+          const int rr = e.res_mod ? drow % e.res_mod : drow;
+          v += e.res[(size_t)rr * e.ldr + dcol];
+        }
+        if (e.out32) e.out32[(size_t)drow * e.ld32 + dcol] = v;
+        if (outT) outT[(size_t)drow * e.ld16 + dcol] = v;
+      }
+    }
+  }
+}
+
+template <int BN_>
+static void launch_f32(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, const ConvA& cv,
+                       hipStream_t st) {
+  constexpr int EPI = 128 * (BN_ + 4) * 4;
+  constexpr int LDS = (2 * (BM + BN_) * 128) > EPI ? (2 * (BM + BN_) * 128) : EPI;
+  const int vec_epi = epi_vec_ok(N, e, 4) ? 1 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN_ - 1) / BN_;
+  hipLaunchKernelGGL(gemm_f32_kernel<BN_>, dim3(ntm * ntn), dim3(256), LDS, st, reinterpret_cast<const float*>(A), lda,
+                     reinterpret_cast<const float*>(W), ldw, M, N, K, e, cv, vec_epi);
+}
+
+// =================================================================================================================
+// skinny GEMM (M <= 32 rows: decoder tokens / class prototypes): y[m][n] = sum_k x[m][k] W[n][k] on the VALU in fp32.
+// One wave per 4 output columns; lanes stride over K in float4 / 8-half chunks (W streamed once, coalesced; the few x
+// rows stay in L1), per-lane partial sums for every (m, column) are reduced across the wave at the end.
+// =================================================================================================================
+template <typename T> struct Load8;     // 8 consecutive k values as floats
+template <> struct Load8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float* o) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+};
+template <typename T> struct Load8 {
+  static __device__ __forceinline__ void ld(const T* p, float* o) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = unpack_lo<T>(v.x); o[1] = unpack_hi<T>(v.x); o[2] = unpack_lo<T>(v.y); o[3] = unpack_hi<T>(v.y);
+    o[4] = unpack_lo<T>(v.z); o[5] = unpack_hi<T>(v.z); o[6] = unpack_lo<T>(v.w); o[7] = unpack_hi<T>(v.w);
+  }
+};
+
+constexpr int SK_COLS = 4;
+
+template <typename T, int MR>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw, int M, int N,
+                                                          int K, LaGemmEpilogue e) {
+  const int lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_COLS;
+  if (n0 >= N) return;
+  float acc[MR][SK_COLS];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c) acc[m][c] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    float w[SK_COLS][8];
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c) Load8<T>::ld(Wt + (size_t)min(n0 + c, N - 1) * ldw + k, w[c]);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        float x[8];
+        Load8<T>::ld(A + (size_t)m * lda + k, x);
+#pragma unroll
+        for (int c = 0; c < SK_COLS; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(x[j], w[c][j], acc[m][c]);
+      }
+    }
+  }
+  T* outT = reinterpret_cast<T*>(e.out16);
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+#pragma unroll
+    for (int c = 0; c < SK_COLS; ++c) {
+      const float s = wave_sum(acc[m][c]);
+      const int col = n0 + c;
+      if (lane == 0 && m < M && col < N) {
+        float v = s + (e.bias ? e.bias[col] : 0.f);
+        if (e.act == LA_ACT_GELU) v = gelu_erf(v);
+        else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
+        if (e.res) v += e.res[(size_t)(e.res_mod ? m % e.res_mod : m) * e.ldr + col];
+        if (e.out32) e.out32[(size_t)m * e.ld32 + col] = v;
+        if (outT) outT[(size_t)m * e.ld16 + col] = (T)v;
+      }
+    }
+  }
+}
+
+template <typename T>
+static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  const int waves = (N + SK_COLS - 1) / SK_COLS;
+  const dim3 grid((waves + 3) / 4), block(256);
+  const T* a = reinterpret_cast<const T*>(A);
+  const T* w = reinterpret_cast<const T*>(W);
+  if (M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<T, 8>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+  else if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<T, 16>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<T, 32>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
 }
 
 template <typename T>
@@ -424,11 +690,28 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                        void* stream) {
   LA_CHECK_ARG(A && W && epi, "la_gemm: null pointer");
   LA_CHECK_ARG(M > 0 && N > 0 && K > 0, "la_gemm: bad shape M=%d N=%d K=%d", M, N, K);
-  LA_CHECK_ARG((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0, "la_gemm: K, lda, ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K,
+  const int kq = (dt == LA_F32) ? 4 : 8;
+  LA_CHECK_ARG((K % kq) == 0 && (lda % kq) == 0 && (ldw % kq) == 0, "la_gemm: K, lda, ldw must be multiples of %d (K=%d lda=%d ldw=%d)", kq, K,
                lda, ldw);
   LA_CHECK_ARG(epi->out32 || epi->out16 || epi->vt, "la_gemm: no output");
-  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_gemm: bad dtype %d", dt);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_gemm: bad dtype %d", dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool skinny = (M <= 32) && (K % 8) == 0 && epi->map == LA_MAP_NONE && !epi->vt;
+  if (skinny) {
+    if (dt == LA_F32) la::launch_skinny<float>(A, lda, W, ldw, M, N, K, *epi, st);
+    else if (dt == LA_F16) la::launch_skinny<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    else la::launch_skinny<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
+  if (dt == LA_F32) {
+    LA_CHECK_ARG(!epi->vt, "la_gemm: the transposed-V epilogue is 16-bit only");
+    const la::ConvA nocv{0, 0, 0, 0};
+    if (N <= 32) la::launch_f32<32>(A, lda, W, ldw, M, N, K, *epi, nocv, st);
+    else la::launch_f32<128>(A, lda, W, ldw, M, N, K, *epi, nocv, st);
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
   static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1", "128", "256"
   bool fast = la::fast_ok(A, lda, W, ldw, N, K, *epi) && !(force && force[0] == 'v');
   if (fast) {
@@ -444,5 +727,22 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     else la::launch_gemm<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
   }
   LA_CHECK_LAUNCH("la_gemm");
+  return 0;
+}
+
+extern "C" int la_conv3x3_f32(const float* in, int B, int H, int W, int Cin, const float* wt, const float* bias, int Cout, float* out32,
+                              void* stream) {
+  LA_CHECK_ARG(in && wt && out32, "la_conv3x3_f32: null pointer");
+  LA_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && (Cin % 32) == 0 && Cout > 0, "la_conv3x3_f32: Cin=%d must be a multiple of 32", Cin);
+  LaGemmEpilogue e{};
+  e.bias = bias;
+  e.out32 = out32;
+  e.ld32 = Cout;
+  const la::ConvA cv{1, H, W, Cin};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int M = B * H * W, K = 9 * Cin;
+  if (Cout <= 32) la::launch_f32<32>(in, Cin, wt, K, M, Cout, K, e, cv, st);
+  else la::launch_f32<128>(in, Cin, wt, K, M, Cout, K, e, cv, st);
+  LA_CHECK_LAUNCH("la_conv3x3_f32");
   return 0;
 }

@@ -64,12 +64,12 @@ extern "C" int la_im2col_patch(const float* img, int Bn, int S, int patch, void*
 
 extern "C" int la_im2col_3x3(const void* in16, int B, int H, int W, int C, void* out16, int dt, void* stream) {
   LA_CHECK_ARG(in16 && out16, "la_im2col_3x3: null pointer");
-  LA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C % 8) == 0, "la_im2col_3x3: bad geometry (C=%d must be a multiple of 8)", C);
-  (void)dt;
-  const long total = (long)B * H * W * 9 * (C / 8);
+  const int per16 = (dt == LA_F32) ? 4 : 8;   // elements per 16-byte chunk
+  LA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C % per16) == 0, "la_im2col_3x3: bad geometry (C=%d must be a multiple of %d)", C, per16);
+  const long total = (long)B * H * W * 9 * (C / per16);
   int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(la::im2col_3x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const uint4*>(in16), B, H, W, C / 8, reinterpret_cast<uint4*>(out16));
+                     reinterpret_cast<const uint4*>(in16), B, H, W, C / per16, reinterpret_cast<uint4*>(out16));
   LA_CHECK_LAUNCH("la_im2col_3x3");
   return 0;
 }

@@ -39,6 +39,19 @@ template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float 
 template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t v) { return (float)from_bits16<T>((uint16_t)(v & 0xffffu)); }
 template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t v) { return (float)from_bits16<T>((uint16_t)(v >> 16)); }
 
+// store 2 / 4 consecutive values in the storage type (16-bit packed, or plain fp32)
+template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack2<T>(a, b); }
+template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+template <typename T> __device__ __forceinline__ void store4v(T* p, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = pack2<T>(a, b);
+  v.y = pack2<T>(c, d);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+template <> __device__ __forceinline__ void store4v<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

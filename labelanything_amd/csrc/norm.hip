@@ -26,12 +26,7 @@ struct LnArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) {
-  uint2 v;
-  v.x = pack2<T>(a, b);
-  v.y = pack2<T>(c, d);
-  *reinterpret_cast<uint2*>(p) = v;
-}
+__device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) { store4v<T>(p, a, b, c, d); }
 
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
@@ -139,11 +134,12 @@ extern "C" int la_layernorm(const float* x, const float* x2, int ldx, int rows, 
   LA_CHECK_ARG(out32 || out16 || out16_pe, "la_layernorm: no output");
   LA_CHECK_ARG(!out16_pe || pe, "la_layernorm: out16_pe needs pe");
   LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "la_layernorm: bad window geometry");
-  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_layernorm: bad dtype %d", dt);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_layernorm: bad dtype %d", dt);
   la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dt == LA_F16) la::launch_ln<la::f16_t>(a, st);
-  else la::launch_ln<la::bf16_t>(a, st);
+  else if (dt == LA_BF16) la::launch_ln<la::bf16_t>(a, st);
+  else la::launch_ln<float>(a, st);
   LA_CHECK_LAUNCH("la_layernorm");
   return 0;
 }

@@ -51,9 +51,15 @@ class Arena:
 
 
 class LamEngine:
-    def __init__(self, cfg: LamConfig, weights: Dict[str, Tensor], device: torch.device, dtype: torch.dtype = torch.float16):
+    def __init__(self, cfg: LamConfig, weights: Dict[str, Tensor], device: torch.device, dtype: torch.dtype = torch.float16,
+                 decoder_dtype: Optional[torch.dtype] = torch.float32):
+        """dtype: MFMA operand type of the image encoder and necks (>99% of the FLOPs).  decoder_dtype: operand type of the
+        prompt encoder / mask decoder GEMMs - fp32 by default (exact-fp32 MFMA; ~1% of the FLOPs but the stage where
+        16-bit operand rounding would dominate the logit error), or None to follow ``dtype``."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+        self.ddt = dtype if decoder_dtype is None else decoder_dtype
+        self.ddti = L._DT[self.ddt]
         L.lib()  # fail loudly if the HIP extension is missing
         self.cfg = cfg
         self.dev = device
@@ -72,21 +78,24 @@ class LamEngine:
     def _h(self, t: Tensor) -> Tensor:
         return t.to(self.dt).contiguous()
 
+    def _hd(self, t: Tensor) -> Tensor:
+        return t.to(self.ddt).contiguous()
+
     def _pack_attn(self, pre: str, fuse: str) -> None:
         """decoder Attention (common.py:57-148).  fuse: 'qkv' (same input), 'qk' (q,k share input), 'none'."""
         w, p = self.w32, self.p
         if fuse == "qkv":
-            p[pre + ".qkv.w"] = self._h(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"], w[pre + ".v_proj.weight"]]))
+            p[pre + ".qkv.w"] = self._hd(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"], w[pre + ".v_proj.weight"]]))
             p[pre + ".qkv.b"] = torch.cat([w[pre + ".q_proj.bias"], w[pre + ".k_proj.bias"], w[pre + ".v_proj.bias"]]).contiguous()
         if fuse == "qk":
-            p[pre + ".qk.w"] = self._h(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"]]))
+            p[pre + ".qk.w"] = self._hd(torch.cat([w[pre + ".q_proj.weight"], w[pre + ".k_proj.weight"]]))
             p[pre + ".qk.b"] = torch.cat([w[pre + ".q_proj.bias"], w[pre + ".k_proj.bias"]]).contiguous()
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            p[f"{pre}.{n}.w"] = self._h(w[f"{pre}.{n}.weight"])
+            p[f"{pre}.{n}.w"] = self._hd(w[f"{pre}.{n}.weight"])
 
     def _pack_mlp(self, pre: str) -> None:
-        self.p[pre + ".lin1.w"] = self._h(self.w32[pre + ".lin1.weight"])
-        self.p[pre + ".lin2.w"] = self._h(self.w32[pre + ".lin2.weight"])
+        self.p[pre + ".lin1.w"] = self._hd(self.w32[pre + ".lin1.weight"])
+        self.p[pre + ".lin2.w"] = self._hd(self.w32[pre + ".lin2.weight"])
 
     def _pack_two_way(self, pre: str) -> None:
         for l in range(2):
@@ -154,13 +163,13 @@ class LamEngine:
         md = "mask_decoder"
         self._pack_two_way(md + ".transformer")
         for i in range(3):
-            p[f"{md}.class_mlp.{i}.w"] = self._h(w[f"{md}.class_mlp.layers.{i}.weight"])
+            p[f"{md}.class_mlp.{i}.w"] = self._hd(w[f"{md}.class_mlp.layers.{i}.weight"])
         # ConvTranspose2d weight (Cin, Cout, 2, 2) -> GEMM weight [(ky, kx, cout), cin]
-        p[md + ".up0.w"] = self._h(w[md + ".output_upscaling.0.weight"].permute(2, 3, 1, 0).flatten(0, 2))
-        p[md + ".up3.w"] = self._h(w[md + ".output_upscaling.3.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+        p[md + ".up0.w"] = self._hd(w[md + ".output_upscaling.0.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+        p[md + ".up3.w"] = self._hd(w[md + ".output_upscaling.3.weight"].permute(2, 3, 1, 0).flatten(0, 2))
         if cfg.spatial_convs:
             for i in range(cfg.spatial_convs):
-                p[f"{md}.sc{i}.w"] = self._h(w[f"{md}.spatial_convs.{3 * i}.weight"].permute(0, 2, 3, 1).flatten(1))
+                p[f"{md}.sc{i}.w"] = self._hd(w[f"{md}.spatial_convs.{3 * i}.weight"].permute(0, 2, 3, 1).flatten(1))
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -175,6 +184,12 @@ class LamEngine:
 
     def buf(self, name, shape, dtype=None, zero=False) -> Tensor:
         return self.arena.get(name, shape, self.dt if dtype is None else dtype, zero)
+
+    def dbuf(self, name, shape) -> Tensor:
+        return self.arena.get(name, shape, self.ddt, False)
+
+    def dln(self, x, name, eps, **kw):
+        L.layernorm(x, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.ddti, **kw)
 
     def f32(self, name, shape, zero=False) -> Tensor:
         return self.arena.get(name, shape, torch.float32, zero)
@@ -358,8 +373,8 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     def _attn_core(self, q32, k32, v32, groups, nq, nk, internal, tag) -> Tensor:
         heads = self.cfg.dec_heads
-        o16 = self.buf(tag + ".o16", (groups * nq, internal))
-        L.attn_small(q32, k32, v32, groups, nq, nk, heads, internal // heads, out16=o16, dt=self.dti)
+        o16 = self.dbuf(tag + ".o16", (groups * nq, internal))
+        L.attn_small(q32, k32, v32, groups, nq, nk, heads, internal // heads, out16=o16, dt=self.ddti)
         return o16
 
     def attention_mlp_block(self, pre: str, x32: Tensor, groups: int, n: int, tag: str) -> Tensor:
@@ -367,20 +382,20 @@ class LamEngine:
         w, p = self.w32, self.p
         rows, d = x32.shape
         internal = p[pre + ".attn.q_proj.w"].shape[0]
-        x16 = self.buf(tag + ".x16", (rows, d))
-        L.add_cast(x32, out16=x16, dt=self.dti)
+        x16 = self.dbuf(tag + ".x16", (rows, d))
+        L.add_cast(x32, out16=x16, dt=self.ddti)
         qkv = self.f32(tag + ".qkv", (rows, 3 * internal))
         L.gemm(x16, p[pre + ".attn.qkv.w"], bias=p[pre + ".attn.qkv.b"], out32=qkv)
         o16 = self._attn_core(qkv[:, :internal], qkv[:, internal:2 * internal], qkv[:, 2 * internal:], groups, n, n, internal, tag)
         y = self.f32(tag + ".y", (rows, d))
         L.gemm(o16, p[pre + ".attn.out_proj.w"], bias=w[pre + ".attn.out_proj.bias"], res=x32, out32=y)
-        y16 = self.buf(tag + ".y16", (rows, d))
-        self.ln(y, pre + ".norm", 1e-5, out32=y, out16=y16)
-        hbuf = self.buf(tag + ".h", (rows, self.cfg.dec_mlp))
+        y16 = self.dbuf(tag + ".y16", (rows, d))
+        self.dln(y, pre + ".norm", 1e-5, out32=y, out16=y16)
+        hbuf = self.dbuf(tag + ".h", (rows, self.cfg.dec_mlp))
         L.gemm(y16, p[pre + ".mlp.lin1.w"], bias=w[pre + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
         z = self.f32(tag + ".z", (rows, d))
         L.gemm(hbuf, p[pre + ".mlp.lin2.w"], bias=w[pre + ".mlp.lin2.bias"], res=y, out32=z)
-        self.ln(z, pre + ".norm", 1e-5, out32=z)
+        self.dln(z, pre + ".norm", 1e-5, out32=z)
         return z
 
     def two_way(self, pre: str, tok32: Tensor, groups: int, nt: int, img32: Tensor, img16: Tensor, imgpe16: Tensor, hw: int,
@@ -394,14 +409,14 @@ class LamEngine:
         ri = groups * hw
         tpe = tok32
         t32 = self.f32(tag + ".t32", (r, d))
-        t16 = self.buf(tag + ".t16", (r, d))
-        tq16 = self.buf(tag + ".tq16", (r, d))
+        t16 = self.dbuf(tag + ".t16", (r, d))
+        tq16 = self.dbuf(tag + ".tq16", (r, d))
         tnew = self.f32(tag + ".tnew", (r, d))
         for l in range(2):
             lp = f"{pre}.layers.{l}"
             sa = lp + ".self_attn"
             if l == 0:
-                L.add_cast(tok32, out16=t16, dt=self.dti)
+                L.add_cast(tok32, out16=t16, dt=self.ddti)
                 qkv = self.f32(tag + ".sa_qkv", (r, 3 * d))
                 L.gemm(t16, p[sa + ".qkv.w"], bias=p[sa + ".qkv.b"], out32=qkv)
                 o16 = self._attn_core(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], groups, nt, nt, d, tag + ".sa")
@@ -413,7 +428,7 @@ class LamEngine:
                 L.gemm(t16, p[sa + ".v_proj.w"], bias=w[sa + ".v_proj.bias"], out32=v)
                 o16 = self._attn_core(qk[:, :d], qk[:, d:], v, groups, nt, nt, d, tag + ".sa")
                 L.gemm(o16, p[sa + ".out_proj.w"], bias=w[sa + ".out_proj.bias"], res=t32, out32=tnew)
-            self.ln(tnew, lp + ".norm1", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
+            self.dln(tnew, lp + ".norm1", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
             # tokens -> image
             ca = lp + ".cross_attn_token_to_image"
             q = self.f32(tag + ".tq", (r, di))
@@ -424,12 +439,12 @@ class LamEngine:
             L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
             o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
             L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
-            self.ln(tnew, lp + ".norm2", 1e-5, out32=t32, out16=t16)
+            self.dln(tnew, lp + ".norm2", 1e-5, out32=t32, out16=t16)
             # MLP (ReLU)
-            hbuf = self.buf(tag + ".mlp", (r, cfg.dec_mlp))
+            hbuf = self.dbuf(tag + ".mlp", (r, cfg.dec_mlp))
             L.gemm(t16, p[lp + ".mlp.lin1.w"], bias=w[lp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_RELU)
             L.gemm(hbuf, p[lp + ".mlp.lin2.w"], bias=w[lp + ".mlp.lin2.bias"], res=t32, out32=tnew)
-            self.ln(tnew, lp + ".norm3", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
+            self.dln(tnew, lp + ".norm3", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
             # image -> tokens
             ca = lp + ".cross_attn_image_to_token"
             qi = self.f32(tag + ".iq", (ri, di))
@@ -440,7 +455,7 @@ class LamEngine:
             L.gemm(t16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=vtok)
             oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t")
             L.gemm(oi16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
-            self.ln(img32, lp + ".norm4", 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32, pe_mod=hw)
+            self.dln(img32, lp + ".norm4", 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32, pe_mod=hw)
         if not want_tokens:
             return None, None
         ca = pre + ".final_attn_token_to_image"
@@ -452,22 +467,23 @@ class LamEngine:
         L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
         o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
         L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
-        self.ln(tnew, pre + ".norm_final_attn", 1e-5, out32=t32, out16=t16)
+        self.dln(tnew, pre + ".norm_final_attn", 1e-5, out32=t32, out16=t16)
         return t32, t16
 
     # ------------------------------------------------------------------------------------------------
     # prompt encoder (prompt_encoder.py:564-827)
     # ------------------------------------------------------------------------------------------------
     def _sparse_tokens(self, b, m, c, points, boxes) -> Tuple[Tensor, int]:
-        """Host-side bookkeeping of the sparse prompt tokens -> (xy, kind, shift) device arrays (index work only)."""
+        """Bookkeeping of the sparse prompt tokens -> (xy, kind, shift) device arrays.  Index work only, all on device
+        (inputs are device tensors) so that the whole forward can be captured in a HIP graph."""
         dev = self.dev
         pcount = b * m * c
         parts_xy, parts_kind, parts_shift = [], [], []
         if points is not None:
             xy, lab = points
-            xy = self.h2d(xy.reshape(pcount, -1, 2), torch.float32)
-            lab = self.h2d(lab.reshape(pcount, -1))
-            kind = torch.where(lab == 0, 0, torch.where(lab < 0, 1, 2)).to(torch.int32)
+            xy = xy.reshape(pcount, -1, 2).to(dev, torch.float32)
+            lab = lab.reshape(pcount, -1).to(dev)
+            kind = ((lab != 0).to(torch.int32) + (lab > 0).to(torch.int32))      # 0 NULL, 1 negative, 2 positive
             shift = torch.ones_like(kind)
             if boxes is None:   # extra token at (0,0), label -1 == NEGATIVE in this code base, not shifted (prompt_encoder.py:91-95)
                 xy = torch.cat([xy, torch.zeros(pcount, 1, 2, device=dev)], dim=1)
@@ -477,10 +493,10 @@ class LamEngine:
         if boxes is not None:
             bx, bf = boxes
             nb = bx.shape[3]
-            corners = self.h2d(bx.reshape(pcount, nb * 2, 2), torch.float32)
-            kind = torch.tensor([3, 4], dtype=torch.int32, device=dev).repeat(nb).expand(pcount, -1)
-            flags2 = self.h2d(bf.reshape(pcount, nb)).repeat(1, 2)            # tiled flags vs interleaved corners (:661-667)
-            kind = torch.where(flags2 == 0, 0, kind).to(torch.int32)
+            corners = bx.reshape(pcount, nb * 2, 2).to(dev, torch.float32)
+            kind = (torch.arange(2 * nb, device=dev, dtype=torch.int32) % 2 + 3).expand(pcount, -1)
+            flags2 = bf.reshape(pcount, nb).to(dev).repeat(1, 2)            # tiled flags vs interleaved corners (:661-667)
+            kind = (kind * (flags2 != 0).to(torch.int32)).contiguous()
             parts_xy.append(corners); parts_kind.append(kind); parts_shift.append(torch.ones_like(kind))
         if not parts_xy:
             xy = torch.zeros(pcount, 1, 2, device=dev)
@@ -490,6 +506,10 @@ class LamEngine:
             xy, kind, shift = torch.cat(parts_xy, 1), torch.cat(parts_kind, 1), torch.cat(parts_shift, 1)
         ns = kind.shape[1]
         return (xy.contiguous(), kind.contiguous(), shift.contiguous()), ns
+
+    def sample_rows(self, c: int) -> Tensor:
+        """RandomMatrixEncoder.sample_rows: a fresh permutation every forward, also in eval (prompt_encoder.py:245-248)."""
+        return torch.cat([torch.zeros(1, dtype=torch.long), torch.randperm(self.cfg.bank_size - 1)[: c - 1] + 1])
 
     def prompt_encoder(self, support32: Tensor, b: int, m: int, g: int, points, boxes, masks, flag_examples: Tensor,
                        selected_rows: Optional[Tensor] = None) -> Dict[str, Tensor]:
@@ -512,19 +532,18 @@ class LamEngine:
         sp = self.attention_mlp_block(pe_ + ".sparse_embedding_attention", sp, b * m, c * ns, "pe.sea")
         class_enc = None
         if cfg.bank_size:
-            if selected_rows is None:   # RandomMatrixEncoder draws a fresh permutation every forward, also in eval (:245-248)
-                selected_rows = torch.cat([torch.zeros(1, dtype=torch.long),
-                                           torch.randperm(cfg.bank_size - 1)[: c - 1] + 1])
+            if selected_rows is None:
+                selected_rows = self.sample_rows(c)
             class_enc = w[pe_ + ".class_encoder.pos_embedding"][0, 0].index_select(0, self.h2d(selected_rows)).contiguous()
             ce_rows = class_enc.repeat_interleave(ns, dim=0).contiguous()       # rows ordered (c, n)
             sp2 = self.f32("pe.sparse_ce", (pcount * ns, d))
-            L.add_cast(sp, ce_rows, c * ns, out32=sp2, dt=self.dti)
+            L.add_cast(sp, ce_rows, c * ns, out32=sp2, dt=self.ddti)
             sp = sp2
         # dense stream
         pe32 = self.dense_pe(g)
         src32 = self.f32("pe.src32", (pcount * hw, d))
-        src16 = self.buf("pe.src16", (pcount * hw, d))
-        srcpe16 = self.buf("pe.srcpe16", (pcount * hw, d))
+        src16 = self.dbuf("pe.src16", (pcount * hw, d))
+        srcpe16 = self.dbuf("pe.srcpe16", (pcount * hw, d))
         if masks is not None:
             mk, mf = masks
             mk = self.h2d(mk, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
@@ -532,10 +551,10 @@ class LamEngine:
                 raise ValueError("prompt masks must be square")
             mf = self.h2d(mf.reshape(pcount), torch.int32).contiguous()
             L.mask_embed(mk, mf, pcount, c, mk.shape[-1], g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16,
-                         srcpe16, self.dti)
+                         srcpe16, self.ddti)
         else:
             L.mask_embed(None, None, pcount, c, 0, g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16, srcpe16,
-                         self.dti)
+                         self.ddti)
         self.two_way(pe_ + ".transformer", sp, pcount, ns, src32, src16, srcpe16, hw, pe32, "pe.tw", want_tokens=False)
         emb = self.f32("pe.emb", (pcount, d))
         L.colmean(src32, pcount, hw, d, emb)
@@ -565,16 +584,16 @@ class LamEngine:
         c = class_emb.shape[1]
         pe32 = self.dense_pe(g)
         img32 = self.f32("md.img32", (b * hw, d))
-        img16 = self.buf("md.img16", (b * hw, d))
-        imgpe16 = self.buf("md.imgpe16", (b * hw, d))
-        L.add_cast(query32, out32=img32, out16=img16, dt=self.dti)
-        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.dti)
+        img16 = self.dbuf("md.img16", (b * hw, d))
+        imgpe16 = self.dbuf("md.imgpe16", (b * hw, d))
+        L.add_cast(query32, out32=img32, out16=img16, dt=self.ddti)
+        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.ddti)
         tok = self.h2d(class_emb, torch.float32).reshape(b * c, d).contiguous()
         t32, t16 = self.two_way(md + ".transformer", tok, b, c, img32, img16, imgpe16, hw, pe32, "md.tw", want_tokens=True)
         # class_mlp (3 x Linear, ReLU between) -> prototypes
-        h1 = self.buf("md.cm1", (b * c, d))
+        h1 = self.dbuf("md.cm1", (b * c, d))
         L.gemm(t16, p[md + ".class_mlp.0.w"], bias=w[md + ".class_mlp.layers.0.bias"], out16=h1, act=L.ACT_RELU)
-        h2 = self.buf("md.cm2", (b * c, d))
+        h2 = self.dbuf("md.cm2", (b * c, d))
         L.gemm(h1, p[md + ".class_mlp.1.w"], bias=w[md + ".class_mlp.layers.1.bias"], out16=h2, act=L.ACT_RELU)
         cf = d // 8
         protos = self.f32("md.protos", (b * c, cf))
@@ -583,20 +602,26 @@ class LamEngine:
         c1 = d // 4
         up1 = self.f32("md.up1", (b * 4 * hw, c1))
         L.gemm(img16, p[md + ".up0.w"], bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
-        up1h = self.buf("md.up1h", (b * 4 * hw, c1))
-        self.ln(up1, md + ".output_upscaling.1", 1e-6, gelu=True, out16=up1h)
+        up1h = self.dbuf("md.up1h", (b * 4 * hw, c1))
+        self.dln(up1, md + ".output_upscaling.1", 1e-6, gelu=True, out16=up1h)
         npix = 16 * hw
         feat32 = self.f32("md.feat32", (b * npix, cf))
-        feat16 = self.buf("md.feat16", (b * npix, cf))
+        feat16 = self.dbuf("md.feat16", (b * npix, cf))
         L.gemm(up1h, p[md + ".up3.w"], bias=w[md + ".output_upscaling.3.bias"], out32=feat32, out16=feat16, map=L.MAP_CONVT2X2,
                p=(2 * g, 2 * g, cf, 0, 0))
         if cfg.spatial_convs:
-            col = self.buf("md.col", (b * npix, 9 * cf))
+            implicit = self.ddt == torch.float32 and cf % 32 == 0
+            col = None if implicit else self.dbuf("md.col", (b * npix, 9 * cf))
             for i in range(cfg.spatial_convs):
-                L.im2col_3x3(feat16, b, 4 * g, 4 * g, cf, col)
-                L.gemm(col, p[f"{md}.sc{i}.w"], bias=w[f"{md}.spatial_convs.{3 * i}.bias"], out32=feat32)
+                if implicit:      # fp32 implicit GEMM: no im2col buffer (feat16 IS fp32 here)
+                    nxt = self.f32("md.feat32b" if i % 2 == 0 else "md.feat32", (b * npix, cf))
+                    L.conv3x3_f32(feat16, b, 4 * g, 4 * g, cf, p[f"{md}.sc{i}.w"], w[f"{md}.spatial_convs.{3 * i}.bias"], cf, nxt)
+                    feat32 = nxt
+                else:
+                    L.im2col_3x3(feat16, b, 4 * g, 4 * g, cf, col)
+                    L.gemm(col, p[f"{md}.sc{i}.w"], bias=w[f"{md}.spatial_convs.{3 * i}.bias"], out32=feat32)
                 if i < cfg.spatial_convs - 1:
-                    self.ln(feat32, f"{md}.spatial_convs.{3 * i + 1}", 1e-6, gelu=True, out16=feat16)
+                    self.dln(feat32, f"{md}.spatial_convs.{3 * i + 1}", 1e-6, gelu=True, out16=feat16)
         seg = torch.empty(b, c, 4 * g, 4 * g, device=self.dev, dtype=torch.float32)
         L.classify(feat32, protos, b, npix, c, cf, seg)
         return seg
@@ -604,9 +629,9 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     # post-processing (lam.py:383-453, 92-93)
     # ------------------------------------------------------------------------------------------------
-    def postprocess(self, seg: Tensor, dims: Tensor, flag_gts: Optional[Tensor] = None, want_argmax: bool = False):
+    def post_sizes(self, dims: Tensor):
+        """Host side of postprocess_masks: per-item (orig_h, orig_w, crop_h, crop_w) + the padded output frame."""
         cfg = self.cfg
-        b, c, h, wd = seg.shape
         s = cfg.image_size
         dims_h = dims.detach().to("cpu", torch.int64)
         hmax, wmax = [int(v) for v in dims_h.reshape(-1, 2).max(dim=0).values.tolist()]
@@ -618,11 +643,21 @@ class LamEngine:
             else:
                 ph, pw = s, s
             sizes.append([int(oh), int(ow), ph, pw])
-        sizes_d = self.h2d(torch.tensor(sizes, dtype=torch.int32))
+        return torch.tensor(sizes, dtype=torch.int32), hmax, wmax
+
+    def postprocess_dev(self, seg: Tensor, sizes_d: Tensor, hmax: int, wmax: int, flag_gts_u8: Optional[Tensor], want_argmax: bool):
+        """Device side (capturable): bilinear to S x S, crop + resample + pad + flag_gts (+ argmax)."""
+        b, c, h, wd = seg.shape
+        s = self.cfg.image_size
         big = self.f32("post.big", (b * c, s, s))
         L.bilinear(seg, b * c, h, wd, s, s, big)
         logits = torch.empty(b, c, hmax, wmax, device=self.dev, dtype=torch.float32)
         am = torch.empty(b, hmax, wmax, device=self.dev, dtype=torch.int64) if want_argmax else None
+        L.post_final(big, b, c, s, sizes_d, flag_gts_u8, hmax, wmax, logits, am)
+        return logits, am
+
+    def postprocess(self, seg: Tensor, dims: Tensor, flag_gts: Optional[Tensor] = None, want_argmax: bool = False):
+        sizes, hmax, wmax = self.post_sizes(dims)
         fg = self.h2d(flag_gts, torch.uint8).contiguous() if flag_gts is not None else None
-        L.post_final(big, b, c, s, sizes_d, fg, hmax, wmax, logits, am)
+        logits, am = self.postprocess_dev(seg.contiguous(), self.h2d(sizes), hmax, wmax, fg, want_argmax)
         return (logits, am) if want_argmax else logits

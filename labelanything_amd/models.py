@@ -62,12 +62,14 @@ class Lam(nn.Module):
     mask_threshold: float = 0.0
     image_format: str = "RGB"
 
-    def __init__(self, cfg: LamConfig, seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float16):
+    def __init__(self, cfg: LamConfig, seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float16,
+                 decoder_dtype: Optional[torch.dtype] = torch.float32):
         super().__init__()
         self.cfg = cfg
         self.image_size = cfg.image_size
         self.custom_preprocess = cfg.custom_preprocess
         self.compute_dtype = compute_dtype
+        self.decoder_dtype = decoder_dtype
         self.class_embeddings = None
         sd = init_state_dict(cfg, 0 if seed is None else seed)
         for k, v in sd.items():
@@ -83,6 +85,8 @@ class Lam(nn.Module):
         self._engine: Optional[LamEngine] = None
         self._engine_key = None
         self._plist = None
+        self._graphs: Dict[Any, Any] = {}
+        self.use_graphs = False          # replay the device-side launch sequence from a HIP graph (per input plan)
         self.selected_rows: Optional[torch.Tensor] = None   # fix the RandomMatrixEncoder rows (parity / reproducibility)
 
     # -- engine management --------------------------------------------------------------------------
@@ -99,9 +103,10 @@ class Lam(nn.Module):
             raise RuntimeError("labelanything_amd runs on an MI355X only: move the model to 'cuda' (no CPU fallback)")
         if self._plist is None:
             self._plist = list(self.parameters()) + list(self.buffers())
-        key = (dev, self.compute_dtype, sum(p._version for p in self._plist))
+        key = (dev, self.compute_dtype, self.decoder_dtype, sum(p._version for p in self._plist))
         if self._engine is None or self._engine_key != key:
-            self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype)
+            self._graphs = {}
+            self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype, self.decoder_dtype)
             self._engine_key = key
         return self._engine
 
@@ -130,17 +135,64 @@ class Lam(nn.Module):
         L.nhwc_to_nchw(eng.dense_pe(g), 1, self.cfg.embed_dim, g * g, out)
         return out
 
-    def _embeddings_nhwc(self, batched_input: Dict[str, Any], apply_neck_to_embeddings: bool):
-        """-> (emb32 [B*N*hw, D] NHWC fp32, B, N, g).  lam.py:138-170 / :187-212."""
-        eng = self.engine(validate=False)
-        cfg = self.cfg
+    # ---------------------------------------------------------------------------------------------------------
+    # forward = host preparation (flags / sizes decisions, H2D of the small tensors) + a device-only launch sequence.
+    # The launch sequence allocates nothing new after its first run and never touches the host, so it can be replayed
+    # from a HIP graph (``use_graphs``): the decoder alone is ~170 short launches and is launch-bound otherwise.
+    # ---------------------------------------------------------------------------------------------------------
+    def _prepare(self, batched_input: Dict[str, Any], with_prompts: bool = True, with_post: bool = True):
+        """Host side (lam.py:138-170, 214-239, 401-404): returns (device inputs, hashable plan)."""
+        eng = self.engine()
+        inp: Dict[str, torch.Tensor] = {}
         if "embeddings" in batched_input:
             emb = batched_input["embeddings"]
             if isinstance(emb, dict):
                 raise NotImplementedError("feature pyramids are an off-path ablation of the reference")
+            inp["embeddings"] = eng.h2d(emb, torch.float32)
+        elif "images" in batched_input:
+            inp["images"] = eng.h2d(batched_input["images"], torch.float32)
+        else:
+            raise ValueError("Either 'images' or 'embeddings' must be provided.")
+        kinds = []
+        if with_prompts:
+            # a prompt type is dropped entirely when all its flags are zero (host decision, lam.py:214-239)
+            if "prompt_points" in batched_input and bool((batched_input["flag_points"] != 0).any()):
+                inp["prompt_points"] = eng.h2d(batched_input["prompt_points"], torch.float32)
+                inp["flag_points"] = eng.h2d(batched_input["flag_points"], torch.int32)
+                kinds.append("point")
+            if "prompt_bboxes" in batched_input and bool((batched_input["flag_bboxes"] != 0).any()):
+                inp["prompt_bboxes"] = eng.h2d(batched_input["prompt_bboxes"], torch.float32)
+                inp["flag_bboxes"] = eng.h2d(batched_input["flag_bboxes"], torch.int32)
+                kinds.append("box")
+            if "prompt_masks" in batched_input and bool((batched_input["flag_masks"] != 0).any()):
+                inp["prompt_masks"] = eng.h2d(batched_input["prompt_masks"], torch.float32)
+                inp["flag_masks"] = eng.h2d(batched_input["flag_masks"], torch.int32)
+                kinds.append("mask")
+            if not kinds:
+                raise ValueError("No prompts provided")
+            inp["flag_examples"] = eng.h2d(batched_input["flag_examples"], torch.uint8)
+            if self.cfg.bank_size:
+                c = inp["flag_examples"].shape[2]
+                rows = self.selected_rows if self.selected_rows is not None else eng.sample_rows(c)
+                inp["selected_rows"] = eng.h2d(rows.to(torch.long))
+        hmax = wmax = 0
+        if with_post:
+            sizes, hmax, wmax = eng.post_sizes(batched_input["dims"])
+            inp["sizes"] = eng.h2d(sizes)
+            if "flag_gts" in batched_input:
+                inp["flag_gts"] = eng.h2d(batched_input["flag_gts"], torch.uint8)
+        plan = (tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in inp.items())), tuple(kinds), hmax, wmax)
+        return inp, plan
+
+    def _embeddings_dev(self, inp: Dict[str, torch.Tensor], apply_neck_to_embeddings: bool):
+        """-> (emb32 [B*N*hw, D] NHWC fp32, B, N, g).  Device only."""
+        eng = self.engine(validate=False)
+        cfg = self.cfg
+        if "embeddings" in inp:
+            emb = inp["embeddings"]
             b, n, c, h, w = emb.shape
             g = h
-            x = emb.to(eng.dev, torch.float32).reshape(b * n, c, h * w).contiguous()
+            x = emb.reshape(b * n, c, h * w).contiguous()
             need_neck = cfg.lam_neck and apply_neck_to_embeddings
             e32 = eng.f32("in.emb32", (b * n * h * w, c))
             e16 = eng.buf("in.emb16", (b * n * h * w, c)) if need_neck else None
@@ -148,18 +200,19 @@ class Lam(nn.Module):
             if need_neck:
                 e32 = eng.lam_neck(e32, e16, b * n, g)
             return e32, b, n, g
-        if "images" in batched_input:
-            im = batched_input["images"]
-            b, n = im.shape[:2]
-            x = im.to(eng.dev, torch.float32).flatten(0, 1)
-            e32, e16, c, g = eng.encode_images(x)
-            if cfg.lam_neck:
-                e32 = eng.lam_neck(e32, e16, b * n, g)
-            return e32, b, n, g
-        raise ValueError("Either 'images' or 'embeddings' must be provided.")
+        im = inp["images"]
+        b, n = im.shape[:2]
+        e32, e16, c, g = eng.encode_images(im.flatten(0, 1))
+        if cfg.lam_neck:
+            e32 = eng.lam_neck(e32, e16, b * n, g)
+        return e32, b, n, g
+
+    def _embeddings_nhwc(self, batched_input: Dict[str, Any], apply_neck_to_embeddings: bool):
+        inp, _ = self._prepare(batched_input, with_prompts=False, with_post=False)
+        return self._embeddings_dev(inp, apply_neck_to_embeddings)
 
     def prepare_prompts(self, batched_input):
-        """A prompt type is dropped entirely when all its flags are zero (host sync, lam.py:214-239)."""
+        """Reference-shaped helper (lam.py:214-239): a prompt type is dropped when all its flags are zero."""
         points = boxes = masks = None
         if "prompt_points" in batched_input and bool((batched_input["flag_points"] != 0).any()):
             points = (batched_input["prompt_points"], batched_input["flag_points"])
@@ -169,32 +222,72 @@ class Lam(nn.Module):
             masks = (batched_input["prompt_masks"], batched_input["flag_masks"])
         return points, boxes, masks, batched_input["flag_examples"]
 
-    @torch.no_grad()
-    def _forward(self, batched_input):
-        eng = self.engine()
+    @staticmethod
+    def _prompts_of(inp):
+        points = (inp["prompt_points"], inp["flag_points"]) if "prompt_points" in inp else None
+        boxes = (inp["prompt_bboxes"], inp["flag_bboxes"]) if "prompt_bboxes" in inp else None
+        masks = (inp["prompt_masks"], inp["flag_masks"]) if "prompt_masks" in inp else None
+        return points, boxes, masks
+
+    def _run(self, inp: Dict[str, torch.Tensor], plan, want_argmax: bool, want_post: bool = True):
+        """Device-only launch sequence of Lam.forward (lam.py:115-136 + postprocess)."""
+        eng = self.engine(validate=False)
         d = self.cfg.embed_dim
-        e32, b, n, g = self._embeddings_nhwc(batched_input, apply_neck_to_embeddings=True)
+        e32, b, n, g = self._embeddings_dev(inp, apply_neck_to_embeddings=True)
         hw = g * g
         ev = e32.view(b, n, hw, d)
         query = ev[:, 0].contiguous().view(b * hw, d)
         support = ev[:, 1:].contiguous().view(b * (n - 1) * hw, d)
-        points, boxes, masks, flag_examples = self.prepare_prompts(batched_input)
-        pe_result = eng.prompt_encoder(support, b, n - 1, g, points, boxes, masks, flag_examples, self.selected_rows)
+        points, boxes, masks = self._prompts_of(inp)
+        pe_result = eng.prompt_encoder(support, b, n - 1, g, points, boxes, masks, inp["flag_examples"], inp.get("selected_rows"))
         seg = eng.mask_decoder(query, b, g, pe_result["class_embeddings"])
-        return seg, pe_result
+        out = {"low_res_logits": seg, "class_embeddings": pe_result["class_embeddings"],
+               "class_examples_embeddings": pe_result["class_examples_embeddings"]}
+        if want_post:
+            logits, am = eng.postprocess_dev(seg, inp["sizes"], plan[2], plan[3], inp.get("flag_gts"), want_argmax)
+            out["logits"] = logits
+            if want_argmax:
+                out["argmax"] = am
+        return out
+
+    def _run_graphed(self, inp, plan, want_argmax: bool):
+        key = (plan, want_argmax)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static = {k: v.clone() for k, v in inp.items()}
+            self._run(static, plan, want_argmax)                      # warm-up: sizes every arena buffer, fills caches
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run(static, plan, want_argmax)
+            entry = (graph, static, out)
+            self._graphs[key] = entry
+        graph, static, out = entry
+        for k, v in inp.items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return {k: v.clone() for k, v in out.items()}
 
     @torch.no_grad()
-    def forward(self, batched_input: Dict[str, Any]) -> Dict[str, torch.Tensor]:
-        seg, pe_result = self._forward(batched_input)
-        logits = self.engine(False).postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"))
-        return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"]}
+    def _forward(self, batched_input):
+        """(low-res logits, prompt-encoder result) like the reference's Lam._forward (lam.py:115-136)."""
+        inp, plan = self._prepare(batched_input, with_post=False)
+        out = self._run(inp, plan, False, want_post=False)
+        return out["low_res_logits"], out
 
     @torch.no_grad()
+    def forward(self, batched_input: Dict[str, Any], want_argmax: bool = False) -> Dict[str, torch.Tensor]:
+        inp, plan = self._prepare(batched_input)
+        out = self._run_graphed(inp, plan, want_argmax) if self.use_graphs else self._run(inp, plan, want_argmax)
+        res = {"logits": out["logits"], "class_examples_embeddings": out["class_examples_embeddings"]}
+        if want_argmax:
+            res["argmax"] = out["argmax"]
+        return res
+
     def forward_argmax(self, batched_input: Dict[str, Any]):
         """forward + the caller's ``logits.argmax(dim=1)`` (experiment/run.py:697) fused into the last kernel."""
-        seg, pe_result = self._forward(batched_input)
-        logits, am = self.engine(False).postprocess(seg, batched_input["dims"], batched_input.get("flag_gts"), want_argmax=True)
-        return {"logits": logits, "class_examples_embeddings": pe_result["class_examples_embeddings"], "argmax": am}
+        return self.forward(batched_input, want_argmax=True)
 
     def postprocess_masks(self, masks: torch.Tensor, original_sizes: torch.Tensor) -> torch.Tensor:
         return self.engine().postprocess(masks.to(self._device(), torch.float32).contiguous(), original_sizes)
@@ -203,10 +296,11 @@ class Lam(nn.Module):
     def generate_class_embeddings(self, example_dict, chunk_size=None):
         """Supports only: every image of the dict is a support (lam.py:349-360).  chunk_size is accepted and ignored
         (the kernels never materialise the tensors the reference chunks for)."""
-        eng = self.engine()
-        e32, b, n, g = self._embeddings_nhwc(example_dict, apply_neck_to_embeddings=False)
-        points, boxes, masks, flag_examples = self.prepare_prompts(example_dict)
-        res = eng.prompt_encoder(e32, b, n, g, points, boxes, masks, flag_examples, self.selected_rows)
+        inp, _ = self._prepare(example_dict, with_post=False)
+        eng = self.engine(validate=False)
+        e32, b, n, g = self._embeddings_dev(inp, apply_neck_to_embeddings=False)
+        points, boxes, masks = self._prompts_of(inp)
+        res = eng.prompt_encoder(e32, b, n, g, points, boxes, masks, inp["flag_examples"], inp.get("selected_rows"))
         pcount, hw, d = res["class_examples_src"].shape
         src = torch.empty(pcount, d, g, g, device=eng.dev)
         L.nhwc_to_nchw(res["class_examples_src"].contiguous(), pcount, d, hw, src)

@@ -14,10 +14,14 @@ from tests.helpers import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
-# (query embedding, class embeddings, low-res logits, final logits, argmax mismatch fraction)
+# Tolerances (max|a-b| / max|b|) for: query embedding, class embeddings, low-res logits, final logits, and the fraction
+# of pixels whose argmax differs.  north_star asks for 1e-3 on logits in fp16/bf16; measured on MI355X with the
+# fp16 encoder + exact-fp32 decoder (the default): embeddings 0.5-1.1e-3, class prototypes 0.7-6e-4, logits 0.6-1.5e-3
+# (profiles/r01_parity.log).  The bounds below are ~1.5x the worst measured value.  bf16 operands carry 8 mantissa
+# bits (8x the fp16 rounding error) and are accepted at 8x the fp16 bound.
 TOL = {
-    torch.float16: dict(emb=2.5e-3, cls=2.5e-3, low=8e-3, logits=8e-3, argmax=0.12),
-    torch.bfloat16: dict(emb=2e-2, cls=2e-2, low=6e-2, logits=6e-2, argmax=0.7),
+    torch.float16: dict(emb=1.6e-3, cls=1.0e-3, low=2.5e-3, logits=2.5e-3, argmax=0.02),
+    torch.bfloat16: dict(emb=1.3e-2, cls=8e-3, low=2e-2, logits=2e-2, argmax=0.12),
 }
 
 
@@ -90,3 +94,22 @@ def test_image_encoder_handle_returns_nchw():
     both = lam.image_encoder(x, return_last_block_state=True)
     assert both["last_block_state"].shape == (2, 128, 14, 14)
     assert rel_err(both["last_hidden_state"], out) < 1e-6
+
+
+def test_hip_graph_replay_matches_eager_and_tracks_new_inputs():
+    """use_graphs: the captured launch sequence reproduces the eager result bit for bit, also after the inputs change."""
+    case = CASES["sam_tiny_2w2s_all_prompts"]
+    gold, _ = load_golden("sam_tiny_2w2s_all_prompts")
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    lam.selected_rows = gold["selected_rows"]
+    b1 = make_episode(**case["episode"])
+    b2 = make_episode(**{**case["episode"], "seed": 777})
+    e1, e2 = lam.forward_argmax(b1), lam.forward_argmax(b2)
+    lam.use_graphs = True
+    g1 = lam.forward_argmax(b1)       # capture
+    g2 = lam.forward_argmax(b2)       # replay with new inputs
+    g1b = lam.forward_argmax(b1)      # replay again
+    torch.cuda.synchronize()
+    for k in ("logits", "argmax", "class_examples_embeddings"):
+        assert torch.equal(e1[k], g1[k]) and torch.equal(e2[k], g2[k]) and torch.equal(e1[k], g1b[k])
+    assert len(lam._graphs) == 1

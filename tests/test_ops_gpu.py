@@ -255,3 +255,46 @@ def test_bad_arguments_raise(L):
     w = torch.zeros(4, 12, device="cuda", dtype=torch.float16)
     with pytest.raises(RuntimeError, match="multiples of 8"):
         L.gemm(a, w, out32=torch.zeros(4, 4, device="cuda"))
+
+
+@pytest.mark.parametrize("mnk", [(300, 200, 256), (4096, 128, 256), (1000, 32, 288), (8, 2048, 256), (20, 256, 2048), (3, 32, 256), (64, 8, 72)])
+def test_gemm_fp32_exact_mfma_and_skinny(L, mnk):
+    """LA_F32: exact-fp32 MFMA (and the VALU skinny kernel for M <= 32) vs torch fp32 matmul."""
+    m, n, k = mnk
+    a = rnd(m, k, seed=50)
+    w = rnd(n, k, seed=51) / math.sqrt(k)
+    bias = rnd(n, seed=52)
+    res = rnd(m, n, seed=53)
+    ref = torch.relu(a.double() @ w.double().t() + bias.double()).float() + res
+    o32 = torch.empty(m, n, device="cuda")
+    oT = torch.empty(m, n, device="cuda")
+    L.gemm(a, w, bias=bias, res=res, out32=o32, out16=oT, act=L.ACT_RELU)
+    torch.cuda.synchronize()
+    assert rel_err(o32, ref) < 2e-6
+    assert torch.equal(o32, oT)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_skinny_16bit(L, dt):
+    m, n, k = 7, 384, 256
+    a = rnd(m, k, seed=54).to(dt)
+    w = (rnd(n, k, seed=55) / math.sqrt(k)).to(dt)
+    bias = rnd(n, seed=56)
+    o32 = torch.empty(m, n, device="cuda")
+    L.gemm(a, w, bias=bias, out32=o32, act=L.ACT_GELU)
+    torch.cuda.synchronize()
+    assert rel_err(o32, F.gelu(a.float() @ w.float().t() + bias)) < 1e-5
+
+
+@pytest.mark.parametrize("c,co", [(32, 32), (64, 32), (32, 48)])
+def test_conv3x3_fp32_implicit_gemm(L, c, co):
+    b, h, w_ = 2, 20, 24
+    x = rnd(b, c, h, w_, seed=57)
+    wt = rnd(co, c, 3, 3, seed=58) / math.sqrt(9 * c)
+    bias = rnd(co, seed=59)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(b * h * w_, co, device="cuda")
+    L.conv3x3_f32(xn, b, h, w_, c, wt.permute(0, 2, 3, 1).reshape(co, 9 * c).contiguous(), bias, co, out)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).float().permute(0, 2, 3, 1).reshape(-1, co)
+    assert rel_err(out, ref) < 2e-6

@@ -11,12 +11,12 @@ from tests.helpers import load_golden, rel_err
 
 def main():
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
-    for dt in (torch.float16, torch.bfloat16):
+    for dt, ddt in ((torch.float16, torch.float32), (torch.float16, None), (torch.bfloat16, torch.float32)):
         for name, case in CASES.items():
             if only and name not in only:
                 continue
             gold, meta = load_golden(name)
-            lam = Lam(case["cfg"], seed=case["weight_seed"], compute_dtype=dt).cuda()
+            lam = Lam(case["cfg"], seed=case["weight_seed"], compute_dtype=dt, decoder_dtype=ddt).cuda()
             lam.selected_rows = gold.get("selected_rows")
             batch = make_episode(**case["episode"])
             t0 = time.time()
@@ -50,7 +50,7 @@ def main():
             errs["argmax_mismatch_frac"] = mism / ref_am.numel()
             am2 = out["logits"].argmax(1).cpu()
             errs["fused_argmax_vs_torch"] = int((am2 != am).sum())
-            print(f"[{name} {str(dt)[6:]}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
+            print(f"[{name} enc={str(dt)[6:]} dec={str(ddt)[6:] if ddt else 'same'}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
             del lam
             torch.cuda.empty_cache()
 
