@@ -1,0 +1,53 @@
+"""CPU, world_size 2 over gloo: the episode sharding used for N > 1 GPUs (no data-path collective)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from labelanything_amd.episodes import make_episode
+from labelanything_amd.parallel import shard_episodes, slice_batch, max_over_ranks, sum_over_ranks
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_episodes: int, out_dir: str):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = make_episode(batch=n_episodes, n_ways=1, k_shots=1, image_size=32, seed=5, prompts=("mask",))
+    mine = shard_episodes(n_episodes, rank, world)
+    sub = slice_batch(batch, mine)
+    assert sub["images"].shape[0] == len(mine)
+    assert torch.equal(sub["images"], batch["images"][mine])
+    # bookkeeping collectives: every episode is processed exactly once across the job
+    seen = torch.zeros(n_episodes, dtype=torch.int64)
+    seen[mine] = 1
+    seen = sum_over_ranks(seen)
+    assert bool((seen == 1).all())
+    t = max_over_ranks(1.0 + rank)
+    assert t == float(world)
+    dist.barrier()
+    torch.save({"rank": rank, "mine": mine}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_episode_sharding(tmp_path):
+    world, n = 2, 5
+    mp.spawn(_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    got = sorted(i for r in range(world) for i in torch.load(tmp_path / f"r{r}.pt")["mine"])
+    assert got == list(range(n))
+
+
+def test_shard_is_balanced_and_disjoint():
+    for n in (1, 7, 8, 33):
+        for world in (1, 2, 4, 8):
+            parts = [shard_episodes(n, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
