@@ -139,8 +139,10 @@ def relpos_terms(qkv: torch.Tensor, b: int, heads: int, g: int, e: int, tabh, ta
                                  _ptr(relh), _ptr(relw), C.c_int(dt_of(qkv)), _stream()), "la_relpos_terms")
 
 
-def attn_fwd(qkv, vt, out16, relh, relw, b: int, heads: int, t: int, tpad: int, g: int, e: int, scale: float, mode: int) -> None:
-    _check(lib().la_attn_fwd(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), C.c_int(b), C.c_int(heads), C.c_int(t),
+def attn_fwd(qkv, vt, out16, relh, relw, b: int, heads: int, t: int, tpad: int, g: int, e: int, scale: float, mode: int,
+             tabh=None, tabw=None) -> None:
+    _check(lib().la_attn_fwd(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), _ptr(tabh), _ptr(tabw), C.c_int(b),
+                             C.c_int(heads), C.c_int(t),
                              C.c_int(tpad), C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(mode), C.c_int(dt_of(qkv)),
                              _stream()), "la_attn_fwd")
 

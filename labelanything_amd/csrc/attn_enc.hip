@@ -106,11 +106,15 @@ struct AttnArgs {
   void* out;
   const float* relh;
   const float* relw;
+  const void* tabh;   // MODE 3: 16-bit rel-pos tables [(2G-1), 64]
+  const void* tabw;
   int B, heads, T, Tpad, G, E;
   float scale;
 };
 
-// MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables).  MODE 2: rel-pos, G == 64 (tile == key row).
+// MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
+// MODE 2: rel-pos, G == 64 (tile == key row).  MODE 3: rel-pos, G <= 16 (SAM windows): the decomposed terms are computed
+// IN the kernel (U[r][q] = R[r] . q on MFMA, 8 extra MFMAs per 32-query tile) - no la_relpos_terms pass, no global bias.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,14 +176,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     int* ki = reinterpret_cast<int*>(bias_lds + 4 * 2 * 32 * GS);
     for (int k = tid; k < a.Tpad; k += 256) ki[k] = ((k / G) << 16) | (k % G);
     keyinfo = ki;
+  } else if (MODE == 3) {
+    // U_h[q][r] = q . Rh[r], U_w[q][r] = q . Rw[r] for r < 2G-1 <= 32; bias(q, k) = U_h[q][qy - kh + G-1] + U_w[q][qx - kw + G-1]
+    const int G = a.G, nrel = 2 * G - 1;
+    my_bh = bias_lds + wave * 2 * 32 * 33;
+    my_bw = my_bh + 32 * 33;
+    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    f32x16 uh, uw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uh[r] = uw[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uh = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(th + ks * 16), qf[ks], uh);
+      uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {      // accumulator: column = query fr, row = table row
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      my_bh[fr * 33 + row] = uh[r] * inv_scale;
+      my_bw[fr * 33 + row] = uw[r] * inv_scale;
+    }
+    int* ki = reinterpret_cast<int*>(bias_lds + 4 * 2 * 32 * 33);
+    for (int k = tid; k < a.Tpad; k += 256) {
+      const int kk = min(k, T_ - 1);       // padded keys are masked later; keep their lookups in range
+      ki[k] = ((G - 1 - kk / G) << 16) | (G - 1 - kk % G);
+    }
+    keyinfo = ki;
   }
 
   // ---- K / V^T tile staging by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per wave instruction) ----------
   // The DMA destination is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk (row = lane/8, slot = lane%8
   // holds logical chunk slot ^ ((row>>1)&7)).  No staging registers: hipcc parked the register-staged variant in
   // scratch and exposed the whole load latency every tile.
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
   const T* ksrc[2];
   const T* vsrc[2];
   int krow[2];
@@ -191,14 +220,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HD + chunk * 8;
     vsrc[i] = vt + ((size_t)bh * HD + row) * a.Tpad + chunk * 8;
   }
+  const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int j, int stage) {
-    char* sk = smem + stage * KV_STAGE;
-    char* sv = sk + 64 * HD * 2;
+    const unsigned sk = lds0 + stage * KV_STAGE;
+    const unsigned sv = sk + 64 * HD * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int key = min(j * 64 + krow[i], T_ - 1);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[i] + (size_t)key * E3), (lptr_t)(sk + (i * 4 + wave) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + j * 64), (lptr_t)(sv + (i * 4 + wave) * 1024), 16, 0, 0);
+      dma16(ksrc[i] + (size_t)key * E3, sk + (i * 4 + wave) * 1024);
+      dma16(vsrc[i] + j * 64, sv + (i * 4 + wave) * 1024);
     }
   };
 
@@ -211,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   const int ntiles = (T_ + 63) >> 6;
   dma(0, 0);
+  dma_wait<0>();
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
@@ -248,6 +279,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
           const int info = keyinfo[key];
           s[t][r] += my_bh[fr * GS + (info >> 16)] + my_bw[fr * GS + (info & 0xffff)];
+        }
+    }
+    if (MODE == 3) {
+      const int qy = qc / a.G, qx = qc % a.G;
+      const float* bh_q = my_bh + fr * 33 + qy;
+      const float* bw_q = my_bw + fr * 33 + qx;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int info = keyinfo[key];
+          s[t][r] += bh_q[info >> 16] + bw_q[info & 0xffff];
         }
     }
     if (j * 64 + 64 > T_) {  // tail tile: mask keys >= T (wave-uniform branch)
@@ -313,7 +357,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       }
     }
 
-    __syncthreads();   // drains this wave's DMA (vmcnt) and orders the stage swap
+    dma_wait<0>();     // next tile (issued before this tile's MFMAs) has landed for this wave ...
+    __syncthreads();   // ... and for all waves; orders the stage swap
   }
 
   // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
@@ -364,20 +409,28 @@ extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, 
   return 0;
 }
 
-extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, int B, int heads, int T,
-                           int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
+extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
+                           const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
   LA_CHECK_ARG(qkv && vt && out16, "la_attn_fwd: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * la::HD, "la_attn_fwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd: bad dtype %d", dt);
-  la::AttnArgs a{qkv, vt, out16, relh, relw, B, heads, T, Tpad, G, E, scale};
+  la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t kv = 2 * la::KV_STAGE;
   if (mode == LA_ATTN_PLAIN) {
     if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, kv, st);
     else la::launch_attn<la::bf16_t, 0>(a, kv, st);
   } else if (mode == LA_ATTN_RELPOS) {
-    LA_CHECK_ARG(relh && relw && G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
+    LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
+    if (tabh && tabw && G <= 16) {        // windows: bias terms computed in-kernel from the tables
+      const size_t lds = kv + 4 * 2 * 32 * 33 * sizeof(float) + (size_t)Tpad * sizeof(int);
+      if (dt == LA_F16) la::launch_attn<la::f16_t, 3>(a, lds, st);
+      else la::launch_attn<la::bf16_t, 3>(a, lds, st);
+      LA_CHECK_LAUNCH("la_attn_fwd");
+      return 0;
+    }
+    LA_CHECK_ARG(relh && relw, "la_attn_fwd: rel-pos terms missing (run la_relpos_terms, or pass the tables for G <= 16)");
     if (G == 64) {
       const size_t lds = kv + 4 * 32 * 65 * sizeof(float);
       if (dt == LA_F16) la::launch_attn<la::f16_t, 2>(a, lds, st);

@@ -276,8 +276,13 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
       if (e.act == LA_ACT_GELU) {
+        if (sizeof(T) == 2 && !e.out32) {      // result only survives as a 16-bit value
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
       } else if (e.act == LA_ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -309,6 +314,34 @@ static bool epi_vec_ok(int N, const LaGemmEpilogue& e, int elt_bytes) {
   return true;
 }
 
+
+// One 64-deep K tile for a 64 x 64 wave tile: 4 MFMA k-steps, fragments of step ks+1 are fetched from LDS before the
+// MFMAs of step ks are issued (two register sets), so the ds_read latency hides behind matrix work.
+template <typename T>
+__device__ __forceinline__ void mma_ktile(const char* sa, const char* sw, int arow, int wrow, int fr, int fh, f32x16 (&acc)[2][2]) {
+  uint4 af[2][2], wf[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    af[0][i] = *reinterpret_cast<const uint4*>(sa + swz_off(arow + i * 32 + fr, fh));
+    wf[0][i] = *reinterpret_cast<const uint4*>(sw + swz_off(wrow + i * 32 + fr, fh));
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int cur = ks & 1, nxt = cur ^ 1;
+    if (ks < 3) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[nxt][i] = *reinterpret_cast<const uint4*>(sa + swz_off(arow + i * 32 + fr, (ks + 1) * 2 + fh));
+        wf[nxt][i] = *reinterpret_cast<const uint4*>(sw + swz_off(wrow + i * 32 + fr, (ks + 1) * 2 + fh));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[cur][i], wf[cur][j], acc[i][j]);
+  }
+}
+
 // =================================================================================================================
 // v2 fast path (K % 64 == 0, N % 8 == 0, 16-byte aligned rows): operand tiles go global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass; the XOR swizzle is applied to the per-lane SOURCE
@@ -316,9 +349,6 @@ static bool epi_vec_ok(int N, const LaGemmEpilogue& e, int elt_bytes) {
 // handles 8 consecutive output columns (16-byte stores, float4 residual / bias loads).  Tile BM x BN with one
 // 64 x 64 sub-tile per wave: 128x128 (4 waves, 2 blocks/CU) or 256x128 (8 waves).
 // =================================================================================================================
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 constexpr int EPI_LD = BN + 4;                      // fp32 row stride of the staged output tile
 constexpr int EPI_BYTES = 128 * EPI_LD * 4;         // one 128-row chunk
 
@@ -358,10 +388,10 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
     }
     ldsoff[i] = grp * 1024;                        // A tile occupies [0, BM_*128), W tile follows: same linear space
   }
+  const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + kt * BK), (lptr_t)(smem + stage * STAGE + ldsoff[i]), 16, 0, 0);
+    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, lds0 + stage * STAGE + ldsoff[i]);
   };
 
   f32x16 acc[2][2];
@@ -375,29 +405,108 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
   const int nk = K / BK;
   const int fr = lane & 31, fh = lane >> 5;
   dma(0, 0);
+  dma_wait<0>();
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) dma(kt + 1, (kt + 1) & 1);
     const char* sa = smem + (kt & 1) * STAGE;
     const char* sw = sa + BM_ * BK * 2;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      uint4 af[2], wf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const uint4*>(sa + swz_off(wm * 64 + i * 32 + fr, ks * 2 + fh));
-        wf[i] = *reinterpret_cast<const uint4*>(sw + swz_off(wn * 64 + i * 32 + fr, ks * 2 + fh));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[i], wf[j], acc[i][j]);
-    }
-    __syncthreads();   // drains this wave's DMA (vmcnt) and orders the stage swap
+    mma_ktile<T>(sa, sw, wm * 64, wn * 64, fr, fh, acc);
+    dma_wait<0>();     // this wave's part of the next tile has landed (issued before the MFMAs above) ...
+    __syncthreads();   // ... and so has everyone else's; also orders the stage swap
   }
 
   // ---- epilogue through LDS, 128 rows at a time ----------------------------------------------------------------
   epilogue_lds<T, 2, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, BM_ / 128, wm >> 1, (wm & 1) * 64, wn * 64, m0, n0, M, N, e, tid);
+}
+
+
+// =================================================================================================================
+// v3: 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), THREE LDS stages with prefetch distance 2.  The 128 x 128 kernel
+// re-reads every operand panel from L2 at 64 FLOP/byte and waits for each DMA in the iteration that issued it; here
+// the byte/FLOP ratio drops by 1.33x and two tiles of DMA stay in flight across the barrier: waves wait with a COUNTED
+// s_waitcnt vmcnt(NDMA) (only the oldest tile must have landed) and a raw s_barrier (a __syncthreads() would drain
+// vmcnt to 0).  Per iteration: wait(tile kt) -> barrier -> issue DMA(tile kt+2) into the buffer read in kt-1 -> MFMAs.
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_dma3_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                            int M, int N, int K, LaGemmEpilogue e) {
+  constexpr int BM_ = 256;
+  constexpr int NW = 8, NT = 512;
+  constexpr int STAGE = (BM_ + BN) * BK * 2;       // 48 KiB
+  constexpr int NDMA = (BM_ + BN) / 8 / NW;        // 6 wave-level DMA instructions per k-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN;
+
+  const T* src[NDMA];
+  int ldsoff[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int grp = i * NW + wave;
+    const int trow = grp * 8 + (lane >> 3);
+    const int slot = lane & 7;
+    if (grp < BM_ / 8) {
+      const int r = trow;
+      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
+    } else {
+      const int r = trow - BM_;
+      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+    }
+    ldsoff[i] = grp * 1024;
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma = [&](int kt, int stage) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, lds0 + stage * STAGE + ldsoff[i]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed (this wave's part); the tile issued after it may stay in flight
+    if (kt + 1 < nk) dma_wait<NDMA>();
+    else dma_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) {
+      const int st2 = (stage + 2 >= 3) ? stage - 1 : stage + 2;
+      dma(kt + 2, st2);
+    }
+    const char* sa = smem + stage * STAGE;
+    const char* sw = sa + BM_ * BK * 2;
+    mma_ktile<T>(sa, sw, wm * 64, wn * 64, fr, fh, acc);
+    stage = (stage == 2) ? 0 : stage + 1;
+  }
+  __syncthreads();
+  epilogue_lds<T, 2, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, BM_ / 128, wm >> 1, (wm & 1) * 64, wn * 64, m0, n0, M, N, e, tid);
+}
+
+template <typename T>
+static void launch_fast3(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = 3 * (256 + BN) * BK * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma3_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int ntm = (M + 255) / 256, ntn = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_dma3_kernel<T>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e);
 }
 
 template <typename T, int BM_>
@@ -717,10 +826,13 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   if (fast) {
     const long tiles256 = (long)((M + 255) / 256) * ((N + la::BN - 1) / la::BN);
     bool big = false;   // 256x128 measured 5-10% slower than 128x128 on every SAM ViT-B shape (profiles/r01_gemm_v2.log)
-    (void)tiles256;
     if (force && force[0] == '1') big = false;
     if (force && force[0] == '2') big = true;
-    if (dt == LA_F16) big ? la::launch_fast<la::f16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::f16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+    const bool v3 = (force && force[0] == '3') || (!force && tiles256 >= 512);
+    if (v3) {
+      if (dt == LA_F16) la::launch_fast3<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+      else la::launch_fast3<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    } else if (dt == LA_F16) big ? la::launch_fast<la::f16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::f16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
     else big ? la::launch_fast<la::bf16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::bf16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
   } else {
     if (dt == LA_F16) la::launch_gemm<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);

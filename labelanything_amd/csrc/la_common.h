@@ -55,6 +55,19 @@ template <> __device__ __forceinline__ void store4v<float>(float* p, float a, fl
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// GELU(erf) for epilogues whose result is rounded to 16 bit anyway: erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7,
+// three orders below the fp16 rounding step) = 1 v_rcp + 1 v_exp + 8 FMA instead of libm's ~40-instruction erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);          // erf(|x|/sqrt2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // ---- wave reductions (64 lanes) ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v, int width = 64) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -70,6 +83,28 @@ __device__ __forceinline__ float wave_max(float v, int width = 64) {
 // groups over a 256-B bank row (MI355X_MICROARCH LDS table); XOR-ing the chunk with (row>>1)&7 makes
 // the 16 rows of every group land on 16 distinct 16-B slots.
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// ---- LDS-DMA ---------------------------------------------------------------------------------
+// 16 bytes per lane, global -> LDS without touching VGPRs: global_load_lds_dwordx4, destination = M0 + lane*16.
+// Issued through inline asm ON PURPOSE: hipcc treats the builtin as a pending LDS write and inserts s_waitcnt vmcnt(0)
+// in front of the next ds_read, which serialises every prefetch pipeline (guide: "glds pipelining across barriers").
+// With the asm form the compiler does not know about the transfer, so the caller MUST order it by hand:
+// dma_wait<N>() (counted s_waitcnt vmcnt) followed by a barrier before any wave reads the bytes.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // XCD-aware tile order: consecutive workgroups round-robin over the 8 XCDs, so give each XCD a
 // contiguous chunk of the tile sequence (bijective also when n % 8 != 0).

@@ -263,11 +263,15 @@ class LamEngine:
             vt = self.buf("enc.vt." + tag, (nb * heads, 64, tpad), zero=True)
             L.gemm(xin, p[bp + ".qkv.w"], bias=w[bp + ".attn.qkv.bias"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t,
                    vt_Tpad=tpad, vt_hd=64, vt_heads=heads)
-            relh = self.f32("enc.relh." + tag, (nb * heads, t, gg))
-            relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
-            L.relpos_terms(qkv, nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
             ao = self.buf("enc.ao." + tag, (arows, e))
-            L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS)
+            if gg <= 16:      # windows: rel-pos terms are computed inside the attention kernel
+                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS,
+                           tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
+            else:
+                relh = self.f32("enc.relh." + tag, (nb * heads, t, gg))
+                relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
+                L.relpos_terms(qkv, nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
+                L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS)
             if is_global:
                 L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
             else:
