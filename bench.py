@@ -135,13 +135,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local % ndev)              # one rank per GPU on a real node; wraps only in the 1-GPU smoke test
+    dev = torch.device("cuda", local % ndev)
     dist = None
+    backend = os.environ.get("LA_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the 1-GPU smoke test
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
     lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None)
     lam = lam.to(dev)
@@ -163,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out["logits"]).all()
