@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
     if (!__all(m_new == m_run)) {
-      const float alpha = exp2f((m_run - m_new) * c2);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
       l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < 2; ++d)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(fmaf(s[t][r], c2, -mc));
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -mc));   // raw v_exp_f32 (no denormal fix-up)
         s[t][r] = p;
         psum += p;
       }

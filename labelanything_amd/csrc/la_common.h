@@ -33,8 +33,12 @@ template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T
 template <typename T> __device__ __forceinline__ uint16_t bits16(T v) { return __builtin_bit_cast(uint16_t, v); }
 template <typename T> __device__ __forceinline__ T from_bits16(uint16_t v) { return __builtin_bit_cast(T, v); }
 
+// two floats -> one dword of 2 x 16 bit, round-to-nearest-even: a single v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 on gfx950
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)bits16<T>((T)lo) | ((uint32_t)bits16<T>((T)hi) << 16);
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, t2));
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t v) { return (float)from_bits16<T>((uint16_t)(v & 0xffffu)); }
 template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t v) { return (float)from_bits16<T>((uint16_t)(v >> 16)); }
