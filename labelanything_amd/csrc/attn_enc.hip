@@ -23,6 +23,7 @@ namespace la {
 constexpr int HD = 64;
 constexpr int KV_STAGE = 2 * 64 * HD * 2;  // K tile + V^T tile, 16 KiB
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 8.0f;   // log2 units
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
   // ---- bias staging ---------------------------------------------------------------------------------
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * KV_STAGE);
-  float rw[2][16];
+  f32x16 rw[2];
   float* my_bh = nullptr;
   float* my_bw = nullptr;
   const int* keyinfo = nullptr;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         rw[t][g4 * 4 + 0] = v.x * inv_scale;
         rw[t][g4 * 4 + 1] = v.y * inv_scale;
         rw[t][g4 * 4 + 2] = v.z * inv_scale;
-        rw[t][g4 * 4 + 3] = v.w * inv_scale;
+        rw[t][g4 * 4 + 3] = v.w * inv_scale;   // (vector element writes with constant indices stay in registers)
       }
   } else if (MODE == 1) {
     const int G = a.G, GS = G + 1;
@@ -248,22 +249,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const char* sk = smem + (j & 1) * KV_STAGE;
     const char* sv = sk + 64 * HD * 2;
 
-    // ---- S^T tile: 64 keys x 32 queries, accumulator initialised with the positional bias -------------
+    // ---- S^T tile: 64 keys x 32 queries.  G == 64: the C operand of the first MFMA IS the relw register block
+    // (no per-tile initialisation pass); the per-row scalar relh[q][tile] is folded into the softmax constants below.
     f32x16 s[2];
-    if (MODE == 2) {
-      const float rh = my_bh[fr * 65 + j];
+    float rh = 0.f;
+    if (MODE == 2) rh = my_bh[fr * 65 + j];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      const uint4 kf0 = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, fh));
+      if (MODE == 2) {
+        s[t] = Half16<T>::mfma32(kf0, qf[0], rw[t]);
+      } else {
+        f32x16 z;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = rw[t][r] + rh;
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        s[t] = Half16<T>::mfma32(kf0, qf[0], z);
+      }
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 1; ks < 4; ++ks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
@@ -305,14 +309,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 
     // ---- online softmax, one query row per lane pair (lane, lane ^ 32) -----------------------------------
+    // Scores live in "raw" units (logit / scale); true score = s + rh.  The running max is only advanced when some row
+    // of the wave outgrows it by more than RESCALE_THR (in log2 units): P then stays <= 2^THR, which fp16/bf16 hold at
+    // full relative precision, and the O / l rescale pass disappears from almost every tile.
     float mx = s[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    if (!__all(m_new == m_run)) {
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) + rh;
+    if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
       l_run *= alpha;
 #pragma unroll
@@ -321,13 +328,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
       m_run = m_new;
     }
-    const float mc = m_run * c2;
+    const float mc = (rh - m_run) * c2;
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -mc));   // raw v_exp_f32 (no denormal fix-up)
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, mc));   // raw v_exp_f32 (no denormal fix-up)
         s[t][r] = p;
         psum += p;
       }
