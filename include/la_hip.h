@@ -101,8 +101,9 @@ int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void*
  * qkv 16-bit [B*T, 3E] supplies q and k; vt is V transposed per (b, head): [B*heads, 64, Tpad] (zero padded,
  * written by la_gemm's vt epilogue).  mode LA_ATTN_RELPOS adds relh[q][k / G] + relw[q][k % G]
  * (image_encoder.py:246-253); LA_ATTN_PLAIN is the HF ViT softmax(qk^T/sqrt(d))v.  The T x T score matrix is
- * never materialised.  For G <= 16 (SAM windows) pass the 16-bit rel-pos tables tabh/tabw [(2G-1), 64] instead of
- * relh/relw: the decomposed terms are then computed inside the kernel and la_relpos_terms is not needed. */
+ * never materialised.  For G <= 16 (SAM windows) and G == 64 (SAM global blocks at 1024 px) pass the 16-bit rel-pos tables
+ * tabh/tabw [(2G-1), 64] instead of relh/relw: the decomposed terms are then computed inside the kernel (a few MFMAs
+ * per query tile) and la_relpos_terms is not needed. */
 int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw,
                 const void* tabh, const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode,
                 int dt, void* stream);

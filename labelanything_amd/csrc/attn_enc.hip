@@ -114,7 +114,8 @@ struct AttnArgs {
 };
 
 // MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
-// MODE 2: rel-pos, G == 64 (tile == key row).  MODE 3: rel-pos, G <= 16 (SAM windows): the decomposed terms are computed
+// MODE 2: rel-pos, G == 64 (tile == key row), terms from la_relpos_terms.  MODE 4: same with the terms computed in-kernel.
+// MODE 3: rel-pos, G <= 16 (SAM windows): the decomposed terms are computed
 // IN the kernel (U[r][q] = R[r] . q on MFMA, 8 extra MFMAs per 32-query tile) - no la_relpos_terms pass, no global bias.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
@@ -164,6 +165,52 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         rw[t][g4 * 4 + 2] = v.z * inv_scale;
         rw[t][g4 * 4 + 3] = v.w * inv_scale;   // (vector element writes with constant indices stay in registers)
       }
+  } else if (MODE == 4) {
+    // G == 64, terms computed in-kernel.  The wave's 32 queries share the image row y and cover columns x0 .. x0+31.
+    //   relw[q][kw] = q . Rw[x - kw + 63] = Uw[(x - x0) + 63 - kw][q],  Uw[i][q] = Rw[x0 + i] . q,  i < 96   (12 MFMAs)
+    //   relh[q][j]  = q . Rh[y - j + 63]  = Uh[63 - j][q],              Uh[i][q] = Rh[y + i] . q,   i < 64   ( 8 MFMAs)
+    // Uw tiles are bounced through a per-wave LDS scratch to reach the score-accumulator register layout.
+    my_bh = bias_lds + wave * 32 * 65;
+    const int y = q0 >> 6, x0 = q0 & 63;
+    const T* tabw = reinterpret_cast<const T*>(a.tabw);
+    const T* tabh = reinterpret_cast<const T*>(a.tabh);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rw[t][r] = 0.f;
+#pragma unroll 1
+    for (int tt = 0; tt < 3; ++tt) {
+      const T* tp = tabw + (size_t)min(x0 + tt * 32 + fr, 126) * HD + fh * 8;
+      f32x16 u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) my_bh[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = u[r] * inv_scale;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kw = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const int i = fr + 63 - kw - tt * 32;
+          if (i >= 0 && i < 32) rw[t][r] = my_bh[fr * 33 + i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int tt = 0; tt < 2; ++tt) {
+      const T* tp = tabh + (size_t)min(y + tt * 32 + fr, 126) * HD + fh * 8;
+      f32x16 u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) my_bh[fr * 65 + 63 - (tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh)] = u[r] * inv_scale;
+    }
   } else if (MODE == 1) {
     const int G = a.G, GS = G + 1;
     my_bh = bias_lds + wave * 2 * 32 * GS;
@@ -253,11 +300,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     // (no per-tile initialisation pass); the per-row scalar relh[q][tile] is folded into the softmax constants below.
     f32x16 s[2];
     float rh = 0.f;
-    if (MODE == 2) rh = my_bh[fr * 65 + j];
+    if (MODE == 2 || MODE == 4) rh = my_bh[fr * 65 + j];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const uint4 kf0 = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, fh));
-      if (MODE == 2) {
+      if (MODE == 2 || MODE == 4) {
         s[t] = Half16<T>::mfma32(kf0, qf[0], rw[t]);
       } else {
         f32x16 z;
@@ -437,7 +484,14 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
       LA_CHECK_LAUNCH("la_attn_fwd");
       return 0;
     }
-    LA_CHECK_ARG(relh && relw, "la_attn_fwd: rel-pos terms missing (run la_relpos_terms, or pass the tables for G <= 16)");
+    if (tabh && tabw && G == 64) {        // global blocks: terms computed in the prologue of each query tile
+      const size_t lds = kv + 4 * 32 * 65 * sizeof(float);
+      if (dt == LA_F16) la::launch_attn<la::f16_t, 4>(a, lds, st);
+      else la::launch_attn<la::bf16_t, 4>(a, lds, st);
+      LA_CHECK_LAUNCH("la_attn_fwd");
+      return 0;
+    }
+    LA_CHECK_ARG(relh && relw, "la_attn_fwd: rel-pos terms missing (run la_relpos_terms, or pass the tables for G <= 16 / G == 64)");
     if (G == 64) {
       const size_t lds = kv + 4 * 32 * 65 * sizeof(float);
       if (dt == LA_F16) la::launch_attn<la::f16_t, 2>(a, lds, st);

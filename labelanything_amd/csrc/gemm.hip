@@ -192,7 +192,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
   reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-template <typename T, int TI, int TJ, int BN_, int NT>
+template <typename T, int TI, int TJ, int BN_, int NT, int CR = 128>
 __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI][TJ], int nchunks, int my_chunk, int wrow0, int wcol0,
                                              int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid) {
   constexpr int LD = BN_ + 4;
@@ -226,10 +226,11 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
       }
     }
     __syncthreads();
-    const int mrow0 = m0 + chunk * 128;
+    const int mrow0 = m0 + chunk * CR;
     if (vt_tile) {
-      for (int it = tid; it < BN_ * 32; it += NT) {
-        const int rg = it & 31, c = it >> 5;
+      constexpr int RG = CR / 4;
+      for (int it = tid; it < BN_ * RG; it += NT) {
+        const int rg = it % RG, c = it / RG;
         const int col = n0 + c, row = mrow0 + rg * 4;
         if (col >= N || row >= M) continue;
         const float4 v = *reinterpret_cast<const float4*>(&epi[c * LD + rg * 4]);
@@ -253,7 +254,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
       continue;
     }
     constexpr int CG = BN_ / 8;
-    for (int it = tid; it < 128 * CG; it += NT) {
+    for (int it = tid; it < CR * CG; it += NT) {
       const int cg = it % CG, r = it / CG;
       const int row = mrow0 + r, col0 = n0 + cg * 8;
       if (row >= M || col0 >= N) continue;
@@ -347,7 +348,7 @@ __device__ __forceinline__ void mma_ktile(const char* sa, const char* sw, int ar
 // (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass; the XOR swizzle is applied to the per-lane SOURCE
 // address because the DMA destination is lane-linear), and the epilogue is staged through LDS so that every lane
 // handles 8 consecutive output columns (16-byte stores, float4 residual / bias loads).  Tile BM x BN with one
-// 64 x 64 sub-tile per wave: 128x128 (4 waves, 2 blocks/CU) or 256x128 (8 waves).
+// 64 x 64 sub-tile per wave: 128x128 (4 waves, 2 blocks/CU).
 // =================================================================================================================
 constexpr int EPI_LD = BN + 4;                      // fp32 row stride of the staged output tile
 constexpr int EPI_BYTES = 128 * EPI_LD * 4;         // one 128-row chunk
@@ -422,19 +423,21 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
 
 
 // =================================================================================================================
-// v3: 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), THREE LDS stages with prefetch distance 2.  The 128 x 128 kernel
-// re-reads every operand panel from L2 at 64 FLOP/byte and waits for each DMA in the iteration that issued it; here
-// the byte/FLOP ratio drops by 1.33x and two tiles of DMA stay in flight across the barrier: waves wait with a COUNTED
-// s_waitcnt vmcnt(NDMA) (only the oldest tile must have landed) and a raw s_barrier (a __syncthreads() would drain
-// vmcnt to 0).  Per iteration: wait(tile kt) -> barrier -> issue DMA(tile kt+2) into the buffer read in kt-1 -> MFMAs.
+// v4: 256 x 128 block tile, 4 waves (2 x 2) with a 128 x 64 tile PER WAVE (4 x 2 MFMA 32x32 accumulators = 128 VGPRs),
+// BK = 32, three LDS stages (72 KiB -> 2 workgroups per CU), prefetch distance 2 with counted vmcnt.
+// Rationale (PMC: 0 bank conflicts, 41 % of wave time parked in waitcnt/barrier, MFMA busy 40 %): the 128x128 kernel moves
+// 1.5 KiB through the LDS port per MFMA (1.0 fragment reads + 0.5 DMA writes); this shape moves 1.125 KiB.
+// Rows are 64 B here, so four tile rows share a 256-B bank row: chunk c of row r lives in slot c ^ ((r >> 2) & 3).
 // =================================================================================================================
+__device__ __forceinline__ int swz64_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
 template <typename T>
-__global__ __launch_bounds__(512, 2) void gemm_dma3_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+__global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
                                                             int M, int N, int K, LaGemmEpilogue e) {
-  constexpr int BM_ = 256;
-  constexpr int NW = 8, NT = 512;
-  constexpr int STAGE = (BM_ + BN) * BK * 2;       // 48 KiB
-  constexpr int NDMA = (BM_ + BN) / 8 / NW;        // 6 wave-level DMA instructions per k-tile
+  constexpr int BM_ = 256, BK_ = 32;
+  constexpr int NW = 4, NT = 256;
+  constexpr int STAGE = (BM_ + BN) * BK_ * 2;      // 24 KiB
+  constexpr int NDMA = (BM_ + BN) / 16 / NW;       // 6 wave-level DMA instructions (16 rows x 64 B each) per k-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -446,66 +449,73 @@ __global__ __launch_bounds__(512, 2) void gemm_dma3_kernel(const T* __restrict__
   int ldsoff[NDMA];
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
-    const int grp = i * NW + wave;
-    const int trow = grp * 8 + (lane >> 3);
-    const int slot = lane & 7;
-    if (grp < BM_ / 8) {
+    const int grp = i * NW + wave;                 // 16-row group over [A rows | W rows]
+    const int trow = grp * 16 + (lane >> 2);
+    const int slot = lane & 3;
+    if (grp < BM_ / 16) {
       const int r = trow;
-      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
+      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 2) & 3)) << 3);
     } else {
       const int r = trow - BM_;
-      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 2) & 3)) << 3);
     }
     ldsoff[i] = grp * 1024;
   }
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, lds0 + stage * STAGE + ldsoff[i]);
+    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK_, lds0 + stage * STAGE + ldsoff[i]);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK;
+  const int nk = K / BK_;
   const int fr = lane & 31, fh = lane >> 5;
   dma(0, 0);
   if (nk > 1) dma(1, 1);
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed (this wave's part); the tile issued after it may stay in flight
     if (kt + 1 < nk) dma_wait<NDMA>();
     else dma_wait<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 2 < nk) {
-      const int st2 = (stage + 2 >= 3) ? stage - 1 : stage + 2;
-      dma(kt + 2, st2);
-    }
+    if (kt + 2 < nk) dma(kt + 2, (stage + 2 >= 3) ? stage - 1 : stage + 2);
     const char* sa = smem + stage * STAGE;
-    const char* sw = sa + BM_ * BK * 2;
-    mma_ktile<T>(sa, sw, wm * 64, wn * 64, fr, fh, acc);
+    const char* sw = sa + BM_ * BK_ * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 af[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + swz64_off(wm * 128 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const uint4*>(sw + swz64_off(wn * 64 + j * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[i], wf[j], acc[i][j]);
+    }
     stage = (stage == 2) ? 0 : stage + 1;
   }
   __syncthreads();
-  epilogue_lds<T, 2, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, BM_ / 128, wm >> 1, (wm & 1) * 64, wn * 64, m0, n0, M, N, e, tid);
+  epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
 }
 
 template <typename T>
-static void launch_fast3(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-  constexpr int LDS = 3 * (256 + BN) * BK * 2;
+static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = 3 * (256 + BN) * 32 * 2;     // 72 KiB >= 67.5 KiB epilogue chunk
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma3_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int ntm = (M + 255) / 256, ntn = (N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm_dma3_kernel<T>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+  hipLaunchKernelGGL((gemm_dma4_kernel<T>), dim3(ntm * ntn), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e);
 }
 
@@ -821,19 +831,22 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     LA_CHECK_LAUNCH("la_gemm");
     return 0;
   }
-  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1", "128", "256"
+  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128)
   bool fast = la::fast_ok(A, lda, W, ldw, N, K, *epi) && !(force && force[0] == 'v');
   if (fast) {
+    // measured on MI355X (profiles/r01_gemm_variants.log): the 256x128 / 128x64-per-wave kernel wins by ~5 % on the short-K
+    // (K = 768) shapes once there are >= 2 full waves of tiles; the 128x128 kernel wins on long K and small grids.
     const long tiles256 = (long)((M + 255) / 256) * ((N + la::BN - 1) / la::BN);
-    bool big = false;   // 256x128 measured 5-10% slower than 128x128 on every SAM ViT-B shape (profiles/r01_gemm_v2.log)
-    if (force && force[0] == '1') big = false;
-    if (force && force[0] == '2') big = true;
-    const bool v3 = (force && force[0] == '3') || (!force && tiles256 >= 512);
-    if (v3) {
-      if (dt == LA_F16) la::launch_fast3<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
-      else la::launch_fast3<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
-    } else if (dt == LA_F16) big ? la::launch_fast<la::f16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::f16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
-    else big ? la::launch_fast<la::bf16_t, 256>(A, lda, W, ldw, M, N, K, *epi, st) : la::launch_fast<la::bf16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+    bool v4 = (K <= 1024) && (tiles256 >= 512);
+    if (force && force[0] == '4') v4 = true;
+    if (force && force[0] == '2') v4 = false;
+    if (v4) {
+      if (dt == LA_F16) la::launch_fast4<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+      else la::launch_fast4<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    } else {
+      if (dt == LA_F16) la::launch_fast<la::f16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+      else la::launch_fast<la::bf16_t, 128>(A, lda, W, ldw, M, N, K, *epi, st);
+    }
   } else {
     if (dt == LA_F16) la::launch_gemm<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
     else la::launch_gemm<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);

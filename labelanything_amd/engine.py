@@ -264,7 +264,7 @@ class LamEngine:
             L.gemm(xin, p[bp + ".qkv.w"], bias=w[bp + ".attn.qkv.bias"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t,
                    vt_Tpad=tpad, vt_hd=64, vt_heads=heads)
             ao = self.buf("enc.ao." + tag, (arows, e))
-            if gg <= 16:      # windows: rel-pos terms are computed inside the attention kernel
+            if gg <= 16 or gg == 64:      # rel-pos terms are computed inside the attention kernel
                 L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS,
                            tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             else:

@@ -45,6 +45,8 @@ def main():
         fl = 4 * b * heads * t_ * t_ * 64
         t = timeit(lambda: L.attn_fwd(qkv, vt, out, relh, relw, b, heads, t_, t_, g, e, 0.125, L.ATTN_RELPOS))
         print(f"attn relpos {name}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
+        t = timeit(lambda: L.attn_fwd(qkv, vt, out, None, None, b, heads, t_, t_, g, e, 0.125, L.ATTN_RELPOS, tabh=tab, tabw=tab))
+        print(f"attn relpos in-kernel {name}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
         t = timeit(lambda: L.attn_fwd(qkv, vt, out, None, None, b, heads, t_, t_, 0, e, 0.125, L.ATTN_PLAIN))
         print(f"attn plain  {name}: {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
         t = timeit(lambda: L.relpos_terms(qkv, b, heads, g, e, tab, tab, relh, relw))
