@@ -28,7 +28,8 @@ enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2 };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
 enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3 };
 /* la_attn_fwd modes */
-enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1 };
+/* LA_ATTN_RELPOS_WIN16: SAM window attention with the keys held in a 16-wide padded slot order (see la_attn_fwd) */
+enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1, LA_ATTN_RELPOS_WIN16 = 2 };
 
 const char* la_last_error(void);
 int la_version(void);
@@ -59,6 +60,7 @@ typedef struct LaGemmEpilogue {
   int p0, p1, p2, p3, p4;
   void* vt;
   int vt_col0, vt_T, vt_Tpad, vt_hd, vt_heads;
+  int vt_ws;           /* > 0: token t of a ws x ws window goes to slot (t / ws) * 16 + t % ws of the V^T row (LA_ATTN_RELPOS_WIN16) */
 } LaGemmEpilogue;
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.
@@ -103,7 +105,10 @@ int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void*
  * (image_encoder.py:246-253); LA_ATTN_PLAIN is the HF ViT softmax(qk^T/sqrt(d))v.  The T x T score matrix is
  * never materialised.  For G <= 16 (SAM windows) and G == 64 (SAM global blocks at 1024 px) pass the 16-bit rel-pos tables
  * tabh/tabw [(2G-1), 64] instead of relh/relw: the decomposed terms are then computed inside the kernel (a few MFMAs
- * per query tile) and la_relpos_terms is not needed. */
+ * per query tile) and la_relpos_terms is not needed.
+ * mode LA_ATTN_RELPOS_WIN16 (G <= 16, tables required): keys live in slot order s = kh*16 + kw (16*G slots, Tpad >= 16*G,
+ * V^T written with LaGemmEpilogue.vt_ws = G, K rows gathered by the kernel).  A 64-slot tile is then exactly four key
+ * rows, so the bias of every score register is bh[4 per tile] + bw[8 per lane] instead of three LDS lookups. */
 int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw,
                 const void* tabh, const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode,
                 int dt, void* stream);

@@ -15,6 +15,7 @@
 //                 generic path (windows, other grids): per-wave LDS tables indexed by (key / G, key % G).
 // la_relpos_terms  one wave per (batch, head, query row y): relh = Q_y . Rh_y^T and U = Q_y . Rw^T on MFMA
 //               straight from global memory, U scattered to relw[q][qx - r + G - 1].
+#include <cstdlib>
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   // ---- bias staging ---------------------------------------------------------------------------------
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * KV_STAGE);
   f32x16 rw[2];
+  float bw8[8];
   float* my_bh = nullptr;
   float* my_bw = nullptr;
   const int* keyinfo = nullptr;
@@ -165,6 +167,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         rw[t][g4 * 4 + 2] = v.z * inv_scale;
         rw[t][g4 * 4 + 3] = v.w * inv_scale;   // (vector element writes with constant indices stay in registers)
       }
+  } else if (MODE == 5) {
+    // windows in 16-wide slot order: U tables as in MODE 3, then the bias of score register (t, r) in tile j is
+    //   bh4[2t + (r >> 3)]  (key row 4j + 2t + (r>>3))  +  bw8[((r >> 2) & 1) * 4 + (r & 3)]  (key column 8((r>>2)&1) + 4fh + (r&3)),
+    // with padded rows / columns carrying NEG_BIG (no separate masking pass).
+    const int G = a.G, nrel = 2 * G - 1;
+    my_bh = bias_lds + wave * 2 * 32 * 33;
+    my_bw = my_bh + 32 * 33;
+    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    f32x16 uh, uw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uh[r] = uw[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uh = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(th + ks * 16), qf[ks], uh);
+      uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      my_bh[fr * 33 + row] = uh[r] * inv_scale;
+      my_bw[fr * 33 + row] = uw[r] * inv_scale;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int qx = qc % G;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kw = 8 * (i >> 2) + 4 * fh + (i & 3);
+      bw8[i] = (kw < G) ? my_bw[fr * 33 + qx + G - 1 - kw] : NEG_BIG;
+    }
   } else if (MODE == 4) {
     // G == 64, terms computed in-kernel.  The wave's 32 queries share the image row y and cover columns x0 .. x0+31.
     //   relw[q][kw] = q . Rw[x - kw + 63] = Uw[(x - x0) + 63 - kw][q],  Uw[i][q] = Rw[x0 + i] . q,  i < 96   (12 MFMAs)
@@ -274,7 +306,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const unsigned sv = sk + 64 * HD * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int key = min(j * 64 + krow[i], T_ - 1);
+      int key;
+      if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
+        const int slot = j * 64 + krow[i];
+        key = min(slot >> 4, a.G - 1) * a.G + min(slot & 15, a.G - 1);
+      } else {
+        key = min(j * 64 + krow[i], T_ - 1);
+      }
       dma16(ksrc[i] + (size_t)key * E3, sk + (i * 4 + wave) * 1024);
       dma16(vsrc[i] + j * 64, sv + (i * 4 + wave) * 1024);
     }
@@ -287,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
 
-  const int ntiles = (T_ + 63) >> 6;
+  const int ntiles = (MODE == 5) ? ((16 * a.G + 63) >> 6) : ((T_ + 63) >> 6);
   dma(0, 0);
   dma_wait<0>();
   __syncthreads();
@@ -306,6 +344,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       const uint4 kf0 = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, fh));
       if (MODE == 2 || MODE == 4) {
         s[t] = Half16<T>::mfma32(kf0, qf[0], rw[t]);
+      } else if (MODE == 5) {
+        f32x16 z;
+        const int qy = qc / a.G;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int kh = 4 * j + 2 * t + hh;
+          const float bh = (kh < a.G) ? my_bh[fr * 33 + qy + a.G - 1 - kh] : NEG_BIG;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) z[hh * 8 + i] = bh + bw8[i];
+        }
+        s[t] = Half16<T>::mfma32(kf0, qf[0], z);
       } else {
         f32x16 z;
 #pragma unroll
@@ -345,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           s[t][r] += bh_q[info >> 16] + bw_q[info & 0xffff];
         }
     }
-    if (j * 64 + 64 > T_) {  // tail tile: mask keys >= T (wave-uniform branch)
+    if (MODE != 5 && j * 64 + 64 > T_) {  // tail tile: mask keys >= T (wave-uniform branch)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -432,6 +481,177 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SAM window attention (T = ws^2 <= 256 tokens, e.g. 196): latency / bandwidth-bound, so a different shape:
+// ONE WAVE per (window, head, 32-query tile), no LDS staging of K / V and no workgroup barriers in the key loop - the
+// MFMA A operands (K rows, V^T rows) are fetched straight from global memory (the 7 query tiles of a window-head hit
+// the same lines in L1/L2).  16 independent waves per CU hide the load latency.  Rel-pos terms are computed in the
+// prologue (U[r][q] = R[r] . q, 8 MFMAs) and bounced through a small per-wave LDS table, as in MODE 3 above.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 3) void attn_window_kernel(AttnArgs a, int qtiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int G = a.G, T_ = a.T, E3 = 3 * a.E;
+  // key -> (G-1-kh, G-1-kw) lookup, shared by the 4 waves
+  int* keyinfo = reinterpret_cast<int*>(smem);
+  for (int k = tid; k < a.Tpad; k += 256) {
+    const int kk = min(k, T_ - 1);
+    keyinfo[k] = ((G - 1 - kk / G) << 16) | (G - 1 - kk % G);
+  }
+  __syncthreads();
+  const int job = blockIdx.x * 4 + wave;
+  const int njobs = a.B * a.heads * qtiles;
+  if (job >= njobs) return;
+  const int qt = job % qtiles, bh = job / qtiles;
+  const int h = bh % a.heads, b = bh / a.heads;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* vt = reinterpret_cast<const T*>(a.vt);
+  const int q0 = qt * 32, q = q0 + fr, qc = min(q, T_ - 1);
+  const float inv_scale = 1.0f / a.scale;
+  const float c2 = a.scale * 1.44269504088896340736f;
+
+  uint4 qf[4];
+  {
+    const T* p = qkv + ((size_t)b * T_ + qc) * E3 + h * HD + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
+  }
+  // ---- decomposed rel-pos terms -> per-wave LDS tables [32 queries][33] --------------------------------------
+  float* my_bh = reinterpret_cast<float*>(smem + a.Tpad * sizeof(int)) + wave * 2 * 32 * 33;
+  float* my_bw = my_bh + 32 * 33;
+  {
+    const int nrel = 2 * G - 1;
+    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    f32x16 uh, uw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uh[r] = uw[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uh = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(th + ks * 16), qf[ks], uh);
+      uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      my_bh[fr * 33 + row] = uh[r] * inv_scale;
+      my_bw[fr * 33 + row] = uw[r] * inv_scale;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float* bh_q = my_bh + fr * 33 + qc / G;
+  const float* bw_q = my_bw + fr * 33 + qc % G;
+
+  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * HD + fh * 8;      // + key * E3 + ks * 16
+  const T* vbase = vt + ((size_t)bh * HD + fr) * a.Tpad + fh * 8;          // + d_half * 32 * Tpad + key0 + ks * 16
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int ntiles = (T_ + 63) >> 6;
+  for (int j = 0; j < ntiles; ++j) {
+    // ---- S^T = K Q^T (A operand straight from global) -----------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const T* kp = kbase + (size_t)min(j * 64 + t * 32 + fr, T_ - 1) * E3;
+      uint4 kf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(kp + ks * 16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[t] = Half16<T>::mfma32(kf[ks], qf[ks], s[t]);
+    }
+    // V^T fragments for this tile: issue the loads now, they land while the softmax runs
+    uint4 vf[2][4];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) vf[d][ks] = *reinterpret_cast<const uint4*>(vbase + (size_t)d * 32 * a.Tpad + j * 64 + ks * 16);
+    // ---- bias + mask ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int info = keyinfo[key];
+        const float sv = s[t][r] + bh_q[info >> 16] + bw_q[info & 0xffff];
+        s[t][r] = (key < T_) ? sv : NEG_BIG;
+      }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = -m_run * c2;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, mc));
+        s[t][r] = p;
+        psum += p;
+      }
+    l_run += psum;
+    uint4 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int t = ks >> 1, g0 = (ks & 1) * 8;
+      const uint32_t x0 = pack2<T>(s[t][g0 + 0], s[t][g0 + 1]);
+      const uint32_t x1 = pack2<T>(s[t][g0 + 2], s[t][g0 + 3]);
+      const uint32_t y0 = pack2<T>(s[t][g0 + 4], s[t][g0 + 5]);
+      const uint32_t y1 = pack2<T>(s[t][g0 + 6], s[t][g0 + 7]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      pf[ks] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) oacc[d] = Half16<T>::mfma32(vf[d][ks], pf[ks], oacc[d]);
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (q < T_) {
+    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HD;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 v;
+        v.x = pack2<T>(oacc[d][g4 * 4 + 0] * inv_l, oacc[d][g4 * 4 + 1] * inv_l);
+        v.y = pack2<T>(oacc[d][g4 * 4 + 2] * inv_l, oacc[d][g4 * 4 + 3] * inv_l);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
+      }
+  }
+}
+
+template <typename T>
+static void launch_window(const AttnArgs& a, hipStream_t st) {
+  const int qtiles = (a.T + 31) / 32;
+  const int njobs = a.B * a.heads * qtiles;
+  const size_t lds = (size_t)a.Tpad * sizeof(int) + 4 * 2 * 32 * 33 * sizeof(float);
+  hipLaunchKernelGGL((attn_window_kernel<T>), dim3((njobs + 3) / 4), dim3(256), lds, st, a, qtiles);
+}
+
 template <typename T, int MODE>
 static void launch_attn(const AttnArgs& a, size_t lds, hipStream_t st) {
   static size_t attr_lds = 0;   // raise the dynamic-LDS limit once (and again only if a larger request shows up)
@@ -475,9 +695,22 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
   if (mode == LA_ATTN_PLAIN) {
     if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, kv, st);
     else la::launch_attn<la::bf16_t, 0>(a, kv, st);
+  } else if (mode == LA_ATTN_RELPOS_WIN16) {
+    LA_CHECK_ARG(tabh && tabw && G > 0 && G <= 16 && G * G == T && Tpad >= 16 * G,
+                 "la_attn_fwd: WIN16 needs the tables, T == G*G, G <= 16 and Tpad >= 16*G (T=%d G=%d Tpad=%d)", T, G, Tpad);
+    const size_t lds = kv + 4 * 2 * 32 * 33 * sizeof(float);
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 5>(a, lds, st);
+    else la::launch_attn<la::bf16_t, 5>(a, lds, st);
   } else if (mode == LA_ATTN_RELPOS) {
     LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
     if (tabh && tabw && G <= 16) {        // windows: bias terms computed in-kernel from the tables
+      static const char* wforce = getenv("LA_WINDOW_PATH");     // debugging: "lds" selects the LDS-staged MODE 3 kernel
+      if (!(wforce && wforce[0] == 'l')) {
+        if (dt == LA_F16) la::launch_window<la::f16_t>(a, st);
+        else la::launch_window<la::bf16_t>(a, st);
+        LA_CHECK_LAUNCH("la_attn_fwd");
+        return 0;
+      }
       const size_t lds = kv + 4 * 2 * 32 * 33 * sizeof(float) + (size_t)Tpad * sizeof(int);
       if (dt == LA_F16) la::launch_attn<la::f16_t, 3>(a, lds, st);
       else la::launch_attn<la::bf16_t, 3>(a, lds, st);

@@ -15,6 +15,9 @@ namespace la {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
 
+// V^T token -> slot (identity, or the 16-wide padded window order)
+__device__ __forceinline__ int vt_slot(int t, int ws) { return ws > 0 ? (t / ws) * 16 + (t % ws) : t; }
+
 struct RowMap {
   int mode, p0, p1, p2, p3, p4;
 };
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
         else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
         if (to_vt) {
           const int b = row / e.vt_T, t = row % e.vt_T;
-          vt[((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + t] = (T)v;
+          vt[((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(t, e.vt_ws)] = (T)v;
           continue;
         }
         int drow = map_row(rm, row);
@@ -238,16 +241,22 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
         const int cv = col - e.vt_col0;
         const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
         const int b = row / e.vt_T, t = row % e.vt_T;
-        T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + t;
-        if ((e.vt_T & 3) == 0 && row + 3 < M) {
+        T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(t, e.vt_ws);
+        if ((e.vt_T & 3) == 0 && row + 3 < M && (e.vt_ws == 0 || ((e.vt_ws & 3) == 0) || (t % e.vt_ws) <= e.vt_ws - 4)) {
+          // 4 consecutive tokens of one batch item (and, for windows, of one window row: contiguous slots, 8-byte aligned
+          // because t % 4 == 0 and the row offset 16 * kh + (t % ws) keeps the parity of t % ws ... only when ws is even)
           store4v<T>(dst, v.x + bias, v.y + bias, v.z + bias, v.w + bias);
+        } else if ((e.vt_T & 3) == 0 && row + 3 < M && e.vt_ws > 0 && (e.vt_ws & 1) == 0) {
+          // group straddles a window row: two token pairs, each inside one row (ws even), 4-byte stores
+          store2<T>(dst, v.x + bias, v.y + bias);
+          store2<T>(vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(t + 2, e.vt_ws), v.z + bias, v.w + bias);
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
           for (int j = 0; j < 4; ++j) {
             const int rj = row + j;
             if (rj >= M) break;
             const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
-            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + tj2] = (T)(vv[j] + bias);
+            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(tj2, e.vt_ws)] = (T)(vv[j] + bias);
           }
         }
       }

@@ -257,14 +257,18 @@ class LamEngine:
                 arows = nb * t
                 xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
                 self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g)
-            tpad = _ceil(t, 64)
+            win16 = (not is_global) and gg <= 16      # windows: V^T / K in 16-wide padded slot order (LA_ATTN_RELPOS_WIN16)
+            tpad = _ceil(16 * gg, 64) if win16 else _ceil(t, 64)
             tag = "g" if is_global else "w"
             qkv = self.buf("enc.qkv." + tag, (arows, 3 * e))
             vt = self.buf("enc.vt." + tag, (nb * heads, 64, tpad), zero=True)
             L.gemm(xin, p[bp + ".qkv.w"], bias=w[bp + ".attn.qkv.bias"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t,
-                   vt_Tpad=tpad, vt_hd=64, vt_heads=heads)
+                   vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=gg if win16 else 0)
             ao = self.buf("enc.ao." + tag, (arows, e))
-            if gg <= 16 or gg == 64:      # rel-pos terms are computed inside the attention kernel
+            if win16:
+                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS_WIN16,
+                           tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
+            elif gg <= 16 or gg == 64:      # rel-pos terms are computed inside the attention kernel
                 L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS,
                            tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             else:

@@ -303,3 +303,37 @@ def test_conv3x3_fp32_implicit_gemm(L, c, co):
     torch.cuda.synchronize()
     ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).float().permute(0, 2, 3, 1).reshape(-1, co)
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("g", [14, 8])
+def test_window_attention_in_padded_slot_order(L, dt, g):
+    """LA_ATTN_RELPOS_WIN16: V^T written by the GEMM epilogue in 16-wide slot order (vt_ws), K gathered by the kernel."""
+    b, heads, e = 5, 2, 128
+    t = g * g
+    tpad = (16 * g + 63) // 64 * 64
+    x = rnd(b * t, e, seed=60).to(dt)
+    wqkv = (rnd(3 * e, e, seed=61) / math.sqrt(e)).to(dt)
+    bias = rnd(3 * e, seed=62) * 0.1
+    qkv = torch.zeros(b * t, 3 * e, device="cuda", dtype=dt)
+    vt = torch.zeros(b * heads, 64, tpad, device="cuda", dtype=dt)
+    L.gemm(x, wqkv, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=g)
+    torch.cuda.synchronize()
+    ref_qkv = x.float() @ wqkv.float().t() + bias
+    v = ref_qkv[:, 2 * e:].view(b, g, g, heads, 64).permute(0, 3, 4, 1, 2)             # (b, heads, 64, kh, kw)
+    slots = vt.view(b, heads, 64, tpad)[..., : 16 * g].reshape(b, heads, 64, g, 16)
+    assert rel_err(slots[..., :g], v) < TOL16[dt]
+    assert float(slots[..., g:].float().abs().max()) == 0.0
+    tabh = (rnd(2 * g - 1, 64, seed=63) * 0.3).to(dt)
+    tabw = (rnd(2 * g - 1, 64, seed=64) * 0.3).to(dt)
+    qkv[:, 2 * e:] = ref_qkv[:, 2 * e:].to(dt)       # reference path reads V from the qkv buffer
+    q = qkv[:, :e].float().view(b, t, heads, 64).transpose(1, 2).reshape(b * heads, g, g, 64)
+    rh = O.rel_pos_table(g, g, tabh.float().cpu()).cuda()
+    rw = O.rel_pos_table(g, g, tabw.float().cpu()).cuda()
+    bh = torch.einsum("nyxc,ykc->nyxk", q, rh).reshape(b, heads, t, g, 1)
+    bw = torch.einsum("nyxc,xkc->nyxk", q, rw).reshape(b, heads, t, 1, g)
+    ref = _attn_ref(qkv, b, heads, t, (bh + bw).reshape(b, heads, t, t))
+    out = torch.zeros(b * t, e, device="cuda", dtype=dt)
+    L.attn_fwd(qkv, vt, out, None, None, b, heads, t, tpad, g, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < TOL16[dt]

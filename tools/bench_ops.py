@@ -66,6 +66,8 @@ def main():
     print(f"attn window (50 win): {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: L.attn_fwd(qkv, vt, out, None, None, b, heads, t_, 256, g, e, 0.125, L.ATTN_RELPOS, tabh=tab, tabw=tab))
     print(f"attn window in-kernel bias (50 win): {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
+    t = timeit(lambda: L.attn_fwd(qkv, vt, out, None, None, b, heads, t_, 256, g, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tab, tabw=tab))
+    print(f"attn window slot-order WIN16 (50 win): {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF/s")
     t = timeit(lambda: L.relpos_terms(qkv, b, heads, g, e, tab, tab, relh, relw))
     print(f"relpos terms window: {t*1e6:8.1f} us")
     x = torch.randn(8192, 768, device="cuda")
