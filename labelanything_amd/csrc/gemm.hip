@@ -369,7 +369,7 @@ constexpr int fast_lds_bytes() {
 
 template <typename T, int BM_>
 __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
-                                                               int M, int N, int K, LaGemmEpilogue e) {
+                                                               int M, int N, int K, LaGemmEpilogue e, int gm) {
   constexpr int NW = (BM_ / 64) * 2;               // waves: (BM_/64) x 2
   constexpr int NT = NW * 64;
   constexpr int STAGE = (BM_ + BN) * BK * 2;       // bytes
@@ -378,8 +378,9 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN;
+  int tm_, tn_;
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
   // ---- DMA plan: instruction i of this wave moves 8 tile rows (1 KiB); lane -> (row lane/8, slot lane%8) --------
   const T* src[NDMA];
@@ -442,7 +443,7 @@ __device__ __forceinline__ int swz64_off(int row, int chunk) { return row * 64 +
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
-                                                            int M, int N, int K, LaGemmEpilogue e) {
+                                                            int M, int N, int K, LaGemmEpilogue e, int gm) {
   constexpr int BM_ = 256, BK_ = 32;
   constexpr int NW = 4, NT = 256;
   constexpr int STAGE = (BM_ + BN) * BK_ * 2;      // 24 KiB
@@ -451,8 +452,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM_, n0 = (tile % ntn) * BN;
+  int tm_, tn_;
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
   const T* src[NDMA];
   int ldsoff[NDMA];
@@ -515,6 +517,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
 }
 
+static int tile_group_m() {
+  static int gm = -1;
+  if (gm < 0) {
+    const char* v = getenv("LA_GEMM_GROUP_M");
+    gm = v ? atoi(v) : 8;
+  }
+  return gm;
+}
+
 template <typename T>
 static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = 3 * (256 + BN) * 32 * 2;     // 72 KiB >= 67.5 KiB epilogue chunk
@@ -525,7 +536,7 @@ static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, 
   }
   const int ntm = (M + 255) / 256, ntn = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_dma4_kernel<T>), dim3(ntm * ntn), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e);
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
 }
 
 template <typename T, int BM_>
@@ -538,7 +549,7 @@ static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, i
   }
   const int ntm = (M + BM_ - 1) / BM_, ntn = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_dma_kernel<T, BM_>), dim3(ntm * ntn), dim3(BM_ * 2), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e);
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
 }
 
 static bool fast_ok(const void* A, int lda, const void* W, int ldw, int N, int K, const LaGemmEpilogue& e) {
@@ -755,33 +766,45 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
     float w[SK_COLS][8];
 #pragma unroll
     for (int c = 0; c < SK_COLS; ++c) Load8<T>::ld(Wt + (size_t)min(n0 + c, N - 1) * ldw + k, w[c]);
+    // no "if (m < M)" around the loads: hipcc would branch around every load and wait for each one in turn (one full memory
+    // latency per row); rows >= M re-read row M-1 and are simply not stored.
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-      if (m < M) {
-        float x[8];
-        Load8<T>::ld(A + (size_t)m * lda + k, x);
+      float x[8];
+      Load8<T>::ld(A + (size_t)min(m, M - 1) * lda + k, x);
 #pragma unroll
-        for (int c = 0; c < SK_COLS; ++c)
+      for (int c = 0; c < SK_COLS; ++c)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(x[j], w[c][j], acc[m][c]);
-      }
+        for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(x[j], w[c][j], acc[m][c]);
     }
   }
-  T* outT = reinterpret_cast<T*>(e.out16);
+  // reduce every (m, column) partial over the wave and hand output #idx to lane idx % 64, so the epilogue (bias / activation /
+  // residual loads / stores) runs ONCE, lane-parallel, instead of 4*MR times on lane 0 behind dependent scalar loads.
+  constexpr int ROUNDS = (MR * SK_COLS + 63) / 64;
+  float mine[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) mine[r] = 0.f;
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
 #pragma unroll
     for (int c = 0; c < SK_COLS; ++c) {
       const float s = wave_sum(acc[m][c]);
-      const int col = n0 + c;
-      if (lane == 0 && m < M && col < N) {
-        float v = s + (e.bias ? e.bias[col] : 0.f);
-        if (e.act == LA_ACT_GELU) v = gelu_erf(v);
-        else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
-        if (e.res) v += e.res[(size_t)(e.res_mod ? m % e.res_mod : m) * e.ldr + col];
-        if (e.out32) e.out32[(size_t)m * e.ld32 + col] = v;
-        if (outT) outT[(size_t)m * e.ld16 + col] = (T)v;
-      }
+      const int idx = m * SK_COLS + c;
+      if (lane == (idx & 63)) mine[idx >> 6] = s;
+    }
+  }
+  T* outT = reinterpret_cast<T*>(e.out16);
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int idx = r * 64 + lane;
+    const int m = idx / SK_COLS, col = n0 + idx % SK_COLS;
+    if (m < M && m < MR && col < N) {
+      float v = mine[r] + (e.bias ? e.bias[col] : 0.f);
+      if (e.act == LA_ACT_GELU) v = gelu_erf(v);
+      else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
+      if (e.res) v += e.res[(size_t)(e.res_mod ? m % e.res_mod : m) * e.ldr + col];
+      if (e.out32) e.out32[(size_t)m * e.ld32 + col] = v;
+      if (outT) outT[(size_t)m * e.ld16 + col] = (T)v;
     }
   }
 }

@@ -119,6 +119,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
   return base + idx;
 }
 
+// Linear tile index -> (tile_m, tile_n) in groups of GM row-panels with M fastest inside a group, so that the ~64 tiles
+// one XCD has in flight cover a GM x (64/GM) patch: both the A row-panels and the W column-panels of the patch stay
+// resident in the 4 MiB L2 instead of W being re-fetched from the fabric for every row-panel.
+__device__ __forceinline__ void tile_coords(int t, int ntm, int ntn, int gm, int& tm, int& tn) {
+  if (gm <= 1) {
+    tm = t / ntn;
+    tn = t % ntn;
+    return;
+  }
+  const int per_group = gm * ntn;
+  const int g = t / per_group;
+  const int first = g * gm;
+  const int rows = min(gm, ntm - first);
+  const int r = t - g * per_group;
+  tm = first + r % rows;
+  tn = r / rows;
+}
+
 }  // namespace la
 
 // ---- host side error plumbing ---------------------------------------------------------------
