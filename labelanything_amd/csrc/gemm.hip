@@ -539,6 +539,257 @@ static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, 
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
 }
 
+
+// =================================================================================================================
+// v6 "ping-pong": 256 x 256 x 64 tile, 8 waves = 2 groups of 4; group g owns rows [128 g, +128), wave i of a group the
+// columns [64 i, +64) -> 128 x 64 per wave (4 x 2 MFMA 32x32 accumulators).  Every SIMD hosts one wave of each group.
+// The K loop is cut into half-tiles ("bursts" of 2 MFMA k-steps = 16 MFMAs = 512 matrix-pipe cycles) and the two groups
+// run ONE BARRIER OUT OF PHASE: while group 0 issues the 16 MFMAs of a burst, group 1 fetches the fragments of its
+// next burst from LDS (12 ds_read_b128) and issues its share of the LDS-DMA for the next K tile, then they swap.
+//
+//   interval      4t      4t+1    4t+2    4t+3    4t+4 ...        (one s_barrier between intervals)
+//   group 0    L(t,b0)  M(t,b0) L(t,b1) M(t,b1) L(t+1,b0)
+//   group 1    M(t-1,b1) L(t,b0) M(t,b0) L(t,b1) M(t,b1)
+//
+// LDS: 2 stages x (A 256x64 + W 256x64) x 2 B = 128 KiB, tile t in stage t & 1.  Hazards:
+//   * DMA(t+1) overwrites the stage of tile t-1, last read by group 1 in interval 4t-1; it is issued in L(t,b0)
+//     (interval 4t for group 0, 4t+1 for group 1) - after that read, separated by a barrier.
+//   * tile t+1 is first read in interval 4t+4; every wave drains its own DMA (s_waitcnt vmcnt(0)) before the barrier that
+//     closes interval 4t+3, i.e. 2-3 intervals (>= 1000 cycles) after issuing it.
+// Operand traffic per MFMA: 0.75 KiB of fragment reads + 0.25 KiB of DMA (vs 1.0 + 0.5 in the 128x128 kernel) and half
+// the L2 reads per FLOP.
+// =================================================================================================================
+constexpr int PP_BM = 256, PP_BN = 256;
+constexpr int PP_STAGE = (PP_BM + PP_BN) * BK * 2;     // 64 KiB
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                          int M, int N, int K, LaGemmEpilogue e, int gm) {
+  constexpr int NW = 8, NT = 512;
+  constexpr int NDMA = (PP_BM + PP_BN) / 8 / NW;       // 8 wave-level DMA instructions (8 rows each) per K tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wi = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ntn = (N + PP_BN - 1) / PP_BN, ntm = (M + PP_BM - 1) / PP_BM;
+  int tm_, tn_;
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  const int m0 = tm_ * PP_BM, n0 = tn_ * PP_BN;
+
+  const T* src[NDMA];
+  int ldsoff[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int g8 = i * NW + wave;                    // 8-row group over [A rows | W rows]
+    const int trow = g8 * 8 + (lane >> 3);
+    const int slot = lane & 7;
+    if (g8 < PP_BM / 8) {
+      const int r = trow;
+      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
+    } else {
+      const int r = trow - PP_BM;
+      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+    }
+    ldsoff[i] = g8 * 1024;
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma = [&](int kt) {
+    const unsigned base = lds0 + (kt & 1) * PP_STAGE;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, base + ldsoff[i]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 af[2][4], wf[2][2];                           // fragments of one burst: [k-step][tile]
+  const int arow = grp * 128, wrow = wi * 64;
+  auto load_burst = [&](int kt, int b) {
+    const char* sa = smem + (kt & 1) * PP_STAGE;
+    const char* sw = sa + PP_BM * BK * 2;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int ch = (b * 2 + k2) * 2 + fh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[k2][j] = *reinterpret_cast<const uint4*>(sw + swz_off(wrow + j * 32 + fr, ch));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[k2][i] = *reinterpret_cast<const uint4*>(sa + swz_off(arow + i * 32 + fr, ch));
+    }
+  };
+  auto mma_burst = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[k2][i], wf[k2][j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  const int nk = K / BK;
+  dma(0);
+  dma_wait<0>();
+  bar();                                   // tile 0 resident
+  if (grp == 1) bar();                     // group 1 runs one interval behind
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- L(kt, b0): fragments of burst 0 + this wave's share of the next tile's DMA ----------------------------
+    if (kt + 1 < nk) dma(kt + 1);
+    load_burst(kt, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    // ---- M(kt, b0) ---------------------------------------------------------------------------------------------------
+    mma_burst();
+    bar();
+    // ---- L(kt, b1) ---------------------------------------------------------------------------------------------------
+    load_burst(kt, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) dma_wait<0>();           // closes global interval 4 kt + 3 for group 1
+    bar();
+    // ---- M(kt, b1) ---------------------------------------------------------------------------------------------------
+    mma_burst();
+    if (grp == 0) dma_wait<0>();           // closes global interval 4 kt + 3 for group 0
+    bar();
+  }
+  if (grp == 0) bar();                     // re-align the two groups
+  __syncthreads();
+
+  // ---- epilogue: four 64-row chunks staged through LDS (each wave's 128 rows span two chunks) -----------------------
+  float* epi = reinterpret_cast<float*>(smem);
+  constexpr int LD = PP_BN + 4;
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  T* outT = reinterpret_cast<T*>(e.out16);
+  T* vt = reinterpret_cast<T*>(e.vt);
+  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk) {
+    if (chunk > 0) __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (grp * 2 + half != chunk) continue;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ti = half * 2 + t2;                 // static: accumulator row-tile of this wave
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          if (!vt_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              epi[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + wrow + tj * 32 + fr] = acc[ti][tj][r];
+          } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
+              *reinterpret_cast<float4*>(&epi[(wrow + tj * 32 + fr) * (64 + 4) + t2 * 32 + 8 * g4 + 4 * fh]) = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + chunk * 64;
+    if (vt_tile) {      // transposed staging [col][64 rows + 4]: items = (col, 4-row group)
+      for (int it = tid; it < PP_BN * 16; it += NT) {
+        const int rg = it & 15, c = it >> 4;
+        const int col = n0 + c, row = mrow0 + rg * 4;
+        if (col >= N || row >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&epi[c * 68 + rg * 4]);
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const int cv = col - e.vt_col0;
+        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
+        const int b = row / e.vt_T, t = row % e.vt_T;
+        T* rowp = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad;
+        if ((e.vt_T & 3) == 0 && row + 3 < M && (e.vt_ws == 0 || (t % e.vt_ws) <= e.vt_ws - 4)) {
+          store4v<T>(rowp + vt_slot(t, e.vt_ws), v.x + bias, v.y + bias, v.z + bias, v.w + bias);
+        } else if ((e.vt_T & 3) == 0 && row + 3 < M && e.vt_ws > 0 && (e.vt_ws & 1) == 0) {
+          store2<T>(rowp + vt_slot(t, e.vt_ws), v.x + bias, v.y + bias);
+          store2<T>(rowp + vt_slot(t + 2, e.vt_ws), v.z + bias, v.w + bias);
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4; ++j) {
+            const int rj = row + j;
+            if (rj >= M) break;
+            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
+            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(tj2, e.vt_ws)] = (T)(vv[j] + bias);
+          }
+        }
+      }
+      continue;
+    }
+    constexpr int CG = PP_BN / 8;
+    for (int it = tid; it < 64 * CG; it += NT) {
+      const int cg = it % CG, r = it / CG;
+      const int row = mrow0 + r, col0 = n0 + cg * 8;
+      if (row >= M || col0 >= N) continue;
+      float v[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8 + 4]);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      }
+      int dcol = col0, row_add = 0, bcol = col0;
+      if (e.map == LA_MAP_CONVT2X2) {
+        const int kyx = col0 / e.p2;
+        dcol = col0 % e.p2;
+        bcol = dcol;
+        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+      }
+      if (e.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (e.act == LA_ACT_GELU) {
+        if (!e.out32) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
+      } else if (e.act == LA_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      int drow = map_row(rm, row);
+      if (drow < 0) continue;
+      drow += row_add;
+      if (e.res) {
+        const int rr = e.res_mod ? drow % e.res_mod : drow;
+        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
+        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
+      if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
+    }
+  }
+}
+
+template <typename T>
+static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = 2 * PP_STAGE;      // 128 KiB (epilogue chunk 64 x 260 x 4 = 65 KiB, transposed 256 x 68 x 4 = 68 KiB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int ntm = (M + PP_BM - 1) / PP_BM, ntn = (N + PP_BN - 1) / PP_BN;
+  hipLaunchKernelGGL((gemm_pp_kernel<T>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
+}
+
 template <typename T, int BM_>
 static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = fast_lds_bytes<BM_>();
@@ -872,7 +1123,11 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     bool v4 = (K <= 1024) && (tiles256 >= 512);
     if (force && force[0] == '4') v4 = true;
     if (force && force[0] == '2') v4 = false;
-    if (v4) {
+    const bool pp = (force && force[0] == '6') && (!epi->vt || (epi->vt_col0 % la::PP_BN) == 0);
+    if (pp) {
+      if (dt == LA_F16) la::launch_pp<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+      else la::launch_pp<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
+    } else if (v4) {
       if (dt == LA_F16) la::launch_fast4<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
       else la::launch_fast4<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
     } else {

@@ -641,16 +641,20 @@ class LamEngine:
         """Host side of postprocess_masks: per-item (orig_h, orig_w, crop_h, crop_w) + the padded output frame."""
         cfg = self.cfg
         s = cfg.image_size
-        dims_h = dims.detach().to("cpu", torch.int64)
-        hmax, wmax = [int(v) for v in dims_h.reshape(-1, 2).max(dim=0).values.tolist()]
+        # plain Python on the (tiny) dims list: torch CPU reductions wake the whole intra-op thread pool (measured
+        # ~19 ms per call on a 128-thread host) which would dwarf the GPU time of a small episode batch
+        dl = dims.detach().to("cpu").tolist()                      # [B][M+1][2]
+        hmax = max(int(hw[0]) for item in dl for hw in item)
+        wmax = max(int(hw[1]) for item in dl for hw in item)
         sizes = []
-        for oh, ow in dims_h[:, 0, :].tolist():
+        for item in dl:
+            oh, ow = int(item[0][0]), int(item[0][1])
             if cfg.custom_preprocess:
                 sc = s * 1.0 / max(oh, ow)
                 ph, pw = int(oh * sc + 0.5), int(ow * sc + 0.5)
             else:
                 ph, pw = s, s
-            sizes.append([int(oh), int(ow), ph, pw])
+            sizes.append([oh, ow, ph, pw])
         return torch.tensor(sizes, dtype=torch.int32), hmax, wmax
 
     def postprocess_dev(self, seg: Tensor, sizes_d: Tensor, hmax: int, wmax: int, flag_gts_u8: Optional[Tensor], want_argmax: bool):

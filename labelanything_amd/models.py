@@ -140,6 +140,13 @@ class Lam(nn.Module):
     # The launch sequence allocates nothing new after its first run and never touches the host, so it can be replayed
     # from a HIP graph (``use_graphs``): the decoder alone is ~170 short launches and is launch-bound otherwise.
     # ---------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _any_nonzero(t: torch.Tensor) -> bool:
+        """Host decision 'does this prompt type carry any flag' without waking torch's CPU thread pool for a few bytes."""
+        if t.is_cuda:
+            return bool((t != 0).any())          # device-resident flags: one host sync, as in the reference
+        return bool(t.numpy().any())
+
     def _prepare(self, batched_input: Dict[str, Any], with_prompts: bool = True, with_post: bool = True):
         """Host side (lam.py:138-170, 214-239, 401-404): returns (device inputs, hashable plan)."""
         eng = self.engine()
@@ -156,15 +163,15 @@ class Lam(nn.Module):
         kinds = []
         if with_prompts:
             # a prompt type is dropped entirely when all its flags are zero (host decision, lam.py:214-239)
-            if "prompt_points" in batched_input and bool((batched_input["flag_points"] != 0).any()):
+            if "prompt_points" in batched_input and self._any_nonzero(batched_input["flag_points"]):
                 inp["prompt_points"] = eng.h2d(batched_input["prompt_points"], torch.float32)
                 inp["flag_points"] = eng.h2d(batched_input["flag_points"], torch.int32)
                 kinds.append("point")
-            if "prompt_bboxes" in batched_input and bool((batched_input["flag_bboxes"] != 0).any()):
+            if "prompt_bboxes" in batched_input and self._any_nonzero(batched_input["flag_bboxes"]):
                 inp["prompt_bboxes"] = eng.h2d(batched_input["prompt_bboxes"], torch.float32)
                 inp["flag_bboxes"] = eng.h2d(batched_input["flag_bboxes"], torch.int32)
                 kinds.append("box")
-            if "prompt_masks" in batched_input and bool((batched_input["flag_masks"] != 0).any()):
+            if "prompt_masks" in batched_input and self._any_nonzero(batched_input["flag_masks"]):
                 inp["prompt_masks"] = eng.h2d(batched_input["prompt_masks"], torch.float32)
                 inp["flag_masks"] = eng.h2d(batched_input["flag_masks"], torch.int32)
                 kinds.append("mask")
