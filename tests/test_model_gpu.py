@@ -113,3 +113,47 @@ def test_hip_graph_replay_matches_eager_and_tracks_new_inputs():
     for k in ("logits", "argmax", "class_examples_embeddings"):
         assert torch.equal(e1[k], g1[k]) and torch.equal(e2[k], g2[k]) and torch.equal(e1[k], g1b[k])
     assert len(lam._graphs) == 1
+
+
+@pytest.mark.parametrize("prompts", [("point",), ("box",), ("mask", "box")])
+def test_prompt_type_combinations_match_oracle(prompts):
+    """Prompt types the golden cases do not cover (points only incl. the padding point, boxes only, masks + boxes),
+    HIP path vs the CPU oracle on the same seeded episode (decoder-only D=256 geometry, exact-fp32 decoder => 1e-4)."""
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    case = CASES["novit_d256_2w3s"]
+    cfg = case["cfg"]
+    ep = dict(case["episode"])
+    ep.update(prompts=prompts, seed=321)
+    ep.pop("drop_mask_of", None)
+    batch = make_episode(**ep)
+    rows = torch.tensor([0, 17, 42])
+    lam = Lam(cfg, seed=3).cuda()
+    lam.selected_rows = rows
+    out = lam(batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.lam_forward(init_state_dict(cfg, 3), geometry_for(cfg), batch, selected_rows=rows)
+    assert rel_err(out["logits"], ref["logits"]) < 1e-4
+    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 1e-4
+
+
+def test_class_and_example_attention_variants_match_oracle():
+    """class_attention + example_attention switches (build_lam.py:192-194) on a ragged-size batch of 2 episodes."""
+    from labelanything_amd.config import LamConfig
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    cfg = LamConfig(encoder=None, use_vit=False, image_size=128, image_embed_dim=64, embed_dim=64, spatial_convs=3,
+                    class_attention=True, example_attention=True, example_class_attention=False, custom_preprocess=True)
+    batch = make_episode(batch=2, n_ways=2, k_shots=2, image_size=128, seed=9, prompts=("mask", "point"), embeddings_channels=64,
+                         grid=8, dims=[[100, 128], [128, 64], [90, 90], [128, 128], [77, 50]])
+    batch["flag_gts"][1, 2] = False
+    lam = Lam(cfg, seed=4).cuda()
+    out = lam(batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.lam_forward(init_state_dict(cfg, 4), geometry_for(cfg), batch)
+    assert out["logits"].shape == ref["logits"].shape == (2, 3, 128, 128)
+    assert rel_err(out["logits"], ref["logits"]) < 1e-4

@@ -25,7 +25,8 @@ def main():
     print("device", torch.cuda.get_device_name(0), "dtype", dt)
     for (m, n, k, name) in [(8192, 2304, 768, "qkv"), (8192, 768, 768, "proj"), (8192, 3072, 768, "lin1"),
                             (8192, 768, 3072, "lin2"), (32768, 2304, 768, "qkv x4"), (32768, 3072, 768, "lin1 x4"),
-                            (32768, 768, 3072, "lin2 x4"), (4096, 4096, 4096, "4k cube")]:
+                            (32768, 768, 3072, "lin2 x4"), (65536, 768, 768, "proj x8"), (78400, 768, 768, "projw x8"),
+                            (65536, 768, 3072, "lin2 x8"), (65536, 3072, 768, "lin1 x8"), (4096, 4096, 4096, "4k cube")]:
         a = torch.randn(m, k, device="cuda").to(dt)
         w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(dt)
         bias = torch.randn(n, device="cuda")
