@@ -124,7 +124,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int BH = a.B * a.heads;
-  const int bh = blockIdx.x % BH, qblk = blockIdx.x / BH;  // same (image, head) -> same XCD when BH % 8 == 0
+  // Workgroup -> (image*head, query block).  Workgroup b runs on XCD b % 8; the ~64 workgroups an XCD has in flight must
+  // share their K / V^T (1 MiB per image-head at T = 4096) or every tile streams from the fabric (PMC: 6 GB FETCH per
+  // 16-image launch with bh fastest).  So inside one XCD the query block runs fastest: 64 resident workgroups = 2 heads.
+  int bh, qblk;
+  {
+    const int nq = (a.T + 127) / 128;
+    if ((BH & 7) == 0) {
+      const int idx = blockIdx.x >> 3;
+      qblk = idx % nq;
+      bh = (idx / nq) * 8 + (blockIdx.x & 7);
+    } else {
+      bh = blockIdx.x % BH;
+      qblk = blockIdx.x / BH;
+    }
+  }
   const int h = bh % a.heads, b = bh / a.heads;
   const int T_ = a.T, E3 = 3 * a.E;
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
