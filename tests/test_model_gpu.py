@@ -157,3 +157,25 @@ def test_class_and_example_attention_variants_match_oracle():
         ref = O.lam_forward(init_state_dict(cfg, 4), geometry_for(cfg), batch)
     assert out["logits"].shape == ref["logits"].shape == (2, 3, 128, 128)
     assert rel_err(out["logits"], ref["logits"]) < 1e-4
+
+
+def test_many_pairs_5way_5shot_matches_oracle():
+    """BASELINE cfg3 episode shape (5-way 5-shot: 26 images, 150 (support, class) pairs) on the reduced HF encoder:
+    exercises the large-token paths (M > 32 token GEMMs on the fp32 MFMA kernel, 150-token class_example_attention)."""
+    from labelanything_amd.config import LamConfig
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    cfg = LamConfig(encoder="hf_tiny", image_size=240, image_embed_dim=128, embed_dim=64, spatial_convs=3,
+                    class_encoder={"name": "RandomMatrixEncoder", "bank_size": 20, "embed_dim": 64}, custom_preprocess=False)
+    batch = make_episode(batch=1, n_ways=5, k_shots=5, image_size=240, seed=55, prompts=("mask", "point"))
+    rows = torch.tensor([0, 3, 9, 11, 14, 18])
+    lam = Lam(cfg, seed=8).cuda()
+    lam.selected_rows = rows
+    out = lam(batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.lam_forward(init_state_dict(cfg, 8), geometry_for(cfg), batch, selected_rows=rows)
+    assert out["logits"].shape == (1, 6, 240, 240)
+    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
+    assert rel_err(out["logits"], ref["logits"]) < 4e-3
