@@ -262,31 +262,53 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
       }
       continue;
     }
+    // Row-major pass: thread -> (8-column group cg, rows r0 + k * NT / CG).  cg is the same for every item of a thread
+    // (NT % CG == 0), so bias / column mapping are per-thread constants, and the loop is fully unrolled so that the LDS
+    // reads and residual loads of all items are in flight together.
     constexpr int CG = BN_ / 8;
-    for (int it = tid; it < CR * CG; it += NT) {
-      const int cg = it % CG, r = it / CG;
-      const int row = mrow0 + r, col0 = n0 + cg * 8;
-      if (row >= M || col0 >= N) continue;
+    static_assert(NT % CG == 0 && (CR * CG) % NT == 0, "epilogue item mapping");
+    constexpr int RSTEP = NT / CG, ITERS = CR * CG / NT;
+    const int cg = tid % CG, r0 = tid / CG;
+    const int col0 = n0 + cg * 8;
+    if (col0 >= N) continue;
+    int dcol = col0, row_add = 0, bcol = col0;
+    if (e.map == LA_MAP_CONVT2X2) {
+      const int kyx = col0 / e.p2;
+      dcol = col0 % e.p2;
+      bcol = dcol;
+      row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+    }
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+      const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    const bool fast_gelu = sizeof(T) == 2 && !e.out32;      // result only survives as a 16-bit value
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+      const int r = r0 + k * RSTEP;
+      const int row = mrow0 + r;
+      if (row >= M) continue;
+      int drow = map_row(rm, row);
+      if (drow < 0) continue;
+      drow += row_add;
       float v[8];
       {
         const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8]);
         const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8 + 4]);
         v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
       }
-      int dcol = col0, row_add = 0, bcol = col0;
-      if (e.map == LA_MAP_CONVT2X2) {
-        const int kyx = col0 / e.p2;
-        dcol = col0 % e.p2;
-        bcol = dcol;
-        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+      float4 r0v = make_float4(0.f, 0.f, 0.f, 0.f), r1v = r0v;
+      if (e.res) {
+        const int rr = e.res_mod ? drow % e.res_mod : drow;
+        r0v = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
+        r1v = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
       }
-      if (e.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
-        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bv[j];
       if (e.act == LA_ACT_GELU) {
-        if (sizeof(T) == 2 && !e.out32) {      // result only survives as a 16-bit value
+        if (fast_gelu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
         } else {
@@ -297,15 +319,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      int drow = map_row(rm, row);
-      if (drow < 0) continue;
-      drow += row_add;
-      if (e.res) {
-        const int rr = e.res_mod ? drow % e.res_mod : drow;
-        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
-        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-      }
+      v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w; v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
       if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
       if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
     }
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
   int tm_, tn_;
-  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm & 255, tm_, tn_);
   const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
   const T* src[NDMA];
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK_;
+  const int nk = (gm & 256) ? 2 : K / BK_;          // debug: bit 8 = run only two k-steps (prologue + epilogue cost)
   const int fr = lane & 31, fh = lane >> 5;
   dma(0, 0);
   if (nk > 1) dma(1, 1);
@@ -514,6 +528,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
     stage = (stage == 2) ? 0 : stage + 1;
   }
   __syncthreads();
+  if (gm & 512) {                                   // debug: bit 9 = skip the epilogue (keep the accumulators alive)
+    if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
+    return;
+  }
   epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
 }
 
@@ -522,6 +540,8 @@ static int tile_group_m() {
   if (gm < 0) {
     const char* v = getenv("LA_GEMM_GROUP_M");
     gm = v ? atoi(v) : 8;
+    const char* d = getenv("LA_GEMM_DEBUG");        // bit 8: two k-steps only, bit 9: no epilogue (timing experiments)
+    if (d) gm |= atoi(d);
   }
   return gm;
 }
@@ -543,60 +563,93 @@ static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, 
 // =================================================================================================================
 // v6 "ping-pong": 256 x 256 x 64 tile, 8 waves = 2 groups of 4; group g owns rows [128 g, +128), wave i of a group the
 // columns [64 i, +64) -> 128 x 64 per wave (4 x 2 MFMA 32x32 accumulators).  Every SIMD hosts one wave of each group.
-// The K loop is cut into half-tiles ("bursts" of 2 MFMA k-steps = 16 MFMAs = 512 matrix-pipe cycles) and the two groups
-// run ONE BARRIER OUT OF PHASE: while group 0 issues the 16 MFMAs of a burst, group 1 fetches the fragments of its
-// next burst from LDS (12 ds_read_b128) and issues its share of the LDS-DMA for the next K tile, then they swap.
+// A k-step (64) is walked QUADRANT-major: the wave's tile is 2 x 2 quadrants of 64 x 32 and one burst = one quadrant
+// over the whole k-step (2 row tiles x 4 k-slices = 8 MFMAs = 256 matrix-pipe cycles); quadrant order (0,0) (0,1)
+// (1,1) (1,0) so that each burst loads only one new operand half.  The two groups run ONE BARRIER OUT OF PHASE: while
+// group 0 issues a burst, group 1 fetches fragments from LDS and issues its share of the LDS-DMA, then they swap.
 //
-//   interval      4t      4t+1    4t+2    4t+3    4t+4 ...        (one s_barrier between intervals)
-//   group 0    L(t,b0)  M(t,b0) L(t,b1) M(t,b1) L(t+1,b0)
-//   group 1    M(t-1,b1) L(t,b0) M(t,b0) L(t,b1) M(t,b1)
+//   interval      8t     8t+1    8t+2    8t+3    8t+4    8t+5    8t+6    8t+7        (one s_barrier between intervals)
+//   group 0       L1      M1      L2      M2      L3      M3      L4      M4
+//   group 1     M4(t-1)   L1      M1      L2      M2      L3      M3      L4
+//   L1: read A0,W0  L2: read W1  L3: read A1  L4: read W0        M1: q(0,0)  M2: q(0,1)  M3: q(1,1)  M4: q(1,0)
 //
-// LDS: 2 stages x (A 256x64 + W 256x64) x 2 B = 128 KiB, tile t in stage t & 1.  Hazards:
-//   * DMA(t+1) overwrites the stage of tile t-1, last read by group 1 in interval 4t-1; it is issued in L(t,b0)
-//     (interval 4t for group 0, 4t+1 for group 1) - after that read, separated by a barrier.
-//   * tile t+1 is first read in interval 4t+4; every wave drains its own DMA (s_waitcnt vmcnt(0)) before the barrier that
-//     closes interval 4t+3, i.e. 2-3 intervals (>= 1000 cycles) after issuing it.
+// LDS: 2 stages x (A 256x64 + W 256x64) x 2 B = 128 KiB, k-step t in stage t & 1; full 128-byte rows so every DMA piece
+// (8 rows) moves whole cache lines.  Rows are stored HALF-major: operand half h (the rows of quadrant index h of every
+// wave) is one contiguous 16 KiB "half-tile" = 16 DMA pieces = 2 per wave, and a half-tile is restaged as soon as its
+// last reader is done instead of waiting for the whole stage:
+//   L1 issues A1(t+1)   L2 issues W0(t+1)   L3 issues A0(t+2)   L4 issues W1(t+2)
+// Hazards (g1 runs one interval later than g0; reads are retired by the lgkmcnt(0) at the top of the following M):
+//   * WAR: each half-tile is restaged two L phases after the L phase that read it last (A0: L1 -> L3, W1: L2 -> L4,
+//     A1: L3 -> next L1, W0: L4 -> next L2), i.e. >= 1 full interval after the slower group's reads retired.
+//   * RAW: k-step t+1 is first read in interval 8t+8.  Every wave retires its own pieces of k-step t+1 with a COUNTED
+//     vmcnt before the barrier that closes interval 8t+7 (group 0 at the end of M4, group 1 in L4): only the younger
+//     A0(t+2), W1(t+2) may stay in flight -> vmcnt(4).
 // Operand traffic per MFMA: 0.75 KiB of fragment reads + 0.25 KiB of DMA (vs 1.0 + 0.5 in the 128x128 kernel) and half
 // the L2 reads per FLOP.
 // =================================================================================================================
 constexpr int PP_BM = 256, PP_BN = 256;
 constexpr int PP_STAGE = (PP_BM + PP_BN) * BK * 2;     // 64 KiB
+constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB half-tile
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
                                                           int M, int N, int K, LaGemmEpilogue e, int gm) {
-  constexpr int NW = 8, NT = 512;
-  constexpr int NDMA = (PP_BM + PP_BN) / 8 / NW;       // 8 wave-level DMA instructions (8 rows each) per K tile
+  constexpr int NT = 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wi = wave & 3;
   const int fr = lane & 31, fh = lane >> 5;
   const int ntn = (N + PP_BN - 1) / PP_BN, ntm = (M + PP_BM - 1) / PP_BM;
   int tm_, tn_;
-  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm & 255, tm_, tn_);
   const int m0 = tm_ * PP_BM, n0 = tn_ * PP_BN;
 
-  const T* src[NDMA];
-  int ldsoff[NDMA];
+  // DMA pieces of this wave: for half-tile (operand o, half h) the 8-row groups p = wave and wave + 8 of its 128 LDS rows.
+  // LDS row lr of A half h holds tile row (lr / 64) * 128 + h * 64 + lr % 64; of W half h tile column (lr / 32) * 64 +
+  // h * 32 + lr % 32.  The 16-byte chunk c of a row sits in slot c ^ ((lr >> 1) & 7) (conflict-free ds_read_b128).
+  const T* src[2][2][2];     // [operand][half][piece]
 #pragma unroll
-  for (int i = 0; i < NDMA; ++i) {
-    const int g8 = i * NW + wave;                    // 8-row group over [A rows | W rows]
-    const int trow = g8 * 8 + (lane >> 3);
-    const int slot = lane & 7;
-    if (g8 < PP_BM / 8) {
-      const int r = trow;
-      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
-    } else {
-      const int r = trow - PP_BM;
-      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave + 8 * i) * 8 + (lane >> 3);
+      const int slot = lane & 7;
+      const int ch = (slot ^ ((lr >> 1) & 7)) << 3;
+      const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63);
+      const int rw = (lr >> 5) * 64 + h * 32 + (lr & 31);
+      src[0][h][i] = A + (size_t)min(m0 + ra, M - 1) * lda + ch;
+      src[1][h][i] = Wt + (size_t)min(n0 + rw, N - 1) * ldw + ch;
     }
-    ldsoff[i] = g8 * 1024;
-  }
   const unsigned lds0 = lds_addr_of(smem);
-  auto dma = [&](int kt) {
-    const unsigned base = lds0 + (kt & 1) * PP_STAGE;
+  const bool dbg_nodma = gm & 1024, dbg_nolds = gm & 2048, dbg_nobar = gm & 4096;
+  const int nk = (gm & 256) ? 2 : K / BK;             // debug bit 8: two k-steps only
+  // half-tile (o, h) of k-step kt: stage kt & 1, operand o at + o * 32 KiB, half h at + h * 16 KiB
+  const bool dbg_saddr = gm & 8192, dbg_inm = gm & 16384;
+  unsigned soff[2][2][2];
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, base + ldsoff[i]);
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) soff[o][h][i] = (unsigned)((const char*)src[o][h][i] - (const char*)(o ? Wt : A));
+  auto dma_piece = [&](int kt, int o, int h, int i) {
+    if (kt >= nk) return;
+    const unsigned base = lds0 + (kt & 1) * PP_STAGE + o * (2 * PP_HALF) + h * PP_HALF + wave * 1024 + i * 8 * 1024;
+    if (dbg_saddr) {
+      const T* sb = (o ? Wt : A) + kt * BK;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(base);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(soff[o][h][i]), "s"(sb), "s"(dst)
+                   : "memory");
+    } else {
+      dma16(src[o][h][i] + kt * BK, base);
+    }
+  };
+  auto dma_ht = [&](int kt, int o, int h) {
+    dma_piece(kt, o, h, 0);
+    dma_piece(kt, o, h, 1);
   };
 
   f32x16 acc[4][2];
@@ -607,63 +660,102 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 af[2][4], wf[2][2];                           // fragments of one burst: [k-step][tile]
-  const int arow = grp * 128, wrow = wi * 64;
-  auto load_burst = [&](int kt, int b) {
-    const char* sa = smem + (kt & 1) * PP_STAGE;
-    const char* sw = sa + PP_BM * BK * 2;
+  uint4 af[4][2], wf[4];                              // fragments [k-slice][row tile] / [k-slice] of the current halves
+  const int wrow = wi * 64;                           // first tile column of this wave (epilogue)
+  auto load_a = [&](int kt, int h) {
+    const char* sa = smem + (kt & 1) * PP_STAGE + h * PP_HALF;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const int ch = (b * 2 + k2) * 2 + fh;
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[k2][j] = *reinterpret_cast<const uint4*>(sw + swz_off(wrow + j * 32 + fr, ch));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[k2][i] = *reinterpret_cast<const uint4*>(sa + swz_off(arow + i * 32 + fr, ch));
-    }
+      for (int i = 0; i < 2; ++i) af[ks][i] = *reinterpret_cast<const uint4*>(sa + swz_off(grp * 64 + i * 32 + fr, ks * 2 + fh));
   };
-  auto mma_burst = [&]() {
-    __builtin_amdgcn_s_setprio(1);
+  auto load_w = [&](int kt, int h) {
+    const char* sw = smem + (kt & 1) * PP_STAGE + 2 * PP_HALF + h * PP_HALF;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[k2][i], wf[k2][j], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(sw + swz_off(wi * 32 + fr, ks * 2 + fh));
   };
   auto bar = [&]() {
-    __builtin_amdgcn_s_barrier();
+    if (!dbg_nobar) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+#define LA_PP_BURST(HA, HB, KD, O, H)                                                                \
+  do {                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
+      acc[2 * HA][HB] = Half16<T>::mfma32(af[ks][0], wf[ks], acc[2 * HA][HB]);                       \
+      acc[2 * HA + 1][HB] = Half16<T>::mfma32(af[ks][1], wf[ks], acc[2 * HA + 1][HB]);               \
+      if (dbg_inm && (ks == 0 || ks == 2)) {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        dma_piece(KD, O, H, ks >> 1);                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+    }                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
 
-  const int nk = K / BK;
-  dma(0);
-  dma_wait<0>();
-  bar();                                   // tile 0 resident
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+  // prologue: all of k-step 0, then A0(1), W1(1) (what L3/L4 of a "k-step -1" would have issued)
+  dma_ht(0, 0, 0);
+  dma_ht(0, 1, 0);
+  dma_ht(0, 0, 1);
+  dma_ht(0, 1, 1);
+  dma_ht(1, 0, 0);
+  dma_ht(1, 1, 1);
+  if (nk > 1) dma_wait<4>();
+  else dma_wait<0>();
+  bar();                                   // k-step 0 resident
   if (grp == 1) bar();                     // group 1 runs one interval behind
   for (int kt = 0; kt < nk; ++kt) {
-    // ---- L(kt, b0): fragments of burst 0 + this wave's share of the next tile's DMA ----------------------------
-    if (kt + 1 < nk) dma(kt + 1);
-    load_burst(kt, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    // ---- L1 / M1: quadrant (0,0) -------------------------------------------------------------------------------------
+    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 1, 0, 1);
+    if (!dbg_nolds || kt == 0) {
+      load_w(kt, 0);
+      load_a(kt, 0);
+    }
     bar();
-    // ---- M(kt, b0) ---------------------------------------------------------------------------------------------------
-    mma_burst();
+    LA_PP_BURST(0, 0, kt + 1, 0, 1);
     bar();
-    // ---- L(kt, b1) ---------------------------------------------------------------------------------------------------
-    load_burst(kt, 1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    if (grp == 1) dma_wait<0>();           // closes global interval 4 kt + 3 for group 1
+    // ---- L2 / M2: quadrant (0,1) -------------------------------------------------------------------------------------
+    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 1, 1, 0);
+    if (!dbg_nolds) load_w(kt, 1);
     bar();
-    // ---- M(kt, b1) ---------------------------------------------------------------------------------------------------
-    mma_burst();
-    if (grp == 0) dma_wait<0>();           // closes global interval 4 kt + 3 for group 0
+    LA_PP_BURST(0, 1, kt + 1, 1, 0);
+    bar();
+    // ---- L3 / M3: quadrant (1,1) -------------------------------------------------------------------------------------
+    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 2, 0, 0);
+    if (!dbg_nolds) load_a(kt, 1);
+    bar();
+    LA_PP_BURST(1, 1, kt + 2, 0, 0);
+    bar();
+    // ---- L4 / M4: quadrant (1,0) -------------------------------------------------------------------------------------
+    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 2, 1, 1);
+    if (!dbg_nolds) load_w(kt, 0);
+    if (grp == 1) {                        // group 1 closes interval 8 kt + 7 here: k-step kt+1 must be complete
+      if (kt + 2 < nk) {
+        if (dbg_inm) dma_wait<2>();
+        else dma_wait<4>();
+      } else dma_wait<0>();
+    }
+    bar();
+    LA_PP_BURST(1, 0, kt + 2, 1, 1);
+    if (grp == 0) {
+      if (kt + 2 < nk) dma_wait<4>();
+      else dma_wait<0>();
+    }
     bar();
   }
+#undef LA_PP_BURST
   if (grp == 0) bar();                     // re-align the two groups
   __syncthreads();
+  if (gm & 512) {                          // debug bit 9: no epilogue
+    if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
+    if ((gm & 32768) && blockIdx.x == 5 && tid == 0)
+      printf("pp main loop: %llu cycles for %d k-steps\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start), nk);
+    return;
+  }
 
   // ---- epilogue: four 64-row chunks staged through LDS (each wave's 128 rows span two chunks) -----------------------
   float* epi = reinterpret_cast<float*>(smem);
