@@ -197,7 +197,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
 
 template <typename T, int TI, int TJ, int BN_, int NT, int CR = 128>
 __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI][TJ], int nchunks, int my_chunk, int wrow0, int wcol0,
-                                             int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid) {
+                                             int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid, int dbg = 0) {
   constexpr int LD = BN_ + 4;
   const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
   const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
@@ -207,7 +207,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
 #pragma unroll 1
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk > 0) __syncthreads();
-    if (my_chunk == chunk) {
+    if (my_chunk == chunk && !(dbg & 2048)) {
       if (!vt_tile) {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -320,6 +320,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w; v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
+      if ((dbg & 1024) && v[0] != 123.25f) continue;       // timing experiment: no global stores
       if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
       if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
     }
@@ -397,26 +398,29 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
   const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
   // ---- DMA plan: instruction i of this wave moves 8 tile rows (1 KiB); lane -> (row lane/8, slot lane%8) --------
-  const T* src[NDMA];
+  // source = wave-uniform base (A or W, advanced by the k-tile) + 32-bit per-lane byte offset (launcher checks < 4 GiB)
+  constexpr int NA = BM_ / 8 / NW;                 // pieces i < NA are A rows, the rest W rows
+  static_assert((BM_ / 8) % NW == 0, "A / W pieces must split per instruction index");
+  unsigned soff[NDMA];
   int ldsoff[NDMA];
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int grp = i * NW + wave;                 // row group index over [A rows | W rows]
     const int trow = grp * 8 + (lane >> 3);        // tile row in the concatenated (BM_ + BN) row space
     const int slot = lane & 7;
-    if (grp < BM_ / 8) {
+    if (i < NA) {
       const int r = trow;
-      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3);
+      soff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3)) * sizeof(T));
     } else {
       const int r = trow - BM_;
-      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3);
+      soff[i] = (unsigned)(((size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3)) * sizeof(T));
     }
     ldsoff[i] = grp * 1024;                        // A tile occupies [0, BM_*128), W tile follows: same linear space
   }
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK, lds0 + stage * STAGE + ldsoff[i]);
+    for (int i = 0; i < NDMA; ++i) dma16s((i < NA ? A : Wt) + kt * BK, soff[i], lds0 + stage * STAGE + ldsoff[i]);
   };
 
   f32x16 acc[2][2];
@@ -470,26 +474,27 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm & 255, tm_, tn_);
   const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
-  const T* src[NDMA];
+  constexpr int NA = BM_ / 16 / NW;                // pieces i < NA are A rows, the rest W rows
+  unsigned soff[NDMA];                             // 32-bit byte offsets from A / W (launcher checks < 4 GiB)
   int ldsoff[NDMA];
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
     const int grp = i * NW + wave;                 // 16-row group over [A rows | W rows]
     const int trow = grp * 16 + (lane >> 2);
     const int slot = lane & 3;
-    if (grp < BM_ / 16) {
+    if (i < NA) {
       const int r = trow;
-      src[i] = A + (size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 2) & 3)) << 3);
+      soff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 2) & 3)) << 3)) * sizeof(T));
     } else {
       const int r = trow - BM_;
-      src[i] = Wt + (size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 2) & 3)) << 3);
+      soff[i] = (unsigned)(((size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 2) & 3)) << 3)) * sizeof(T));
     }
     ldsoff[i] = grp * 1024;
   }
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16(src[i] + kt * BK_, lds0 + stage * STAGE + ldsoff[i]);
+    for (int i = 0; i < NDMA; ++i) dma16s((i < NA ? A : Wt) + kt * BK_, soff[i], lds0 + stage * STAGE + ldsoff[i]);
   };
 
   f32x16 acc[4][2];
@@ -502,6 +507,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
 
   const int nk = (gm & 256) ? 2 : K / BK_;          // debug: bit 8 = run only two k-steps (prologue + epilogue cost)
   const int fr = lane & 31, fh = lane >> 5;
+  if ((gm & 4096) && blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+    for (int i = 0; i < (K >> 6); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  if ((gm & 8192) && blockIdx.x < 512 && (blockIdx.x & 1)) {
+#pragma unroll 1
+    for (int i = 0; i < (K >> 6); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   dma(0, 0);
   if (nk > 1) dma(1, 1);
   int stage = 0;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
     if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
     return;
   }
-  epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
+  epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid, gm);
 }
 
 static int tile_group_m() {
@@ -638,6 +651,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
     if (dbg_saddr) {
       const T* sb = (o ? Wt : A) + kt * BK;
       const unsigned dst = __builtin_amdgcn_readfirstlane(base);
+      if ((gm & 65536) && i == 1) {          // timing experiment: second piece re-uses M0 (lands on the first piece)
+        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(soff[o][h][i]), "s"(sb) : "memory");
+        return;
+      }
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   do {                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    __builtin_amdgcn_s_setprio(1);                                                                   \
+    if (!(gm & 131072)) __builtin_amdgcn_s_setprio(1);                                               \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
       acc[2 * HA][HB] = Half16<T>::mfma32(af[ks][0], wf[ks], acc[2 * HA][HB]);                       \
       acc[2 * HA + 1][HB] = Half16<T>::mfma32(af[ks][1], wf[ks], acc[2 * HA + 1][HB]);               \
@@ -696,7 +713,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
     __builtin_amdgcn_sched_barrier(0);                                                               \
   } while (0)
 
-  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
   // prologue: all of k-step 0, then A0(1), W1(1) (what L3/L4 of a "k-step -1" would have issued)
   dma_ht(0, 0, 0);
   dma_ht(0, 1, 0);
@@ -752,12 +768,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   __syncthreads();
   if (gm & 512) {                          // debug bit 9: no epilogue
     if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
-    if ((gm & 32768) && blockIdx.x == 5 && tid == 0)
-      printf("pp main loop: %llu cycles for %d k-steps\n", (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start), nk);
     return;
   }
 
   // ---- epilogue: four 64-row chunks staged through LDS (each wave's 128 rows span two chunks) -----------------------
+  const int dbg = gm;
   float* epi = reinterpret_cast<float*>(smem);
   constexpr int LD = PP_BN + 4;
   const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
@@ -863,6 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
         const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
       }
+      if ((dbg & 1024) && v[0] != 123.25f) continue;       // timing experiment: no global stores
       if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
       if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
     }
@@ -895,9 +911,10 @@ static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, i
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
 }
 
-static bool fast_ok(const void* A, int lda, const void* W, int ldw, int N, int K, const LaGemmEpilogue& e) {
+static bool fast_ok(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   if ((K % 64) != 0) return false;
+  if ((size_t)M * lda * 2 >= (1ull << 32) || (size_t)N * ldw * 2 >= (1ull << 32)) return false;   // 32-bit DMA offsets
   if (!al16(A) || !al16(W)) return false;
   return epi_vec_ok(N, e, 2);
 }
@@ -1207,7 +1224,7 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     return 0;
   }
   static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128)
-  bool fast = la::fast_ok(A, lda, W, ldw, N, K, *epi) && !(force && force[0] == 'v');
+  bool fast = la::fast_ok(A, lda, W, ldw, M, N, K, *epi) && !(force && force[0] == 'v');
   if (fast) {
     // measured on MI355X (profiles/r01_gemm_variants.log): the 256x128 / 128x64-per-wave kernel wins by ~5 % on the short-K
     // (K = 768) shapes once there are >= 2 full waves of tiles; the 128x128 kernel wins on long K and small grids.

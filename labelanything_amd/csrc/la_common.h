@@ -108,6 +108,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_uniform
                : "v"(gsrc), "s"(dst)
                : "memory");
 }
+// Same, with the source as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: one address VGPR instead of
+// two and no 64-bit VALU add per piece.
+__device__ __forceinline__ void dma16s(const void* gbase_uniform, unsigned voff, unsigned lds_dst_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gbase_uniform), "s"(dst)
+               : "memory");
+}
 template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // XCD-aware tile order: consecutive workgroups round-robin over the 8 XCDs, so give each XCD a
