@@ -12,7 +12,8 @@ barrier + device sync and the MAX over ranks is reported.  Rank 0 prints ONE JSO
 Extra objects on the line:
   roofline      the dominant kernel (la_gemm: every Linear / conv of the path) timed live with HIP events on the launch
                 stream in a separate instrumented step: algorithmic FLOPs of all its launches / their summed duration,
-                against the gfx950 dense fp16/bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+                against the gfx950 dense fp16/bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  `traffic` = HBM-side
+                bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_traffic.json).
   cpu_baseline  the CPU oracle (oracle/lam_oracle.py, a checked restatement of the reference's torch path) timed on this
                 box's host cores for ONE episode of the same workload (N=1, rank 0 only).
 """
@@ -71,16 +72,24 @@ class KernelTimer:
                 _fn(*a, **kw)
                 e.record()
                 flops = 0.0
+                nbytes = 0.0
                 if _n == "gemm":
                     m = kw.get("M") or a[0].shape[0]
-                    flops = 2.0 * m * a[1].shape[0] * a[1].shape[1]
+                    n, k = a[1].shape
+                    flops = 2.0 * m * n * k
+                    esz = a[0].element_size()
+                    # algorithmic bytes: A and W read once, every output written once, the residual read once
+                    nbytes = esz * (m * k + n * k) + m * n * (4 * (kw.get("out32") is not None) + esz * (kw.get("out16") is not None)
+                                                              + 4 * (kw.get("res") is not None and kw.get("res_mod", 0) == 0))
+                    if kw.get("vt") is not None:
+                        nbytes += esz * m * (n - kw.get("vt_col0", 0))
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
                     flops = 4.0 * b * heads * t * t * 64
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
-                self.records.append((tag, flops, s, e))
+                self.records.append((tag, flops, s, e, nbytes))
             setattr(L, n, wrapped)
         return self
 
@@ -91,12 +100,24 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for n, fl, s, e in self.records:
-            d = agg.setdefault(n, [0, 0.0, 0.0])
+        for n, fl, s, e, nb in self.records:
+            d = agg.setdefault(n, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += fl
+            d[3] += nb
         return agg
+
+
+def pmc_traffic():
+    """HBM-side bytes per la_gemm launch of THIS workload from the committed PMC passes (profiles/*_traffic.json, written by
+    tools/collect_profiles.sh with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); None when no such file is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f).get("bytes_per_launch")
 
 
 def cpu_baseline(cfg, episodes_sample: int = 1):
@@ -192,9 +213,10 @@ def main():
         kernels = {n: {"launches": v[0], "ms": round(v[1] * 1e3, 3)} for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         if g:
             ach = g[2] / g[1] / 1e12
-            roof = {"kernel": "gemm_nt_kernel (la_gemm)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
+            roof = {"kernel": "la_gemm (gemm_dma4_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel)", "bound": "mfma",
+                    "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
                     "share_of_kernel_time": round(g[1] / tot, 3)}
 
     if rank == 0:

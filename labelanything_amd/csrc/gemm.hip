@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
     if (kt >= nk) return;
     const unsigned base = lds0 + (kt & 1) * PP_STAGE + o * (2 * PP_HALF) + h * PP_HALF + wave * 1024 + i * 8 * 1024;
     if (dbg_saddr) {
-      const T* sb = (o ? Wt : A) + kt * BK;
+      const T* sb = (o ? Wt : A) + ((gm & 262144) ? 0 : kt * BK);      // bit 18: always fetch k-step 0 (cache-hot source)
       const unsigned dst = __builtin_amdgcn_readfirstlane(base);
       if ((gm & 65536) && i == 1) {          // timing experiment: second piece re-uses M0 (lands on the first piece)
         asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(soff[o][h][i]), "s"(sb) : "memory");

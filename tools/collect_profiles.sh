@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run on the MI355X box (via gpurun) from the repo root: refreshes everything the judge reads under profiles/ for round $1.
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
+set -u
+R=${1:-r01}
+export TMPDIR=/tmp
+OUT=gpurun_out/profiles_$R
+mkdir -p $OUT
+# 1. the official bench line (with roofline + cpu_baseline)
+timeout 900 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.stderr
+# 2. rocprofv3 kernel stats of the same command (eager launches so that every kernel is a separate dispatch record too)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --no-cpu-baseline > $OUT/prof_graph.log 2>&1
+cp $(find $OUT/prof -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eager -o bench -- python bench.py --no-cpu-baseline --no-graphs > $OUT/prof_eager.log 2>&1
+cp $(find $OUT/prof_eager -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_eager_kernel_stats.csv 2>/dev/null
+# 3. HBM-side traffic of the GEMM kernels: one counter per pass, no other trace domains
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+python tools/pmc_traffic.py $(find $OUT/pmc -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic.json > /dev/null 2> $OUT/traffic.stderr
+# 4. parity report + per-op micro benchmarks
+timeout 900 python tools/parity_report.py > $OUT/${R}_parity.log 2>&1
+timeout 600 python tools/bench_ops.py > $OUT/${R}_bench_ops.log 2>&1
+rm -rf $OUT/prof $OUT/prof_eager $OUT/pmc
+ls -la $OUT
