@@ -197,7 +197,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
 
 template <typename T, int TI, int TJ, int BN_, int NT, int CR = 128>
 __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI][TJ], int nchunks, int my_chunk, int wrow0, int wcol0,
-                                             int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid, int dbg = 0) {
+                                             int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid) {
   constexpr int LD = BN_ + 4;
   const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
   const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
@@ -207,7 +207,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
 #pragma unroll 1
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     if (chunk > 0) __syncthreads();
-    if (my_chunk == chunk && !(dbg & 2048)) {
+    if (my_chunk == chunk) {
       if (!vt_tile) {
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
@@ -320,7 +320,6 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
       v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w; v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
-      if ((dbg & 1024) && v[0] != 123.25f) continue;       // timing experiment: no global stores
       if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
       if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
     }
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   const int wm = wave >> 1, wn = wave & 1;
   const int ntn = (N + BN - 1) / BN, ntm = (M + BM_ - 1) / BM_;
   int tm_, tn_;
-  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm & 255, tm_, tn_);
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
   const int m0 = tm_ * BM_, n0 = tn_ * BN;
 
   constexpr int NA = BM_ / 16 / NW;                // pieces i < NA are A rows, the rest W rows
@@ -505,16 +504,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (gm & 256) ? 2 : K / BK_;          // debug: bit 8 = run only two k-steps (prologue + epilogue cost)
+  const int nk = K / BK_;
   const int fr = lane & 31, fh = lane >> 5;
-  if ((gm & 4096) && blockIdx.x >= 256 && blockIdx.x < 512) {
-#pragma unroll 1
-    for (int i = 0; i < (K >> 6); ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  if ((gm & 8192) && blockIdx.x < 512 && (blockIdx.x & 1)) {
-#pragma unroll 1
-    for (int i = 0; i < (K >> 6); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   dma(0, 0);
   if (nk > 1) dma(1, 1);
   int stage = 0;
@@ -541,11 +532,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
     stage = (stage == 2) ? 0 : stage + 1;
   }
   __syncthreads();
-  if (gm & 512) {                                   // debug: bit 9 = skip the epilogue (keep the accumulators alive)
-    if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
-    return;
-  }
-  epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid, gm);
+  epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
 }
 
 static int tile_group_m() {
@@ -553,8 +540,6 @@ static int tile_group_m() {
   if (gm < 0) {
     const char* v = getenv("LA_GEMM_GROUP_M");
     gm = v ? atoi(v) : 8;
-    const char* d = getenv("LA_GEMM_DEBUG");        // bit 8: two k-steps only, bit 9: no epilogue (timing experiments)
-    if (d) gm |= atoi(d);
   }
   return gm;
 }
@@ -614,13 +599,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   const int fr = lane & 31, fh = lane >> 5;
   const int ntn = (N + PP_BN - 1) / PP_BN, ntm = (M + PP_BM - 1) / PP_BM;
   int tm_, tn_;
-  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm & 255, tm_, tn_);
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
   const int m0 = tm_ * PP_BM, n0 = tn_ * PP_BN;
 
   // DMA pieces of this wave: for half-tile (operand o, half h) the 8-row groups p = wave and wave + 8 of its 128 LDS rows.
   // LDS row lr of A half h holds tile row (lr / 64) * 128 + h * 64 + lr % 64; of W half h tile column (lr / 32) * 64 +
   // h * 32 + lr % 32.  The 16-byte chunk c of a row sits in slot c ^ ((lr >> 1) & 7) (conflict-free ds_read_b128).
-  const T* src[2][2][2];     // [operand][half][piece]
+  unsigned soff[2][2][2];    // [operand][half][piece] byte offsets from A / W (launcher checks < 4 GiB)
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -630,43 +615,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
       const int ch = (slot ^ ((lr >> 1) & 7)) << 3;
       const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63);
       const int rw = (lr >> 5) * 64 + h * 32 + (lr & 31);
-      src[0][h][i] = A + (size_t)min(m0 + ra, M - 1) * lda + ch;
-      src[1][h][i] = Wt + (size_t)min(n0 + rw, N - 1) * ldw + ch;
+      soff[0][h][i] = (unsigned)(((size_t)min(m0 + ra, M - 1) * lda + ch) * sizeof(T));
+      soff[1][h][i] = (unsigned)(((size_t)min(n0 + rw, N - 1) * ldw + ch) * sizeof(T));
     }
   const unsigned lds0 = lds_addr_of(smem);
-  const bool dbg_nodma = gm & 1024, dbg_nolds = gm & 2048, dbg_nobar = gm & 4096;
-  const int nk = (gm & 256) ? 2 : K / BK;             // debug bit 8: two k-steps only
-  // half-tile (o, h) of k-step kt: stage kt & 1, operand o at + o * 32 KiB, half h at + h * 16 KiB
-  const bool dbg_saddr = gm & 8192, dbg_inm = gm & 16384;
-  unsigned soff[2][2][2];
-#pragma unroll
-  for (int o = 0; o < 2; ++o)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) soff[o][h][i] = (unsigned)((const char*)src[o][h][i] - (const char*)(o ? Wt : A));
-  auto dma_piece = [&](int kt, int o, int h, int i) {
-    if (kt >= nk) return;
-    const unsigned base = lds0 + (kt & 1) * PP_STAGE + o * (2 * PP_HALF) + h * PP_HALF + wave * 1024 + i * 8 * 1024;
-    if (dbg_saddr) {
-      const T* sb = (o ? Wt : A) + ((gm & 262144) ? 0 : kt * BK);      // bit 18: always fetch k-step 0 (cache-hot source)
-      const unsigned dst = __builtin_amdgcn_readfirstlane(base);
-      if ((gm & 65536) && i == 1) {          // timing experiment: second piece re-uses M0 (lands on the first piece)
-        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(soff[o][h][i]), "s"(sb) : "memory");
-        return;
-      }
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(soff[o][h][i]), "s"(sb), "s"(dst)
-                   : "memory");
-    } else {
-      dma16(src[o][h][i] + kt * BK, base);
-    }
-  };
+  const int nk = K / BK;
+  // half-tile (o, h) of k-step kt: stage kt & 1, operand o at + o * 32 KiB, half h at + h * 16 KiB; this wave's pieces at
+  // + wave KiB and + (8 + wave) KiB.  Source = wave-uniform base advanced by the k-step + 32-bit lane offset.
   auto dma_ht = [&](int kt, int o, int h) {
-    dma_piece(kt, o, h, 0);
-    dma_piece(kt, o, h, 1);
+    if (kt >= nk) return;
+    const unsigned base = lds0 + (kt & 1) * PP_STAGE + o * (2 * PP_HALF) + h * PP_HALF + wave * 1024;
+    const T* sb = (o ? Wt : A) + kt * BK;
+    dma16s(sb, soff[o][h][0], base);
+    dma16s(sb, soff[o][h][1], base + 8 * 1024);
   };
 
   f32x16 acc[4][2];
@@ -692,22 +653,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
     for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(sw + swz_off(wi * 32 + fr, ks * 2 + fh));
   };
   auto bar = [&]() {
-    if (!dbg_nobar) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-#define LA_PP_BURST(HA, HB, KD, O, H)                                                                \
+#define LA_PP_BURST(HA, HB)                                                                \
   do {                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    if (!(gm & 131072)) __builtin_amdgcn_s_setprio(1);                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
       acc[2 * HA][HB] = Half16<T>::mfma32(af[ks][0], wf[ks], acc[2 * HA][HB]);                       \
       acc[2 * HA + 1][HB] = Half16<T>::mfma32(af[ks][1], wf[ks], acc[2 * HA + 1][HB]);               \
-      if (dbg_inm && (ks == 0 || ks == 2)) {                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-        dma_piece(KD, O, H, ks >> 1);                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-      }                                                                                              \
     }                                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                               \
@@ -726,37 +682,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   if (grp == 1) bar();                     // group 1 runs one interval behind
   for (int kt = 0; kt < nk; ++kt) {
     // ---- L1 / M1: quadrant (0,0) -------------------------------------------------------------------------------------
-    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 1, 0, 1);
-    if (!dbg_nolds || kt == 0) {
-      load_w(kt, 0);
-      load_a(kt, 0);
-    }
+    dma_ht(kt + 1, 0, 1);
+    load_w(kt, 0);
+    load_a(kt, 0);
     bar();
-    LA_PP_BURST(0, 0, kt + 1, 0, 1);
+    LA_PP_BURST(0, 0);
     bar();
     // ---- L2 / M2: quadrant (0,1) -------------------------------------------------------------------------------------
-    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 1, 1, 0);
-    if (!dbg_nolds) load_w(kt, 1);
+    dma_ht(kt + 1, 1, 0);
+    load_w(kt, 1);
     bar();
-    LA_PP_BURST(0, 1, kt + 1, 1, 0);
+    LA_PP_BURST(0, 1);
     bar();
     // ---- L3 / M3: quadrant (1,1) -------------------------------------------------------------------------------------
-    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 2, 0, 0);
-    if (!dbg_nolds) load_a(kt, 1);
+    dma_ht(kt + 2, 0, 0);
+    load_a(kt, 1);
     bar();
-    LA_PP_BURST(1, 1, kt + 2, 0, 0);
+    LA_PP_BURST(1, 1);
     bar();
     // ---- L4 / M4: quadrant (1,0) -------------------------------------------------------------------------------------
-    if (!dbg_nodma && !dbg_inm) dma_ht(kt + 2, 1, 1);
-    if (!dbg_nolds) load_w(kt, 0);
+    dma_ht(kt + 2, 1, 1);
+    load_w(kt, 0);
     if (grp == 1) {                        // group 1 closes interval 8 kt + 7 here: k-step kt+1 must be complete
-      if (kt + 2 < nk) {
-        if (dbg_inm) dma_wait<2>();
-        else dma_wait<4>();
-      } else dma_wait<0>();
+      if (kt + 2 < nk) dma_wait<4>();
+      else dma_wait<0>();
     }
     bar();
-    LA_PP_BURST(1, 0, kt + 2, 1, 1);
+    LA_PP_BURST(1, 0);
     if (grp == 0) {
       if (kt + 2 < nk) dma_wait<4>();
       else dma_wait<0>();
@@ -766,13 +718,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
 #undef LA_PP_BURST
   if (grp == 0) bar();                     // re-align the two groups
   __syncthreads();
-  if (gm & 512) {                          // debug bit 9: no epilogue
-    if (acc[0][0][0] == 123.456f) e.out32[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
-    return;
-  }
 
   // ---- epilogue: four 64-row chunks staged through LDS (each wave's 128 rows span two chunks) -----------------------
-  const int dbg = gm;
   float* epi = reinterpret_cast<float*>(smem);
   constexpr int LD = PP_BN + 4;
   const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
@@ -878,7 +825,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
         const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
       }
-      if ((dbg & 1024) && v[0] != 123.25f) continue;       // timing experiment: no global stores
       if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
       if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
     }
@@ -1223,7 +1169,7 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     LA_CHECK_LAUNCH("la_gemm");
     return 0;
   }
-  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128)
+  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128), "6" (256x256)
   bool fast = la::fast_ok(A, lda, W, ldw, M, N, K, *epi) && !(force && force[0] == 'v');
   if (fast) {
     // measured on MI355X (profiles/r01_gemm_variants.log): the 256x128 / 128x64-per-wave kernel wins by ~5 % on the short-K
@@ -1232,7 +1178,11 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     bool v4 = (K <= 1024) && (tiles256 >= 512);
     if (force && force[0] == '4') v4 = true;
     if (force && force[0] == '2') v4 = false;
-    const bool pp = (force && force[0] == '6') && (!epi->vt || (epi->vt_col0 % la::PP_BN) == 0);
+    // long-K shapes with >= 2 full waves of 256 x 256 tiles: the ping-pong kernel (+15 % on 65536x768x3072)
+    const long tiles_pp = (long)((M + la::PP_BM - 1) / la::PP_BM) * ((N + la::PP_BN - 1) / la::PP_BN);
+    bool pp = (K >= 2048) && (tiles_pp >= 512);
+    if (force) pp = force[0] == '6';
+    pp = pp && (!epi->vt || (epi->vt_col0 % la::PP_BN) == 0);
     if (pp) {
       if (dt == LA_F16) la::launch_pp<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
       else la::launch_pp<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
