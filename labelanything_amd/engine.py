@@ -226,8 +226,19 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     # SAM ViTDet encoder (image_encoder.py:110-131,179-197,200-255)
     # ------------------------------------------------------------------------------------------------
+    def _check_encoder_input(self, images: Tensor) -> None:
+        spec: EncoderSpec = self.cfg.encoder_spec
+        if spec.head_dim != 64:
+            # la_attn_fwd is specialised for 64-wide heads (SAM ViT-B/L, every HF ViT here); SAM ViT-H has 80
+            raise NotImplementedError(f"encoder attention is built for head_dim 64 only (this encoder has {spec.head_dim}); "
+                                      "feed precomputed embeddings instead")
+        if images.shape[-1] % spec.patch or self.cfg.vit_patch_size != spec.patch:
+            raise ValueError(f"image side {images.shape[-1]} / vit_patch_size {self.cfg.vit_patch_size} do not match the "
+                             f"encoder's {spec.patch}x{spec.patch} patches")
+
     def sam_encoder(self, images: Tensor, want_last_block: bool = False):
         spec: EncoderSpec = self.cfg.encoder_spec
+        self._check_encoder_input(images)
         pre = "image_encoder"
         bn, _, s, _ = images.shape
         if s != spec.img_size:
@@ -317,6 +328,7 @@ class LamEngine:
 
     def hf_encoder(self, images: Tensor):
         spec: EncoderSpec = self.cfg.encoder_spec
+        self._check_encoder_input(images)
         pre = "image_encoder"
         bn, _, s, _ = images.shape
         e, heads, g = spec.dim, spec.heads, s // spec.patch
@@ -364,6 +376,7 @@ class LamEngine:
         spec = self.cfg.encoder_spec
         if spec is None:
             raise ValueError("this model was built without an image encoder (use_vit=False)")
+
         if spec.kind == "sam":
             out32, out16, c = self.sam_encoder(images)
         else:

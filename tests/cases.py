@@ -12,6 +12,10 @@ from oracle.lam_oracle import LamGeometry
 register_encoder("sam_tiny", EncoderSpec("sam", dim=128, depth=2, heads=2, mlp=512, img_size=224,
                                          global_idx=(1,), window=8, out_chans=96))
 register_encoder("hf_tiny", EncoderSpec("hf", dim=128, depth=2, heads=2, mlp=512, img_size=224))
+# 8x8 patches (facebook/dino-vitb8 style) and a wide SAM stack (ViT-L style: 1024 wide, 16 heads, 14x14 windows)
+register_encoder("hf_tiny_p8", EncoderSpec("hf", dim=128, depth=2, heads=2, mlp=512, patch=8, img_size=224))
+register_encoder("sam_wide", EncoderSpec("sam", dim=1024, depth=2, heads=16, mlp=4096, img_size=448,
+                                         global_idx=(1,), window=14, out_chans=256))
 
 
 def geometry_for(cfg: LamConfig) -> LamGeometry:

@@ -179,3 +179,43 @@ def test_many_pairs_5way_5shot_matches_oracle():
     assert out["logits"].shape == (1, 6, 240, 240)
     assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
     assert rel_err(out["logits"], ref["logits"]) < 4e-3
+
+
+def _encoder_vs_oracle(cfg, bn, seed):
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(bn, 3, cfg.image_size, cfg.image_size, generator=g)
+    lam = Lam(cfg, seed=seed).cuda()
+    got = lam.image_encoder(images.cuda()).float().cpu()
+    sd, geo = init_state_dict(cfg, seed), geometry_for(cfg)
+    with torch.no_grad():
+        ref = O.sam_encoder(sd, geo, images) if cfg.encoder_spec.kind == "sam" else O.hf_vit_encoder(sd, geo, images)
+    assert got.shape == ref.shape
+    return rel_err(got, ref)
+
+
+def test_patch8_hf_encoder_matches_oracle():
+    """facebook/dino-vitb8 geometry class (build_encoder.py:115-117): 8x8 patches, pos grid 28 resampled to 20."""
+    from labelanything_amd.config import LamConfig
+    cfg = LamConfig(encoder="hf_tiny_p8", image_size=160, vit_patch_size=8, image_embed_dim=128, embed_dim=64, spatial_convs=3,
+                    custom_preprocess=False)
+    assert _encoder_vs_oracle(cfg, 3, 21) < 2e-3
+
+
+def test_wide_sam_encoder_matches_oracle():
+    """SAM ViT-L width (1024 channels, 16 heads of 64, 14x14 windows on a 28x28 grid, padded) through the same kernels."""
+    from labelanything_amd.config import LamConfig
+    cfg = LamConfig(encoder="sam_wide", image_size=448, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False)
+    assert _encoder_vs_oracle(cfg, 2, 22) < 2e-3
+
+
+def test_head_dim_80_is_rejected_loudly():
+    """SAM ViT-H (head_dim 80) attention is not built: the encoder must refuse instead of computing garbage."""
+    from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
+    register_encoder("sam_hd80", EncoderSpec("sam", dim=160, depth=1, heads=2, mlp=320, img_size=224, global_idx=(0,), window=14, out_chans=64))
+    cfg = LamConfig(encoder="sam_hd80", image_size=224, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+    lam = Lam(cfg, seed=1).cuda()
+    with pytest.raises(NotImplementedError, match="head_dim 64"):
+        lam.image_encoder(torch.randn(1, 3, 224, 224).cuda())
