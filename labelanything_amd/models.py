@@ -201,6 +201,11 @@ class Lam(nn.Module):
             g = h
             x = emb.reshape(b * n, c, h * w).contiguous()
             need_neck = cfg.lam_neck and apply_neck_to_embeddings
+            if not need_neck and c != cfg.embed_dim:
+                # lam.py:193-213: prepare_embeddings (generate_class_embeddings / predict) passes cached embeddings
+                # through WITHOUT the neck - they must already be embed_dim wide
+                raise ValueError(f"embeddings have {c} channels but this path feeds them to the {cfg.embed_dim}-wide decoder "
+                                 "without the neck (reference lam.py:193-213); pass post-neck embeddings or use forward()")
             e32 = eng.f32("in.emb32", (b * n * h * w, c))
             e16 = eng.buf("in.emb16", (b * n * h * w, c)) if need_neck else None
             L.nchw_to_nhwc(x, b * n, c, h * w, out32=e32, out16=e16, dt=eng.dti)

@@ -73,3 +73,61 @@ def test_generate_embeddings_huggingface_dir(tmp_path):
     got = load_file(os.path.join(out, "000000000000.safetensors"))["embedding"]
     assert got.shape == (128, 15, 15)
     assert rel_err(got, ref[0]) < 3e-3
+
+
+def test_embedding_cache_round_trip_and_prototype_serving(tmp_path):
+    """generate_embeddings -> files -> load_episode_embeddings -> Lam(embeddings) equals Lam(images) on the same pictures
+    (data/coco.py:251-275 wire format), and set_class_embeddings + predict serves the query from cached prototypes
+    (experiment/utils.py:210-249, lam.py:362-381)."""
+    from label_anything.cli import main
+    from label_anything.preprocess import load_image, IMAGENET_DEFAULT
+    from labelanything_amd.cache import embedding_path, load_embedding, load_episode_embeddings, set_class_embeddings
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    # no LAM neck (image_embed_dim == embed_dim): generate_class_embeddings / predict take cached embeddings as they are
+    from labelanything_amd.config import EncoderSpec, register_encoder
+    register_encoder("sam_tiny64", EncoderSpec("sam", dim=128, depth=2, heads=2, mlp=512, img_size=224, global_idx=(1,), window=8,
+                                               out_chans=64))
+    cfg = LamConfig(encoder="sam_tiny64", image_size=224, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=True)
+    sd = init_state_dict(cfg, 9)
+    ckpt = str(tmp_path / "enc.safetensors")
+    save_file({k[len("image_encoder."):]: v for k, v in sd.items() if k.startswith("image_encoder.")}, ckpt)
+    imgs, out = str(tmp_path / "imgs"), str(tmp_path / "emb")
+    sizes = [(150, 200), (224, 100), (180, 180)]
+    _images(imgs, sizes)
+    r = CliRunner().invoke(main, ["generate_embeddings", "--encoder", "sam_tiny64", "--checkpoint", ckpt, "--directory", imgs,
+                                  "--outfolder", out, "--custom_preprocess", "--batch_size", "3"])
+    assert r.exit_code == 0, r.output + str(r.exception)
+    assert os.path.basename(embedding_path(out, 2)) == "000000000002.safetensors"
+    emb0, gt0 = load_embedding(out, 0)
+    assert emb0.shape == (64, 14, 14) and emb0.dtype == torch.float32 and gt0 is None
+    with pytest.raises(FileNotFoundError):
+        load_embedding(out, 7)
+
+    # 1-way 2-shot episode: query = image 0, supports = images 1, 2
+    emb = load_episode_embeddings(out, [[0, 1, 2]])
+    assert emb.shape == (1, 3, 64, 14, 14)
+    batch = make_episode(batch=1, n_ways=1, k_shots=2, image_size=224, seed=3, prompts=("mask", "point"))
+    batch["dims"] = torch.tensor([[list(s) for s in sizes]])
+    pics = torch.stack([load_image(os.path.join(imgs, f"{i:012d}.png"), 224, True, *IMAGENET_DEFAULT, square=False) for i in range(3)])
+    lam = Lam(cfg, seed=9).cuda()
+    from_images = lam({**batch, "images": pics.unsqueeze(0)})["logits"]
+    b2 = {k: v for k, v in batch.items() if k != "images"}
+    from_cache = lam({**b2, "embeddings": emb})["logits"]
+    torch.cuda.synchronize()
+    assert from_cache.shape == from_images.shape == (1, 2, 224, 200)      # max over ALL original sizes, supports included (lam.py:401)
+    assert rel_err(from_cache, from_images) < 1e-6                      # same fp32 embeddings -> same decoder inputs
+
+    # prototype cache: supports encoded once (no batch axis, like the reference passes them), then query-only predict
+    examples = {k: v[0, 1:] if k in ("dims",) else v[0] for k, v in b2.items() if isinstance(v, torch.Tensor)}
+    examples["embeddings"] = emb[0, 1:]
+    set_class_embeddings(lam, examples)
+    assert lam.class_embeddings["class_embeddings"].shape == (1, 2, 64)
+    pred = lam.predict({"embeddings": emb[:, :1], "dims": batch["dims"][:, 0]})
+    torch.cuda.synchronize()
+    assert rel_err(pred, from_images[..., :150, :200]) < 1e-5
+    # a model WITH a LAM neck must refuse pre-neck embeddings on this path instead of mis-shaping them
+    necked = Lam(LamConfig(encoder="sam_tiny64", image_size=224, image_embed_dim=64, embed_dim=32, spatial_convs=3), seed=1).cuda()
+    necked.class_embeddings = {"class_embeddings": torch.zeros(1, 2, 32).cuda()}
+    with pytest.raises(ValueError, match="without the neck"):
+        necked.predict({"embeddings": emb[:, :1], "dims": batch["dims"][:, 0]})
