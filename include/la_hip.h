@@ -168,6 +168,16 @@ int la_bilinear(const float* in, int N, int h, int w, int H, int W, float* out, 
 int la_post_final(const float* big, int B, int C, int S, const int* sizes, const unsigned char* flag_gts, int Hmax, int Wmax,
                   float* logits, long long* argmax, void* stream);
 
+/* Evaluation metrics without the label maps leaving HBM (experiment/run.py:697-704, utils/metrics.py:28-53,
+ * data/utils.py:567-590): accumulates the K x K multiclass confusion matrix (row = target, column = prediction, pixels with
+ * target == ignore_index dropped) and the 2 x 2 foreground/background matrix (labels > 0 -> 1) of B label maps of HW pixels.
+ * pred, gt int64 [B, HW]; lut int32 [B, L] or NULL maps episode-local labels 0..L-1 of item b to dataset labels (the chained
+ * replacement of to_global_multiclass, collapsed on the host); confmat u64 [K*K], confbin u64 [4], counters u64 [1]
+ * (counters[0] += number of labels outside [0, K), which torchmetrics rejects) are ACCUMULATED - zero them first. */
+int la_confmat_update(const long long* pred, const long long* gt, int B, long HW, const int* lut, int L, int K,
+                      long long ignore_index, unsigned long long* confmat, unsigned long long* confbin,
+                      unsigned long long* counters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

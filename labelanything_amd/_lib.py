@@ -58,6 +58,7 @@ EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
+    "la_confmat_update",
 ]
 
 
@@ -219,6 +220,25 @@ def bilinear(x, n: int, h: int, w: int, oh: int, ow: int, out) -> None:
 def post_final(big, b: int, c: int, s: int, sizes_i32, flag_gts_u8, hmax: int, wmax: int, logits, argmax) -> None:
     _check(lib().la_post_final(_ptr(big), C.c_int(b), C.c_int(c), C.c_int(s), _ptr(sizes_i32), _ptr(flag_gts_u8), C.c_int(hmax),
                                C.c_int(wmax), _ptr(logits), _ptr(argmax), _stream()), "la_post_final")
+
+
+def confmat_update(pred_i64, gt_i64, lut_i32, k: int, ignore_index: int, confmat_u64, confbin_u64, counters_u64) -> None:
+    """pred / gt int64 [B, ...]; lut int32 [B, L] or None; the three accumulators are int64 tensors (bit patterns of u64)."""
+    _dev(pred_i64)
+    if pred_i64.dtype != torch.int64 or gt_i64.dtype != torch.int64 or pred_i64.shape != gt_i64.shape:
+        raise ValueError("confmat_update: pred and gt must be int64 tensors of the same shape")
+    if not (pred_i64.is_contiguous() and gt_i64.is_contiguous()):
+        raise ValueError("confmat_update: label maps must be contiguous")
+    b = pred_i64.shape[0]
+    hw = pred_i64.numel() // b
+    ell = 0
+    if lut_i32 is not None:
+        if lut_i32.dtype != torch.int32 or lut_i32.dim() != 2 or lut_i32.shape[0] != b or not lut_i32.is_contiguous():
+            raise ValueError("confmat_update: lut must be a contiguous int32 [B, L] tensor")
+        ell = lut_i32.shape[1]
+    _check(lib().la_confmat_update(_ptr(pred_i64), _ptr(gt_i64), C.c_int(b), C.c_long(hw), _ptr(lut_i32), C.c_int(ell), C.c_int(k),
+                                   C.c_longlong(ignore_index), _ptr(confmat_u64), _ptr(confbin_u64), _ptr(counters_u64), _stream()),
+           "la_confmat_update")
 
 
 def conv3x3_f32(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out32) -> None:

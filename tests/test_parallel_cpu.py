@@ -51,3 +51,44 @@ def test_shard_is_balanced_and_disjoint():
             flat = sorted(i for p in parts for i in p)
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _meter_worker(rank, world, port, q):
+    import numpy as np
+    import torch.distributed as dist
+    from labelanything_amd.metrics import metrics_from_state
+    from labelanything_amd.parallel import sum_over_ranks
+    from oracle import metrics_oracle as MO
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    p, g = rng.integers(0, 4, 500), rng.integers(0, 4, 500)
+    cm = torch.from_numpy(MO.confusion_matrix(p, g, 4)).clone()
+    cb = torch.from_numpy(MO.binary_confusion_matrix(p, g)).clone()
+    sum_over_ranks(cm)
+    sum_over_ranks(cb)
+    q.put((rank, cm.numpy().tolist(), metrics_from_state(cm, cb)))
+    dist.destroy_process_group()
+
+
+def test_confusion_matrix_all_reduce_two_ranks():
+    """the only collective of the inference path - a SUM all-reduce of the (K+1)^2 int64 confusion matrix."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from oracle import metrics_oracle as MO
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_meter_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    expect = 0
+    for r in range(2):
+        rng = np.random.default_rng(100 + r)
+        pp, gg = rng.integers(0, 4, 500), rng.integers(0, 4, 500)
+        expect = expect + MO.confusion_matrix(pp, gg, 4)
+    assert res[0][1] == res[1][1] == expect.tolist()
+    assert abs(res[0][2]["mIoU"] - MO.strict_mean_iou(expect)) < 1e-6

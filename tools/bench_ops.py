@@ -76,6 +76,19 @@ def main():
     o16 = torch.empty(8192, 768, device="cuda", dtype=dt)
     t = timeit(lambda: L.layernorm(x, gm, bt, 1e-6, out16=o16, dt=L._DT[dt]))
     print(f"layernorm 8192x768: {t*1e6:8.1f} us  {(8192*768*6)/t/1e9:7.1f} GB/s")
+    x = torch.randn(65536, 768, device="cuda")
+    o16 = torch.empty(65536, 768, device="cuda", dtype=dt)
+    t = timeit(lambda: L.layernorm(x, gm, bt, 1e-6, out16=o16, dt=L._DT[dt]))
+    print(f"layernorm 65536x768: {t*1e6:8.1f} us  {(65536*768*6)/t/1e9:7.1f} GB/s")
+    # metrics: 8 x 1024 x 1024 label maps (blocky, like real masks, and random = worst case for the histogram atomics)
+    from labelanything_amd.metrics import SegmentationMeter
+    k = 81
+    for name, gt in (("blocky", torch.randint(0, k, (8, 64, 64)).repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous().cuda()),
+                     ("random", torch.randint(0, k, (8, 1024, 1024)).cuda())):
+        pred = torch.roll(gt, 5, 2).contiguous()
+        m = SegmentationMeter(k)
+        t = timeit(lambda: m.update(pred, gt))
+        print(f"confmat 8x1024x1024 K=81 {name}: {t*1e6:8.1f} us  {gt.numel()*16/t/1e9:7.1f} GB/s")
 
 
 if __name__ == "__main__":

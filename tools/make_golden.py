@@ -64,8 +64,10 @@ class _Finder(importlib.abc.MetaPathFinder):
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.meta_path.insert(0, _Finder())
+# the reference package must win over this repo's same-named shim (label_anything/): its root goes first, the repo last
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
 sys.path.insert(0, "/root/reference")
-sys.path.insert(0, REPO)
+sys.path.append(REPO)
 
 import label_anything.models as RM                      # noqa: E402  (the reference)
 from label_anything.models.image_encoder import ImageEncoderViT   # noqa: E402
