@@ -28,21 +28,23 @@ struct LnArgs {
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) { store4v<T>(p, a, b, c, d); }
 
-template <typename T, int LPR>
+// NVT = float4 vectors per lane (compile time, so the row loads are issued back to back without per-vector predicates);
+// EXACT = every lane has all NVT vectors (E == 4 * LPR * NVT), otherwise the tail vectors are predicated.
+template <typename T, int LPR, int NVT, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int tid = threadIdx.x;
   const int rl = tid / LPR, lane = tid % LPR;
   const int nv = a.E >> 2;
   for (int row = blockIdx.x * RPB + rl; row < a.rows; row += gridDim.x * RPB) {
-    float4 v[LN_MAXV];
+    float4 v[NVT];
     const float4* xp = reinterpret_cast<const float4*>(a.x + (size_t)row * a.ldx);
     const float4* yp = a.x2 ? reinterpret_cast<const float4*>(a.x2 + (size_t)row * a.ldx) : nullptr;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVT; ++i) {
       const int c = lane + i * LPR;
-      if (c < nv) {
+      if (EXACT || c < nv) {
         float4 t = xp[c];
         if (yp) {
           const float4 u = yp[c];
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const float mean = s / (float)a.E;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVT; ++i) {
       const int c = lane + i * LPR;
-      if (c < nv) {
+      if (EXACT || c < nv) {
         const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
@@ -81,9 +83,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const float4* bp = reinterpret_cast<const float4*>(a.beta);
     const float4* pp = a.pe ? reinterpret_cast<const float4*>(a.pe + (size_t)(a.pe_mod ? row % a.pe_mod : row) * a.E) : nullptr;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NVT; ++i) {
       const int c = lane + i * LPR;
-      if (c < nv) {
+      if (EXACT || c < nv) {
         const float4 g = gp[c], be = bp[c];
         float4 o;
         o.x = (v[i].x - mean) * rstd * g.x + be.x;
@@ -104,6 +106,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
 }
 
+template <typename T, int LPR, int NVT>
+static void launch_ln_nv(const LnArgs& a, int blocks, hipStream_t st) {
+  if ((a.E >> 2) == LPR * NVT) hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, true>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, false>), dim3(blocks), dim3(256), 0, st, a);
+}
+
 template <typename T>
 static void launch_ln(const LnArgs& a, hipStream_t st) {
   const int nv = a.E >> 2;
@@ -112,14 +120,23 @@ static void launch_ln(const LnArgs& a, hipStream_t st) {
   const int rpb = 256 / lpr;
   int blocks = (a.rows + rpb - 1) / rpb;
   if (blocks > 8192) blocks = 8192;
-  switch (lpr) {
-    case 64: hipLaunchKernelGGL((layernorm_kernel<T, 64>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((layernorm_kernel<T, 32>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((layernorm_kernel<T, 16>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((layernorm_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, a); break;
+  if (lpr == 64) {
+    const int nvt = (nv + 63) / 64;
+    if (nvt == 1) launch_ln_nv<T, 64, 1>(a, blocks, st);
+    else if (nvt == 2) launch_ln_nv<T, 64, 2>(a, blocks, st);
+    else if (nvt == 3) launch_ln_nv<T, 64, 3>(a, blocks, st);        // E = 768
+    else if (nvt == 4) launch_ln_nv<T, 64, 4>(a, blocks, st);        // E = 1024
+    else if (nvt == 5) launch_ln_nv<T, 64, 5>(a, blocks, st);        // E = 1280
+    else launch_ln_nv<T, 64, LN_MAXV>(a, blocks, st);
+    return;
+  }
+  switch (lpr) {          // narrow rows: one vector per lane
+    case 32: launch_ln_nv<T, 32, 1>(a, blocks, st); break;
+    case 16: launch_ln_nv<T, 16, 1>(a, blocks, st); break;
+    case 8: launch_ln_nv<T, 8, 1>(a, blocks, st); break;
+    case 4: launch_ln_nv<T, 4, 1>(a, blocks, st); break;
+    case 2: launch_ln_nv<T, 2, 1>(a, blocks, st); break;
+    default: launch_ln_nv<T, 1, 1>(a, blocks, st); break;
   }
 }
 
