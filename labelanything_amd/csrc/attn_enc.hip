@@ -119,7 +119,7 @@ struct AttnArgs {
 // MODE 3: rel-pos, G <= 16 (SAM windows): the decomposed terms are computed
 // IN the kernel (U[r][q] = R[r] . q on MFMA, 8 extra MFMAs per 32-query tile) - no la_relpos_terms pass, no global bias.
 template <typename T, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -216,10 +216,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     //   relw[q][kw] = q . Rw[x - kw + 63] = Uw[(x - x0) + 63 - kw][q],  Uw[i][q] = Rw[x0 + i] . q,  i < 96   (12 MFMAs)
     //   relh[q][j]  = q . Rh[y - j + 63]  = Uh[63 - j][q],              Uh[i][q] = Rh[y + i] . q,   i < 64   ( 8 MFMAs)
     // Uw tiles are bounced through a per-wave LDS scratch to reach the score-accumulator register layout.
-    my_bh = bias_lds + wave * 32 * 65;
-    const int y = q0 >> 6, x0 = q0 & 63;
+    // Only HALF of the relh row (32 tiles) is kept in LDS at a time - the second half is recomputed at tile 32 (4 MFMAs) -
+    // so a workgroup needs 48.5 KiB instead of 65 and three of them (12 waves) fit a CU.
+    my_bh = bias_lds + wave * 32 * 33;
+    const int x0 = q0 & 63;
     const T* tabw = reinterpret_cast<const T*>(a.tabw);
-    const T* tabh = reinterpret_cast<const T*>(a.tabh);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -246,17 +247,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
     }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int tt = 0; tt < 2; ++tt) {
-      const T* tp = tabh + (size_t)min(y + tt * 32 + fr, 126) * HD + fh * 8;
-      f32x16 u;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) u[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) my_bh[fr * 65 + 63 - (tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh)] = u[r] * inv_scale;
-    }
   } else if (MODE == 1) {
     const int G = a.G, GS = G + 1;
     my_bh = bias_lds + wave * 2 * 32 * GS;
@@ -342,17 +332,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int ntiles = (MODE == 5) ? ((16 * a.G + 63) >> 6) : ((T_ + 63) >> 6);
   dma(0, 0);
   dma_wait<0>();
+  // MODE 4: relh[q][j] = Uh[63 - j][q], Uh[i][q] = Rh[y + i] . q; half hf covers tiles j in [32 hf, 32 hf + 32) = rows
+  // i in [32 (1 - hf), +32): my_bh[q][j & 31]
+  auto fill_relh_half = [&](int hf) {
+    const int y = q0 >> 6;
+    const T* tp = reinterpret_cast<const T*>(a.tabh) + (size_t)min(y + (1 - hf) * 32 + fr, 126) * HD + fh * 8;
+    f32x16 u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my_bh[fr * 33 + 31 - ((r & 3) + 8 * (r >> 2) + 4 * fh)] = u[r] * inv_scale;
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (MODE == 4) fill_relh_half(0);
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
     const char* sk = smem + (j & 1) * KV_STAGE;
     const char* sv = sk + 64 * HD * 2;
+    if (MODE == 4 && j == 32) fill_relh_half(1);
 
     // ---- S^T tile: 64 keys x 32 queries.  G == 64: the C operand of the first MFMA IS the relw register block
     // (no per-tile initialisation pass); the per-row scalar relh[q][tile] is folded into the softmax constants below.
     f32x16 s[2];
     float rh = 0.f;
-    if (MODE == 2 || MODE == 4) rh = my_bh[fr * 65 + j];
+    if (MODE == 2) rh = my_bh[fr * 65 + j];
+    if (MODE == 4) rh = my_bh[fr * 33 + (j & 31)];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const uint4 kf0 = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, fh));
@@ -732,7 +740,7 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
       return 0;
     }
     if (tabh && tabw && G == 64) {        // global blocks: terms computed in the prologue of each query tile
-      const size_t lds = kv + 4 * 32 * 65 * sizeof(float);
+      const size_t lds = kv + 4 * 32 * 33 * sizeof(float);
       if (dt == LA_F16) la::launch_attn<la::f16_t, 4>(a, lds, st);
       else la::launch_attn<la::bf16_t, 4>(a, lds, st);
       LA_CHECK_LAUNCH("la_attn_fwd");
