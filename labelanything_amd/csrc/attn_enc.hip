@@ -27,7 +27,7 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr float RESCALE_THR = 8.0f;   // log2 units
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NH>
 __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, int B, int heads, int G, int E,
                                                      const T* __restrict__ tabh, const T* __restrict__ tabw,
                                                      float* __restrict__ relh, float* __restrict__ relw) {
@@ -39,14 +39,15 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
   const int ntx = (G + 31) >> 5;
   const uint4 zero = make_uint4(0, 0, 0, 0);
 
-  uint4 af[2][4];
+  constexpr int HDT = 64 * NH, KS = 4 * NH;      // head dim (64 or 128) and MFMA k-slices over it
+  uint4 af[2][KS];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int x = ti * 32 + fr;
     const bool ok = (ti < ntx) && (x < G);
-    const T* p = qkv + ((size_t)b * T_ + (size_t)y * G + (ok ? x : 0)) * (3 * E) + h * HD + fh * 8;
+    const T* p = qkv + ((size_t)b * T_ + (size_t)y * G + (ok ? x : 0)) * (3 * E) + h * HDT + fh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) af[ti][ks] = ok ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+    for (int ks = 0; ks < KS; ++ks) af[ti][ks] = ok ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
   }
   const size_t obase = ((size_t)bh * T_ + (size_t)y * G) * G;
 
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
   for (int tj = 0; tj < ntx; ++tj) {
     const int j = tj * 32 + fr;
     const bool okj = j < G;
-    const T* p = tabh + (size_t)(okj ? (y - j + G - 1) : 0) * HD + fh * 8;
-    uint4 wf[4];
+    const T* p = tabh + (size_t)(okj ? (y - j + G - 1) : 0) * HDT + fh * 8;
+    uint4 wf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wf[ks] = okj ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = okj ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       if (ti >= ntx) continue;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int x = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
   for (int tj = 0; tj < ntr; ++tj) {
     const int rp = tj * 32 + fr;
     const bool okr = rp < nrel;
-    const T* p = tabw + (size_t)(okr ? rp : 0) * HD + fh * 8;
-    uint4 wf[4];
+    const T* p = tabw + (size_t)(okr ? rp : 0) * HDT + fh * 8;
+    uint4 wf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wf[ks] = okr ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = okr ? *reinterpret_cast<const uint4*>(p + ks * 16) : zero;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       if (ti >= ntx) continue;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
+      for (int ks = 0; ks < KS; ++ks) acc = Half16<T>::mfma32(af[ti][ks], wf[ks], acc);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int x = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
@@ -118,8 +119,13 @@ struct AttnArgs {
 // MODE 2: rel-pos, G == 64 (tile == key row), terms from la_relpos_terms.  MODE 4: same with the terms computed in-kernel.
 // MODE 3: rel-pos, G <= 16 (SAM windows): the decomposed terms are computed
 // IN the kernel (U[r][q] = R[r] . q on MFMA, 8 extra MFMAs per 32-query tile) - no la_relpos_terms pass, no global bias.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+// NH = head_dim / 64 (1 or 2).  A 128-wide head is two 64-wide halves everywhere: the K tile is two [64 keys][64 dims]
+// sub-tiles, the V^T tile two [64 dims][64 keys] sub-tiles (same 128-byte rows, same swizzle, same DMA pieces), Q has
+// 4 NH MFMA k-slices and O^T 2 NH accumulator tiles.  (Heads that are not a multiple of 64 wide - SAM ViT-H has 80 - are
+// zero-padded to the next multiple by the host when the weights are packed.)
+template <typename T, int MODE, int NH>
+__global__ __launch_bounds__(256, ((MODE == 4 && NH == 1) ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int HDT = 64 * NH, KS = 4 * NH, SUB = 64 * 64 * 2, KVS = KV_STAGE * NH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -150,15 +156,15 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
   const float c2 = a.scale * 1.44269504088896340736f;  // logits -> log2 domain
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + fh*8 .. +8] -----------------
-  uint4 qf[4];
+  uint4 qf[KS];
   {
-    const T* p = qkv + ((size_t)b * T_ + qc) * E3 + h * HD + fh * 8;
+    const T* p = qkv + ((size_t)b * T_ + qc) * E3 + h * HDT + fh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
   }
 
   // ---- bias staging ---------------------------------------------------------------------------------
-  float* bias_lds = reinterpret_cast<float*>(smem + 2 * KV_STAGE);
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * KVS);
   f32x16 rw[2];
   float bw8[8];
   float* my_bh = nullptr;
@@ -188,13 +194,13 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
     const int G = a.G, nrel = 2 * G - 1;
     my_bh = bias_lds + wave * 2 * 32 * 33;
     my_bw = my_bh + 32 * 33;
-    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
-    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
+    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
     f32x16 uh, uw;
 #pragma unroll
     for (int r = 0; r < 16; ++r) uh[r] = uw[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       uh = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(th + ks * 16), qf[ks], uh);
       uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
     }
@@ -227,12 +233,12 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
       for (int r = 0; r < 16; ++r) rw[t][r] = 0.f;
 #pragma unroll 1
     for (int tt = 0; tt < 3; ++tt) {
-      const T* tp = tabw + (size_t)min(x0 + tt * 32 + fr, 126) * HD + fh * 8;
+      const T* tp = tabw + (size_t)min(x0 + tt * 32 + fr, 126) * HDT + fh * 8;
       f32x16 u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
+      for (int ks = 0; ks < KS; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int r = 0; r < 16; ++r) my_bh[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = u[r] * inv_scale;
@@ -265,13 +271,13 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
     const int G = a.G, nrel = 2 * G - 1;
     my_bh = bias_lds + wave * 2 * 32 * 33;
     my_bw = my_bh + 32 * 33;
-    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
-    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HD + fh * 8;
+    const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
+    const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
     f32x16 uh, uw;
 #pragma unroll
     for (int r = 0; r < 16; ++r) uh[r] = uw[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       uh = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(th + ks * 16), qf[ks], uh);
       uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
     }
@@ -301,13 +307,13 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
     const int row = (i * 4 + wave) * 8 + (lane >> 3);        // tile row 0..63
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     krow[i] = row;
-    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HD + chunk * 8;
-    vsrc[i] = vt + ((size_t)bh * HD + row) * a.Tpad + chunk * 8;
+    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HDT + chunk * 8;
+    vsrc[i] = vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
   }
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int j, int stage) {
-    const unsigned sk = lds0 + stage * KV_STAGE;
-    const unsigned sv = sk + 64 * HD * 2;
+    const unsigned sk = lds0 + stage * KVS;
+    const unsigned sv = sk + NH * SUB;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int key;
@@ -317,14 +323,17 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
       } else {
         key = min(j * 64 + krow[i], T_ - 1);
       }
-      dma16(ksrc[i] + (size_t)key * E3, sk + (i * 4 + wave) * 1024);
-      dma16(vsrc[i] + j * 64, sv + (i * 4 + wave) * 1024);
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {            // dims 64 hh .. of K, rows 64 hh .. of V^T
+        dma16(ksrc[i] + (size_t)key * E3 + hh * 64, sk + hh * SUB + (i * 4 + wave) * 1024);
+        dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
+      }
     }
   };
 
-  f32x16 oacc[2];
+  f32x16 oacc[2 * NH];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
@@ -336,12 +345,12 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
   // i in [32 (1 - hf), +32): my_bh[q][j & 31]
   auto fill_relh_half = [&](int hf) {
     const int y = q0 >> 6;
-    const T* tp = reinterpret_cast<const T*>(a.tabh) + (size_t)min(y + (1 - hf) * 32 + fr, 126) * HD + fh * 8;
+    const T* tp = reinterpret_cast<const T*>(a.tabh) + (size_t)min(y + (1 - hf) * 32 + fr, 126) * HDT + fh * 8;
     f32x16 u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
+    for (int ks = 0; ks < KS; ++ks) u = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tp + ks * 16), qf[ks], u);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) my_bh[fr * 33 + 31 - ((r & 3) + 8 * (r >> 2) + 4 * fh)] = u[r] * inv_scale;
@@ -351,8 +360,8 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
   __syncthreads();
   for (int j = 0; j < ntiles; ++j) {
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
-    const char* sk = smem + (j & 1) * KV_STAGE;
-    const char* sv = sk + 64 * HD * 2;
+    const char* sk = smem + (j & 1) * KVS;
+    const char* sv = sk + NH * SUB;
     if (MODE == 4 && j == 32) fill_relh_half(1);
 
     // ---- S^T tile: 64 keys x 32 queries.  G == 64: the C operand of the first MFMA IS the relw register block
@@ -385,10 +394,10 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
       }
     }
 #pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
+    for (int ks = 1; ks < KS; ++ks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 kf = *reinterpret_cast<const uint4*>(sk + (ks >> 2) * SUB + swz_off(t * 32 + fr, (ks & 3) * 2 + fh));
         s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
       }
     }
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
       m_run = m_new;
@@ -476,8 +485,8 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(d * 32 + fr, ks * 2 + fh));
+      for (int d = 0; d < 2 * NH; ++d) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(sv + (d >> 1) * SUB + swz_off((d & 1) * 32 + fr, ks * 2 + fh));
         oacc[d] = Half16<T>::mfma32(vf, pf[ks], oacc[d]);
       }
     }
@@ -490,9 +499,9 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 3 : 2)) void attn_fwd_kernel(Attn
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.0f / l_tot;
   if (q < T_) {
-    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HD;
+    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HDT;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint2 v;
@@ -674,15 +683,22 @@ static void launch_window(const AttnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((attn_window_kernel<T>), dim3((njobs + 3) / 4), dim3(256), lds, st, a, qtiles);
 }
 
-template <typename T, int MODE>
-static void launch_attn(const AttnArgs& a, size_t lds, hipStream_t st) {
+template <typename T, int MODE, int NH>
+static void launch_attn_nh(const AttnArgs& a, size_t lds, hipStream_t st) {
   static size_t attr_lds = 0;   // raise the dynamic-LDS limit once (and again only if a larger request shows up)
   if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_lds = lds;
   }
   const int nq = (a.T + 127) / 128;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, NH>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
+}
+
+// extra = LDS beyond the two K / V^T stages (bias tables); head_dim = E / heads is 64 or 128
+template <typename T, int MODE>
+static void launch_attn(const AttnArgs& a, size_t extra, hipStream_t st) {
+  if (a.E == a.heads * 128) launch_attn_nh<T, MODE, 2>(a, 2 * (size_t)KV_STAGE * 2 + extra, st);
+  else launch_attn_nh<T, MODE, 1>(a, 2 * (size_t)KV_STAGE + extra, st);
 }
 
 }  // namespace la
@@ -690,17 +706,20 @@ static void launch_attn(const AttnArgs& a, size_t lds, hipStream_t st) {
 extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void* tabh, const void* tabw, float* relh,
                                float* relw, int dt, void* stream) {
   LA_CHECK_ARG(qkv && tabh && tabw && relh && relw, "la_relpos_terms: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * la::HD, "la_relpos_terms: needs head_dim 64 and G <= 64 (G=%d E=%d heads=%d)",
-               G, E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && (E == heads * 64 || E == heads * 128),
+               "la_relpos_terms: needs head_dim 64 or 128 and G <= 64 (G=%d E=%d heads=%d)", G, E, heads);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_terms: bad dtype %d", dt);
   const int waves = B * heads * G;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dt == LA_F16)
-    hipLaunchKernelGGL(la::relpos_kernel<la::f16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const la::f16_t*)qkv, B, heads, G, E,
-                       (const la::f16_t*)tabh, (const la::f16_t*)tabw, relh, relw);
-  else if (dt == LA_BF16)
-    hipLaunchKernelGGL(la::relpos_kernel<la::bf16_t>, dim3((waves + 3) / 4), dim3(256), 0, st, (const la::bf16_t*)qkv, B, heads, G, E,
-                       (const la::bf16_t*)tabh, (const la::bf16_t*)tabw, relh, relw);
-  else LA_CHECK_ARG(false, "la_relpos_terms: bad dtype %d", dt);
+  const dim3 grid((waves + 3) / 4), blk(256);
+  const bool wide = E == heads * 128;
+  if (dt == LA_F16) {
+    if (wide) hipLaunchKernelGGL((la::relpos_kernel<la::f16_t, 2>), grid, blk, 0, st, (const la::f16_t*)qkv, B, heads, G, E, (const la::f16_t*)tabh, (const la::f16_t*)tabw, relh, relw);
+    else hipLaunchKernelGGL((la::relpos_kernel<la::f16_t, 1>), grid, blk, 0, st, (const la::f16_t*)qkv, B, heads, G, E, (const la::f16_t*)tabh, (const la::f16_t*)tabw, relh, relw);
+  } else {
+    if (wide) hipLaunchKernelGGL((la::relpos_kernel<la::bf16_t, 2>), grid, blk, 0, st, (const la::bf16_t*)qkv, B, heads, G, E, (const la::bf16_t*)tabh, (const la::bf16_t*)tabw, relh, relw);
+    else hipLaunchKernelGGL((la::relpos_kernel<la::bf16_t, 1>), grid, blk, 0, st, (const la::bf16_t*)qkv, B, heads, G, E, (const la::bf16_t*)tabh, (const la::bf16_t*)tabw, relh, relw);
+  }
   LA_CHECK_LAUNCH("la_relpos_terms");
   return 0;
 }
@@ -708,12 +727,13 @@ extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, 
 extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
                            const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
   LA_CHECK_ARG(qkv && vt && out16, "la_attn_fwd: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * la::HD, "la_attn_fwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_fwd: needs head_dim 64 or 128 - pad other widths with zero columns (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd: bad dtype %d", dt);
   la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t kv = 2 * la::KV_STAGE;
+  const size_t kv = 0;       // launch_attn adds the K / V^T stages for the head width; the sizes below are the bias tables
   if (mode == LA_ATTN_PLAIN) {
     if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, kv, st);
     else la::launch_attn<la::bf16_t, 0>(a, kv, st);
@@ -727,7 +747,7 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
     LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
     if (tabh && tabw && G <= 16) {        // windows: bias terms computed in-kernel from the tables
       static const char* wforce = getenv("LA_WINDOW_PATH");     // debugging: "lds" selects the LDS-staged MODE 3 kernel
-      if (!(wforce && wforce[0] == 'l')) {
+      if (!(wforce && wforce[0] == 'l') && E == heads * 64) {   // (the no-LDS window kernel is 64-wide only)
         if (dt == LA_F16) la::launch_window<la::f16_t>(a, st);
         else la::launch_window<la::bf16_t>(a, st);
         LA_CHECK_LAUNCH("la_attn_fwd");

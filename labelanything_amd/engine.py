@@ -81,6 +81,34 @@ class LamEngine:
     def _hd(self, t: Tensor) -> Tensor:
         return t.to(self.ddt).contiguous()
 
+    @property
+    def head_pad(self) -> int:
+        """Encoder head width as the attention kernels see it: the next multiple of 64 (64 or 128).  Heads of another
+        width (SAM ViT-H: 80) get zero weight rows / bias entries / table columns for the extra q, k, v dims and zero
+        proj columns, which changes neither q.k nor the projected output."""
+        hd = self.cfg.encoder_spec.head_dim
+        hdp = 64 * ((hd + 63) // 64)
+        if hdp > 128:
+            raise NotImplementedError(f"encoder head_dim {hd} > 128 is not built")
+        return hdp
+
+    @staticmethod
+    def _pad_heads_out(t: Tensor, groups: int, hd: int, hdp: int) -> Tensor:
+        """[groups*hd, ...] -> [groups*hdp, ...]: zero rows appended to every head block of an output dimension."""
+        if hd == hdp:
+            return t.contiguous()
+        v = t.reshape(groups, hd, *t.shape[1:])
+        pad = torch.zeros(groups, hdp - hd, *t.shape[1:], dtype=t.dtype, device=t.device)
+        return torch.cat([v, pad], dim=1).reshape(groups * hdp, *t.shape[1:]).contiguous()
+
+    @staticmethod
+    def _pad_heads_in(t: Tensor, groups: int, hd: int, hdp: int) -> Tensor:
+        """[N, groups*hd] -> [N, groups*hdp]: zero columns appended to every head block of the input dimension."""
+        if hd == hdp:
+            return t.contiguous()
+        v = t.reshape(t.shape[0], groups, hd)
+        return F.pad(v, (0, hdp - hd)).reshape(t.shape[0], groups * hdp).contiguous()
+
     def _pack_attn(self, pre: str, fuse: str) -> None:
         """decoder Attention (common.py:57-148).  fuse: 'qkv' (same input), 'qk' (q,k share input), 'none'."""
         w, p = self.w32, self.p
@@ -119,10 +147,12 @@ class LamEngine:
             p[pre + ".patch.w"] = self._h(w[pre + ".patch_embed.proj.weight"].flatten(1))
             p[pre + ".pos"] = w[pre + ".pos_embed"].reshape(-1, spec.dim).contiguous()
             g = spec.img_size // spec.patch
+            hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 bp = f"{pre}.blocks.{i}"
-                p[bp + ".qkv.w"] = self._h(w[bp + ".attn.qkv.weight"])
-                p[bp + ".proj.w"] = self._h(w[bp + ".attn.proj.weight"])
+                p[bp + ".qkv.w"] = self._h(self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp))
+                p[bp + ".qkv.b"] = self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp)
+                p[bp + ".proj.w"] = self._h(self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp))
                 p[bp + ".lin1.w"] = self._h(w[bp + ".mlp.lin1.weight"])
                 p[bp + ".lin2.w"] = self._h(w[bp + ".mlp.lin2.weight"])
                 size = g if i in spec.global_idx else spec.window
@@ -130,19 +160,21 @@ class LamEngine:
                     tab = w[f"{bp}.attn.rel_pos_{ax}"]
                     if tab.shape[0] != 2 * size - 1:   # get_rel_pos linear resampling (image_encoder.py:321-330), constant per model
                         tab = F.interpolate(tab.t().unsqueeze(0), size=2 * size - 1, mode="linear")[0].t()
-                    p[f"{bp}.tab{ax}"] = self._h(tab)
+                    p[f"{bp}.tab{ax}"] = self._h(F.pad(tab, (0, hdp - hd)))
             self._pack_conv_neck(pre + ".neck")
         elif spec is not None and spec.kind == "hf":
             pre = "image_encoder"
             p[pre + ".patch.w"] = self._h(w[pre + ".embeddings.patch_embeddings.projection.weight"].flatten(1))
+            hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 lp = f"{pre}.encoder.layer.{i}"
-                p[lp + ".qkv.w"] = self._h(torch.cat([w[lp + ".attention.attention.query.weight"],
-                                                      w[lp + ".attention.attention.key.weight"],
-                                                      w[lp + ".attention.attention.value.weight"]]))
-                p[lp + ".qkv.b"] = torch.cat([w[lp + ".attention.attention.query.bias"], w[lp + ".attention.attention.key.bias"],
-                                              w[lp + ".attention.attention.value.bias"]]).contiguous()
-                p[lp + ".o.w"] = self._h(w[lp + ".attention.output.dense.weight"])
+                qkv_w = torch.cat([w[lp + ".attention.attention.query.weight"], w[lp + ".attention.attention.key.weight"],
+                                   w[lp + ".attention.attention.value.weight"]])
+                qkv_b = torch.cat([w[lp + ".attention.attention.query.bias"], w[lp + ".attention.attention.key.bias"],
+                                   w[lp + ".attention.attention.value.bias"]])
+                p[lp + ".qkv.w"] = self._h(self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp))
+                p[lp + ".qkv.b"] = self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp)
+                p[lp + ".o.w"] = self._h(self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp))
                 p[lp + ".fc1.w"] = self._h(w[lp + ".intermediate.dense.weight"])
                 p[lp + ".fc2.w"] = self._h(w[lp + ".output.dense.weight"])
         if cfg.lam_neck:
@@ -228,10 +260,7 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     def _check_encoder_input(self, images: Tensor) -> None:
         spec: EncoderSpec = self.cfg.encoder_spec
-        if spec.head_dim != 64:
-            # la_attn_fwd is specialised for 64-wide heads (SAM ViT-B/L, every HF ViT here); SAM ViT-H has 80
-            raise NotImplementedError(f"encoder attention is built for head_dim 64 only (this encoder has {spec.head_dim}); "
-                                      "feed precomputed embeddings instead")
+        _ = self.head_pad          # raises for head widths beyond 128
         if images.shape[-1] % spec.patch or self.cfg.vit_patch_size != spec.patch:
             raise ValueError(f"image side {images.shape[-1]} / vit_patch_size {self.cfg.vit_patch_size} do not match the "
                              f"encoder's {spec.patch}x{spec.patch} patches")
@@ -247,6 +276,8 @@ class LamEngine:
         hw = g * g
         rows = bn * hw
         scale = spec.head_dim ** -0.5
+        hdp = self.head_pad
+        ea = heads * hdp                # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
         w, p = self.w32, self.p
         images = images.contiguous()
         a = self.buf("enc.patchA", (rows, 3 * spec.patch * spec.patch))
@@ -271,22 +302,22 @@ class LamEngine:
             win16 = (not is_global) and gg <= 16      # windows: V^T / K in 16-wide padded slot order (LA_ATTN_RELPOS_WIN16)
             tpad = _ceil(16 * gg, 64) if win16 else _ceil(t, 64)
             tag = "g" if is_global else "w"
-            qkv = self.buf("enc.qkv." + tag, (arows, 3 * e))
-            vt = self.buf("enc.vt." + tag, (nb * heads, 64, tpad), zero=True)
-            L.gemm(xin, p[bp + ".qkv.w"], bias=w[bp + ".attn.qkv.bias"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t,
-                   vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=gg if win16 else 0)
-            ao = self.buf("enc.ao." + tag, (arows, e))
+            qkv = self.buf("enc.qkv." + tag, (arows, 3 * ea))
+            vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
+            L.gemm(xin, p[bp + ".qkv.w"], bias=p[bp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t,
+                   vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
+            ao = self.buf("enc.ao." + tag, (arows, ea))
             if win16:
-                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS_WIN16,
+                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16,
                            tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             elif gg <= 16 or gg == 64:      # rel-pos terms are computed inside the attention kernel
-                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS,
+                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS,
                            tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             else:
                 relh = self.f32("enc.relh." + tag, (nb * heads, t, gg))
                 relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
-                L.relpos_terms(qkv, nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
-                L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, e, scale, L.ATTN_RELPOS)
+                L.relpos_terms(qkv, nb, heads, gg, ea, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
+                L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS)
             if is_global:
                 L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
             else:
@@ -347,17 +378,19 @@ class LamEngine:
                out32=res, map=L.MAP_GROUP, p=(hw, t, 1, 0, 0))
         tpad = _ceil(t, 64)
         x16 = self.buf("hf.x16", (rows, e))
-        qkv = self.buf("hf.qkv", (rows, 3 * e))
-        vt = self.buf("hf.vt", (bn * heads, 64, tpad), zero=True)
-        ao = self.buf("hf.ao", (rows, e))
+        hdp = self.head_pad
+        ea = heads * hdp
+        qkv = self.buf("hf.qkv", (rows, 3 * ea))
+        vt = self.buf("hf.vt", (bn * heads, hdp, tpad), zero=True)
+        ao = self.buf("hf.ao", (rows, ea))
         hbuf = self.buf("hf.mlp", (rows, spec.mlp))
         scale = spec.head_dim ** -0.5
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
-            L.gemm(x16, p[lp + ".qkv.w"], bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=tpad,
-                   vt_hd=64, vt_heads=heads)
-            L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, e, scale, L.ATTN_PLAIN)
+            L.gemm(x16, p[lp + ".qkv.w"], bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t, vt_Tpad=tpad,
+                   vt_hd=hdp, vt_heads=heads)
+            L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
             L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
             self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
             L.gemm(x16, p[lp + ".fc1.w"], bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)

@@ -211,11 +211,22 @@ def test_wide_sam_encoder_matches_oracle():
     assert _encoder_vs_oracle(cfg, 2, 22) < 2e-3
 
 
-def test_head_dim_80_is_rejected_loudly():
-    """SAM ViT-H (head_dim 80) attention is not built: the encoder must refuse instead of computing garbage."""
+def test_sam_vit_h_style_80_wide_heads_match_oracle():
+    """SAM ViT-H has 80-wide heads (1280 / 16, image_encoder.py:200-255).  The host zero-pads them to 128 for the attention
+    kernels; windows (14x14, padded grid), a global block with la_relpos_terms (28x28 grid) and, at 1024 px, the in-kernel
+    G = 64 path all have to reproduce the unpadded maths."""
     from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
-    register_encoder("sam_hd80", EncoderSpec("sam", dim=160, depth=1, heads=2, mlp=320, img_size=224, global_idx=(0,), window=14, out_chans=64))
-    cfg = LamConfig(encoder="sam_hd80", image_size=224, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
-    lam = Lam(cfg, seed=1).cuda()
-    with pytest.raises(NotImplementedError, match="head_dim 64"):
-        lam.image_encoder(torch.randn(1, 3, 224, 224).cuda())
+    register_encoder("sam_hd80", EncoderSpec("sam", dim=160, depth=2, heads=2, mlp=320, img_size=448, global_idx=(1,), window=14, out_chans=64))
+    cfg = LamConfig(encoder="sam_hd80", image_size=448, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+    assert _encoder_vs_oracle(cfg, 2, 23) < 2e-3
+    register_encoder("sam_hd80_1k", EncoderSpec("sam", dim=160, depth=2, heads=2, mlp=320, img_size=1024, global_idx=(1,), window=14, out_chans=64))
+    cfg = LamConfig(encoder="sam_hd80_1k", image_size=1024, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+    assert _encoder_vs_oracle(cfg, 1, 24) < 2e-3
+
+
+def test_hf_encoder_with_32_wide_heads_is_padded_to_64():
+    """Heads narrower than 64 (e.g. a 4-head 128-wide ViT) ride the same zero-padding."""
+    from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
+    register_encoder("hf_hd32", EncoderSpec("hf", dim=128, depth=2, heads=4, mlp=256, img_size=224))
+    cfg = LamConfig(encoder="hf_hd32", image_size=160, image_embed_dim=128, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+    assert _encoder_vs_oracle(cfg, 2, 25) < 2e-3

@@ -337,3 +337,79 @@ def test_window_attention_in_padded_slot_order(L, dt, g):
     L.attn_fwd(qkv, vt, out, None, None, b, heads, t, tpad, g, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw)
     torch.cuda.synchronize()
     assert rel_err(out, ref) < TOL16[dt]
+
+
+def _wide_inputs(b, heads, t, hd_true, dt, seed):
+    """q/k/v with hd_true real dims per head, zero-padded to 128 (what the host does for SAM ViT-H's 80-wide heads)."""
+    e = heads * 128
+    qkv = torch.zeros(b * t, 3, heads, 128, device="cuda")
+    qkv[..., :hd_true] = rnd(b * t, 3, heads, hd_true, seed=seed)
+    qkv = qkv.reshape(b * t, 3 * e).to(dt)
+    tpad = (t + 63) // 64 * 64
+    v = qkv[:, 2 * e:].view(b, t, heads, 128).permute(0, 2, 3, 1)
+    vt = torch.zeros(b * heads, 128, tpad, device="cuda", dtype=dt)
+    vt[:, :, :t] = v.reshape(b * heads, 128, t)
+    return qkv, vt, e, tpad
+
+
+def _wide_ref(qkv, b, heads, t, scale, bias=None):
+    e = heads * 128
+    q, k, v = [z.view(b, t, heads, 128).transpose(1, 2).float() for z in qkv.float().split(e, dim=1)]
+    s = (q * scale) @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b * t, e)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("hd_true", [128, 80])
+def test_attention_128_wide_heads_all_modes(L, dt, hd_true):
+    """head_dim 128 (two 64-wide halves in every tile), also as the zero-padded image of SAM ViT-H's 80-wide heads
+    (image_encoder.py:200-255 with hd = 1280 / 16): plain, rel-pos from la_relpos_terms, in-kernel G = 64, windows."""
+    scale = hd_true ** -0.5
+    # plain
+    b, heads, t = 2, 2, 333
+    qkv, vt, e, tpad = _wide_inputs(b, heads, t, hd_true, dt, 70)
+    out = torch.empty(b * t, e, device="cuda", dtype=dt)
+    L.attn_fwd(qkv, vt, out, None, None, b, heads, t, tpad, 0, e, scale, L.ATTN_PLAIN)
+    torch.cuda.synchronize()
+    assert rel_err(out, _wide_ref(qkv, b, heads, t, scale)) < TOL16[dt]
+    assert hd_true == 128 or float(out.view(b * t, heads, 128)[..., hd_true:].float().abs().max()) == 0.0
+    # rel-pos: generic grid via la_relpos_terms (G = 20), in-kernel for G = 64, windows G = 14 (both layouts)
+    for g, b, heads in ((20, 2, 2), (64, 1, 2), (14, 3, 2)):
+        t = g * g
+        qkv, vt, e, tpad = _wide_inputs(b, heads, t, hd_true, dt, 71 + g)
+        tabh = torch.zeros(2 * g - 1, 128, device="cuda")
+        tabw = torch.zeros(2 * g - 1, 128, device="cuda")
+        tabh[:, :hd_true] = rnd(2 * g - 1, hd_true, seed=72) * 0.3
+        tabw[:, :hd_true] = rnd(2 * g - 1, hd_true, seed=73) * 0.3
+        tabh, tabw = tabh.to(dt), tabw.to(dt)
+        q = qkv[:, :e].float().view(b, t, heads, 128).transpose(1, 2).reshape(b * heads, g, g, 128)
+        rh = O.rel_pos_table(g, g, tabh.float().cpu()).cuda()
+        rw = O.rel_pos_table(g, g, tabw.float().cpu()).cuda()
+        ref_h = torch.einsum("nyxc,ykc->nyxk", q, rh).reshape(b * heads, t, g)
+        ref_w = torch.einsum("nyxc,xkc->nyxk", q, rw).reshape(b * heads, t, g)
+        bias = (ref_h.view(b, heads, t, g, 1) + ref_w.view(b, heads, t, 1, g)).reshape(b, heads, t, t)
+        ref = _wide_ref(qkv, b, heads, t, scale, bias)
+        relh = torch.zeros(b * heads, t, g, device="cuda")
+        relw = torch.zeros(b * heads, t, g, device="cuda")
+        L.relpos_terms(qkv, b, heads, g, e, tabh, tabw, relh, relw)
+        torch.cuda.synchronize()
+        assert rel_err(relh, ref_h) < 1e-3 and rel_err(relw, ref_w) < 1e-3
+        out = torch.zeros(b * t, e, device="cuda", dtype=dt)
+        L.attn_fwd(qkv, vt, out, relh, relw, b, heads, t, tpad, g, e, scale, L.ATTN_RELPOS)
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < TOL16[dt], f"terms from global, G={g}"
+        if g <= 16 or g == 64:
+            out2 = torch.zeros_like(out)
+            L.attn_fwd(qkv, vt, out2, None, None, b, heads, t, tpad, g, e, scale, L.ATTN_RELPOS, tabh=tabh, tabw=tabw)
+            torch.cuda.synchronize()
+            assert rel_err(out2, ref) < TOL16[dt], f"terms in-kernel, G={g}"
+        if g <= 16:          # 16-wide slot order: V^T re-laid out like the GEMM epilogue does (vt_ws)
+            tp16 = (16 * g + 63) // 64 * 64
+            vt16 = torch.zeros(b * heads, 128, tp16, device="cuda", dtype=dt)
+            vt16[..., : 16 * g].view(b * heads, 128, g, 16)[..., :g] = vt[:, :, :t].reshape(b * heads, 128, g, g)
+            out3 = torch.zeros_like(out)
+            L.attn_fwd(qkv, vt16, out3, None, None, b, heads, t, tp16, g, e, scale, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw)
+            torch.cuda.synchronize()
+            assert rel_err(out3, ref) < TOL16[dt], f"WIN16, G={g}"
