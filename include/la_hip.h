@@ -26,7 +26,7 @@ extern "C" {
 enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2 };
 enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2 };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
-enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3 };
+enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3, LA_MAP_WINDOW_PART = 4 };
 /* la_attn_fwd modes */
 /* LA_ATTN_RELPOS_WIN16: SAM window attention with the keys held in a 16-wide padded slot order (see la_attn_fwd) */
 enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1, LA_ATTN_RELPOS_WIN16 = 2 };
@@ -42,9 +42,17 @@ int la_version(void);
  *  map LA_MAP_CONVT2X2     ConvTranspose2d(k=2,s=2) as a GEMM with pixel shuffle: rows are (b, y, x) on a p1 x p0
  *                          (H x W) grid, cols are (ky, kx, cout) with p2 = cout: dst_row = (b*2H + 2y+ky)*2W + 2x+kx,
  *                          dst_col = cout   (mask_decoder.py:206-222)
+ *  map LA_MAP_WINDOW_PART  the inverse: rows are (b, y, x) tokens of an H x W grid, dst_row = their place in the
+ *                          window-partitioned order (same p0..p4; window_partition, image_encoder.py:258-279).  The padded
+ *                          tokens of the destination are never written: their q, k, v are the bias vector, which the
+ *                          caller stores there once.
+ *  amap (same encodings, same p0..p4, at most one of map / amap non-zero): a map applied to the SOURCE rows instead -
+ *                          GEMM row m reads A[amap(m)] and writes row m.  With LA_MAP_WINDOW_PART the proj GEMM of a SAM
+ *                          window block walks the H x W tokens only and gathers its input from the window-ordered
+ *                          attention output, so neither window GEMM touches the 16 % padded tokens.
  *  residual is fp32, indexed by (res_mod ? dst_row % res_mod : dst_row), dst_col.
  *  vt != NULL: columns >= vt_col0 are NOT written to out16 but transposed into
- *  vt[((row / vt_T) * vt_heads + head) * vt_hd + d][vt_Tpad] at token row % vt_T  (V operand of la_attn_fwd).
+ *  vt[((row / vt_T) * vt_heads + head) * vt_hd + d][vt_Tpad] at token row % vt_T  (V operand of la_attn_fwd), row = dst_row.
  */
 typedef struct LaGemmEpilogue {
   const float* bias;   /* [N] or NULL (for LA_MAP_CONVT2X2: [cout]) */
@@ -61,6 +69,7 @@ typedef struct LaGemmEpilogue {
   void* vt;
   int vt_col0, vt_T, vt_Tpad, vt_hd, vt_heads;
   int vt_ws;           /* > 0: token t of a ws x ws window goes to slot (t / ws) * 16 + t % ws of the V^T row (LA_ATTN_RELPOS_WIN16) */
+  int amap;            /* source-row map (LA_MAP_NONE or LA_MAP_WINDOW_PART), see above */
 } LaGemmEpilogue;
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.

@@ -38,6 +38,11 @@ __device__ __forceinline__ int map_row(const RowMap& m, int row) {
       const int y = wy * ws + tok / ws, x = wx * ws + tok % ws;
       return (y < H && x < W) ? (b * H + y) * W + x : -1;
     }
+    case LA_MAP_WINDOW_PART: {
+      const int ws = m.p0, nwy = m.p1, nwx = m.p2, H = m.p3, W = m.p4;
+      const int x = row % W, y = (row / W) % H, b = row / (W * H);
+      return ((b * nwy + y / ws) * nwx + x / ws) * ws * ws + (y % ws) * ws + (x % ws);
+    }
     case LA_MAP_CONVT2X2: {
       const int W = m.p0, H = m.p1;
       const int x = row % W;
@@ -48,6 +53,12 @@ __device__ __forceinline__ int map_row(const RowMap& m, int row) {
     default:
       return row;
   }
+}
+
+// source row of GEMM row m (LaGemmEpilogue.amap)
+__device__ __forceinline__ int a_row(const LaGemmEpilogue& e, int m) {
+  if (e.amap == LA_MAP_NONE) return m;
+  return map_row(RowMap{e.amap, e.p0, e.p1, e.p2, e.p3, e.p4}, m);
 }
 
 template <typename T>
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
   const T* w_ptr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ra = min(m0 + lr + 32 * i, M - 1);
+    const int ra = a_row(e, min(m0 + lr + 32 * i, M - 1));
     const int rw = min(n0 + lr + 32 * i, N - 1);
     a_ptr[i] = A + (size_t)ra * lda + lc * 8;
     w_ptr[i] = Wt + (size_t)rw * ldw + lc * 8;
@@ -159,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
         if (e.act == LA_ACT_GELU) v = gelu_erf(v);
         else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
         if (to_vt) {
-          const int b = row / e.vt_T, t = row % e.vt_T;
+          const int vr = map_row(rm, row);            // token index in the destination order
+          if (vr < 0) continue;
+          const int b = vr / e.vt_T, t = vr % e.vt_T;
           vt[((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(t, e.vt_ws)] = (T)v;
           continue;
         }
@@ -195,10 +208,40 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
   reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// Transposed-V store of the 4 consecutive GEMM rows of one V column whose destination rows (token index in the output
+// order, -1 = none) are d[0..3].  When the four are consecutive tokens of one batch item whose slots are contiguous they go
+// out as one 8-byte store; a run that straddles a window row of the 16-slot layout as two 4-byte pairs; anything else
+// (a row map that jumps to another window, the ragged end of M) element by element.
+template <typename T>
+__device__ __forceinline__ void vt_store4(T* vt, const LaGemmEpilogue& e, const int (&d)[4], int vhead, int vd, float4 v, float bias) {
+  const float vv[4] = {v.x + bias, v.y + bias, v.z + bias, v.w + bias};
+  auto slot_ptr = [&](int drow) {
+    const int bj = drow / e.vt_T, tj = drow % e.vt_T;
+    return vt + ((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(tj, e.vt_ws);
+  };
+  const bool run = d[0] >= 0 && d[1] == d[0] + 1 && d[2] == d[0] + 2 && d[3] == d[0] + 3;
+  const int t0 = run ? d[0] % e.vt_T : 0;
+  if (run && (t0 & 1) == 0 && t0 + 3 < e.vt_T) {
+    if (e.vt_ws == 0 || (t0 % e.vt_ws) <= e.vt_ws - 4) {
+      store4v<T>(slot_ptr(d[0]), vv[0], vv[1], vv[2], vv[3]);
+      return;
+    }
+    if ((e.vt_ws & 1) == 0) {           // two pairs, each inside one window row
+      store2<T>(slot_ptr(d[0]), vv[0], vv[1]);
+      store2<T>(slot_ptr(d[2]), vv[2], vv[3]);
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (d[j] >= 0) *slot_ptr(d[j]) = (T)vv[j];
+}
+
 template <typename T, int TI, int TJ, int BN_, int NT, int CR = 128>
 __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI][TJ], int nchunks, int my_chunk, int wrow0, int wcol0,
                                              int m0, int n0, int M, int N, const LaGemmEpilogue& e, int tid) {
   constexpr int LD = BN_ + 4;
+  __shared__ int drow_lds[CR];
   const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
   const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
   T* outT = reinterpret_cast<T*>(e.out16);
@@ -228,23 +271,32 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
             }
       }
     }
-    __syncthreads();
+    // destination row of every GEMM row of this chunk (-1: dropped / beyond M), computed once: the maps cost several
+    // integer divisions each and every row is needed by BN_/8 (row-major pass) or BN_ (V^T pass) items
     const int mrow0 = m0 + chunk * CR;
+    for (int i = tid; i < CR; i += NT) drow_lds[i] = (mrow0 + i < M) ? map_row(rm, mrow0 + i) : -1;
+    __syncthreads();
     if (vt_tile) {
       constexpr int RG = CR / 4;
       for (int it = tid; it < BN_ * RG; it += NT) {
         const int rg = it % RG, c = it / RG;
-        const int col = n0 + c, row = mrow0 + rg * 4;
-        if (col >= N || row >= M) continue;
+        const int col = n0 + c;
+        if (col >= N) continue;
         const float4 v = *reinterpret_cast<const float4*>(&epi[c * LD + rg * 4]);
         const float bias = e.bias ? e.bias[col] : 0.f;
         const int cv = col - e.vt_col0;
         const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
+        if (rm.mode != LA_MAP_NONE) {        // mapped rows: destinations from the table
+          const int d[4] = {drow_lds[rg * 4], drow_lds[rg * 4 + 1], drow_lds[rg * 4 + 2], drow_lds[rg * 4 + 3]};
+          vt_store4<T>(vt, e, d, vhead, vd, v, bias);
+          continue;
+        }
+        const int row = mrow0 + rg * 4;
+        if (row >= M) continue;
         const int b = row / e.vt_T, t = row % e.vt_T;
         T* dst = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(t, e.vt_ws);
         if ((e.vt_T & 3) == 0 && row + 3 < M && (e.vt_ws == 0 || ((e.vt_ws & 3) == 0) || (t % e.vt_ws) <= e.vt_ws - 4)) {
-          // 4 consecutive tokens of one batch item (and, for windows, of one window row: contiguous slots, 8-byte aligned
-          // because t % 4 == 0 and the row offset 16 * kh + (t % ws) keeps the parity of t % ws ... only when ws is even)
+          // 4 consecutive tokens of one batch item (and, for windows, of one window row: contiguous slots)
           store4v<T>(dst, v.x + bias, v.y + bias, v.z + bias, v.w + bias);
         } else if ((e.vt_T & 3) == 0 && row + 3 < M && e.vt_ws > 0 && (e.vt_ws & 1) == 0) {
           // group straddles a window row: two token pairs, each inside one row (ws even), 4-byte stores
@@ -288,9 +340,7 @@ __device__ __forceinline__ void epilogue_lds(float* epi, const f32x16 (&acc)[TI]
 #pragma unroll
     for (int k = 0; k < ITERS; ++k) {
       const int r = r0 + k * RSTEP;
-      const int row = mrow0 + r;
-      if (row >= M) continue;
-      int drow = map_row(rm, row);
+      int drow = drow_lds[r];
       if (drow < 0) continue;
       drow += row_add;
       float v[8];
@@ -409,7 +459,7 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
     const int slot = lane & 7;
     if (i < NA) {
       const int r = trow;
-      soff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 1) & 7)) << 3)) * sizeof(T));
+      soff[i] = (unsigned)(((size_t)a_row(e, min(m0 + r, M - 1)) * lda + ((slot ^ ((r >> 1) & 7)) << 3)) * sizeof(T));
     } else {
       const int r = trow - BM_;
       soff[i] = (unsigned)(((size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 1) & 7)) << 3)) * sizeof(T));
@@ -483,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
     const int slot = lane & 3;
     if (i < NA) {
       const int r = trow;
-      soff[i] = (unsigned)(((size_t)min(m0 + r, M - 1) * lda + ((slot ^ ((r >> 2) & 3)) << 3)) * sizeof(T));
+      soff[i] = (unsigned)(((size_t)a_row(e, min(m0 + r, M - 1)) * lda + ((slot ^ ((r >> 2) & 3)) << 3)) * sizeof(T));
     } else {
       const int r = trow - BM_;
       soff[i] = (unsigned)(((size_t)min(n0 + r, N - 1) * ldw + ((slot ^ ((r >> 2) & 3)) << 3)) * sizeof(T));
@@ -615,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
       const int ch = (slot ^ ((lr >> 1) & 7)) << 3;
       const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63);
       const int rw = (lr >> 5) * 64 + h * 32 + (lr & 31);
-      soff[0][h][i] = (unsigned)(((size_t)min(m0 + ra, M - 1) * lda + ch) * sizeof(T));
+      soff[0][h][i] = (unsigned)(((size_t)a_row(e, min(m0 + ra, M - 1)) * lda + ch) * sizeof(T));
       soff[1][h][i] = (unsigned)(((size_t)min(n0 + rw, N - 1) * ldw + ch) * sizeof(T));
     }
   const unsigned lds0 = lds_addr_of(smem);
@@ -761,23 +811,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
         const float4 v = *reinterpret_cast<const float4*>(&epi[c * 68 + rg * 4]);
         const float bias = e.bias ? e.bias[col] : 0.f;
         const int cv = col - e.vt_col0;
-        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
-        const int b = row / e.vt_T, t = row % e.vt_T;
-        T* rowp = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad;
-        if ((e.vt_T & 3) == 0 && row + 3 < M && (e.vt_ws == 0 || (t % e.vt_ws) <= e.vt_ws - 4)) {
-          store4v<T>(rowp + vt_slot(t, e.vt_ws), v.x + bias, v.y + bias, v.z + bias, v.w + bias);
-        } else if ((e.vt_T & 3) == 0 && row + 3 < M && e.vt_ws > 0 && (e.vt_ws & 1) == 0) {
-          store2<T>(rowp + vt_slot(t, e.vt_ws), v.x + bias, v.y + bias);
-          store2<T>(rowp + vt_slot(t + 2, e.vt_ws), v.z + bias, v.w + bias);
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int j = 0; j < 4; ++j) {
-            const int rj = row + j;
-            if (rj >= M) break;
-            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
-            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(tj2, e.vt_ws)] = (T)(vv[j] + bias);
-          }
-        }
+        int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (row + j < M) ? map_row(rm, row + j) : -1;
+        vt_store4<T>(vt, e, d, cv / e.vt_hd, cv % e.vt_hd, v, bias);
       }
       continue;
     }
@@ -1152,8 +1189,11 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                lda, ldw);
   LA_CHECK_ARG(epi->out32 || epi->out16 || epi->vt, "la_gemm: no output");
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_gemm: bad dtype %d", dt);
+  LA_CHECK_ARG(epi->amap == LA_MAP_NONE || (epi->amap == LA_MAP_WINDOW_PART && epi->map == LA_MAP_NONE && dt != LA_F32),
+               "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
+               epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool skinny = (M <= 32) && (K % 8) == 0 && epi->map == LA_MAP_NONE && !epi->vt;
+  const bool skinny = (M <= 32) && (K % 8) == 0 && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && !epi->vt;
   if (skinny) {
     if (dt == LA_F32) la::launch_skinny<float>(A, lda, W, ldw, M, N, K, *epi, st);
     else if (dt == LA_F16) la::launch_skinny<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);

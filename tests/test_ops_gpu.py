@@ -413,3 +413,45 @@ def test_attention_128_wide_heads_all_modes(L, dt, hd_true):
             L.attn_fwd(qkv, vt16, out3, None, None, b, heads, t, tp16, g, e, scale, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw)
             torch.cuda.synchronize()
             assert rel_err(out3, ref) < TOL16[dt], f"WIN16, G={g}"
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 20, 20, 8, 256), (1, 64, 64, 14, 768), (3, 9, 13, 4, 128)])
+def test_gemm_window_partition_output_and_gather(L, dt, shape):
+    """LA_MAP_WINDOW_PART as output map (qkv of a window block: image-order tokens in, window-ordered q/k rows and V^T in
+    16-slot order out, padded tokens untouched) and as source map (proj: window-ordered rows gathered back to image order)."""
+    b, h, w, ws, e = shape
+    heads = e // 64
+    nwy, nwx = -(-h // ws), -(-w // ws)
+    nb, t = b * nwy * nwx, ws * ws
+    rows, arows = b * h * w, nb * t
+    x = rnd(rows, e, seed=80).to(dt)
+    wqkv = (rnd(3 * e, e, seed=81) / math.sqrt(e)).to(dt)
+    bias = rnd(3 * e, seed=82) * 0.1
+    tpad = (16 * ws + 63) // 64 * 64
+    fill = 7.0
+    qkv = torch.full((arows, 3 * e), fill, device="cuda", dtype=dt)
+    vt = torch.full((nb * heads, 64, tpad), fill, device="cuda", dtype=dt)
+    L.gemm(x, wqkv, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=ws,
+           map=L.MAP_WINDOW_PART, p=(ws, nwy, nwx, h, w))
+    torch.cuda.synchronize()
+    ref = (x.float() @ wqkv.float().t() + bias).view(b, h, w, 3 * e)
+    # reference window partition with padding (image_encoder.py:258-279); padded positions keep the fill value
+    pad = torch.full((b, nwy * ws, nwx * ws, 3 * e), fill, device="cuda")
+    pad[:, :h, :w] = ref
+    win = pad.view(b, nwy, ws, nwx, ws, 3 * e).permute(0, 1, 3, 2, 4, 5).reshape(arows, 3 * e)
+    assert rel_err(qkv[:, : 2 * e], win[:, : 2 * e]) < TOL16[dt]
+    v = win[:, 2 * e:].view(nb, ws, ws, heads, 64).permute(0, 3, 4, 1, 2)                      # (nb, heads, 64, kh, kw)
+    slots = vt.view(nb, heads, 64, tpad)[..., : 16 * ws].reshape(nb, heads, 64, ws, 16)
+    assert rel_err(slots[..., :ws], v) < TOL16[dt]
+    assert bool((slots[..., ws:] == fill).all()) and bool((vt.view(nb, heads, 64, tpad)[..., 16 * ws:] == fill).all())
+    assert bool((qkv[:, 2 * e:] == fill).all())                                                # V columns only go to vt
+    # gather: rows of a window-ordered activation back in image order, with bias + residual like the proj GEMM
+    ao = rnd(arows, e, seed=83).to(dt)
+    wp = (rnd(e, e, seed=84) / math.sqrt(e)).to(dt)
+    res = rnd(rows, e, seed=85)
+    out = torch.zeros(rows, e, device="cuda")
+    L.gemm(ao, wp, bias=bias[:e].contiguous(), res=res, out32=out, M=rows, amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwx, h, w))
+    torch.cuda.synchronize()
+    merged = ao.float().view(b, nwy, nwx, ws, ws, e).permute(0, 1, 3, 2, 4, 5).reshape(b, nwy * ws, nwx * ws, e)[:, :h, :w].reshape(rows, e)
+    assert rel_err(out, merged @ wp.float().t() + bias[:e] + res) < TOL16[dt]
