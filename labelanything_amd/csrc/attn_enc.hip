@@ -124,7 +124,7 @@ struct AttnArgs {
 // 4 NH MFMA k-slices and O^T 2 NH accumulator tiles.  (Heads that are not a multiple of 64 wide - SAM ViT-H has 80 - are
 // zero-padded to the next multiple by the host when the weights are packed.)
 template <typename T, int MODE, int NH>
-__global__ __launch_bounds__(256, ((MODE == 4 && NH == 1) ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
   constexpr int HDT = 64 * NH, KS = 4 * NH, SUB = 64 * 64 * 2, KVS = KV_STAGE * NH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256, ((MODE == 4 && NH == 1) ? 3 : 2)) void attn_fw
     // windows in 16-wide slot order: U tables as in MODE 3, then the bias of score register (t, r) in tile j is
     //   bh4[2t + (r >> 3)]  (key row 4j + 2t + (r>>3))  +  bw8[((r >> 2) & 1) * 4 + (r & 3)]  (key column 8((r>>2)&1) + 4fh + (r&3)),
     // with padded rows / columns carrying NEG_BIG (no separate masking pass).
+    // One 32 x 33 table per wave, used twice: first for U_w (only needed to pick the lane's 8 column terms bw8), then
+    // overwritten with U_h, which the key loop reads - 48.5 KiB per workgroup, three workgroups per CU.
     const int G = a.G, nrel = 2 * G - 1;
-    my_bh = bias_lds + wave * 2 * 32 * 33;
-    my_bw = my_bh + 32 * 33;
+    my_bh = bias_lds + wave * 32 * 33;
     const T* th = reinterpret_cast<const T*>(a.tabh) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
     const T* tw = reinterpret_cast<const T*>(a.tabw) + (size_t)min(fr, nrel - 1) * HDT + fh * 8;
     f32x16 uh, uw;
@@ -205,18 +206,18 @@ __global__ __launch_bounds__(256, ((MODE == 4 && NH == 1) ? 3 : 2)) void attn_fw
       uw = Half16<T>::mfma32(*reinterpret_cast<const uint4*>(tw + ks * 16), qf[ks], uw);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-      my_bh[fr * 33 + row] = uh[r] * inv_scale;
-      my_bw[fr * 33 + row] = uw[r] * inv_scale;
-    }
+    for (int r = 0; r < 16; ++r) my_bh[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = uw[r] * inv_scale;
     __builtin_amdgcn_wave_barrier();
     const int qx = qc % G;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int kw = 8 * (i >> 2) + 4 * fh + (i & 3);
-      bw8[i] = (kw < G) ? my_bw[fr * 33 + qx + G - 1 - kw] : NEG_BIG;
+      bw8[i] = (kw < G) ? my_bh[fr * 33 + qx + G - 1 - kw] : NEG_BIG;
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my_bh[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = uh[r] * inv_scale;
+    __builtin_amdgcn_wave_barrier();
   } else if (MODE == 4) {
     // G == 64, terms computed in-kernel.  The wave's 32 queries share the image row y and cover columns x0 .. x0+31.
     //   relw[q][kw] = q . Rw[x - kw + 63] = Uw[(x - x0) + 63 - kw][q],  Uw[i][q] = Rw[x0 + i] . q,  i < 96   (12 MFMAs)
@@ -740,7 +741,7 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
   } else if (mode == LA_ATTN_RELPOS_WIN16) {
     LA_CHECK_ARG(tabh && tabw && G > 0 && G <= 16 && G * G == T && Tpad >= 16 * G,
                  "la_attn_fwd: WIN16 needs the tables, T == G*G, G <= 16 and Tpad >= 16*G (T=%d G=%d Tpad=%d)", T, G, Tpad);
-    const size_t lds = kv + 4 * 2 * 32 * 33 * sizeof(float);
+    const size_t lds = kv + 4 * 32 * 33 * sizeof(float);
     if (dt == LA_F16) la::launch_attn<la::f16_t, 5>(a, lds, st);
     else la::launch_attn<la::bf16_t, 5>(a, lds, st);
   } else if (mode == LA_ATTN_RELPOS) {
