@@ -150,8 +150,9 @@ int la_mask_embed(const float* masks, const int* flags, int P, int C, int Hm, in
 int la_attn_small(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int B, int Nq, int Nk, int heads,
                   int hd, void* out16, float* out32, int ldo, int dt, void* stream);
 
-/* Mean over the hw rows of each [hw, D] slab: x fp32 [P, hw, D] -> out fp32 [P, D] (prompt_encoder.py:735-736). */
-int la_colmean(const float* x, int P, int hw, int D, float* out, void* stream);
+/* Mean over the hw rows of each [hw, D] slab: x fp32 [P, hw, D] -> out fp32 [P, D] (prompt_encoder.py:735-736).
+ * scratch: fp32 [P, 16, D] workspace for the per-chunk partial sums (deterministic two-pass reduction). D % 4 == 0. */
+int la_colmean(const float* x, int P, int hw, int D, float* out, float* scratch, void* stream);
 
 /* Class prototypes: masked mean over supports, divisor clamped to >= 1 (prompt_encoder.py:738-745).
  * emb fp32 [B,M,C,D], flags u8 [B,M,C] -> out fp32 [B,C,D]. */

@@ -180,8 +180,12 @@ def attn_small(q, k, v, b: int, nq: int, nk: int, heads: int, hd: int, *, out16=
                                C.c_int(o.stride(0)), C.c_int(dt), _stream()), "la_attn_small")
 
 
-def colmean(x, p: int, hw: int, d: int, out) -> None:
-    _check(lib().la_colmean(_ptr(x), C.c_int(p), C.c_int(hw), C.c_int(d), _ptr(out), _stream()), "la_colmean")
+COLMEAN_SPLIT = 16
+
+
+def colmean(x, p: int, hw: int, d: int, out, scratch) -> None:
+    """scratch: fp32 [p, COLMEAN_SPLIT, d]."""
+    _check(lib().la_colmean(_ptr(x), C.c_int(p), C.c_int(hw), C.c_int(d), _ptr(out), _ptr(scratch), _stream()), "la_colmean")
 
 
 def class_mean(emb, flags_u8, b: int, m: int, c: int, d: int, out) -> None:

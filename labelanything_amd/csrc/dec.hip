@@ -338,21 +338,41 @@ __global__ __launch_bounds__(256) void attn_manykeys_kernel(SmallAttnArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // pooling / prototypes / classification
 // ---------------------------------------------------------------------------------------------------------
-// mean over the hw rows of each [hw, D] slab (adaptive_avg_pool1d, prompt_encoder.py:735-736)
-__global__ __launch_bounds__(1024) void colmean_kernel(const float* __restrict__ x, int hw, int D, float* __restrict__ out) {
-  __shared__ float part[16][64];
-  const int p = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  float s = 0.f;
-  if (d < D)
-    for (int r = rg; r < hw; r += 16) s += x[((size_t)p * hw + r) * D + d];
-  part[rg][threadIdx.x & 63] = s;
+// mean over the hw rows of each [hw, D] slab (adaptive_avg_pool1d, prompt_encoder.py:735-736).  Few slabs (P = pairs), long
+// columns: the rows of a slab are split over COLMEAN_SPLIT workgroups whose partial sums go to a scratch row each and are
+// folded in a fixed order by the last pass (deterministic - no float atomics), so the whole GPU streams the slab.
+constexpr int COLMEAN_SPLIT = 16;
+__global__ __launch_bounds__(256) void colmean_partial_kernel(const float* __restrict__ x, int hw, int D, float* __restrict__ part) {
+  __shared__ float4 red[256];
+  const int p = blockIdx.y, chunk = blockIdx.x;
+  const int nv = D >> 2;                                   // float4 columns
+  const int lanes = min(nv, 256), groups = 256 / lanes;    // threads per row, rows in flight (D % 4 == 0, D <= 1024)
+  const int c = threadIdx.x % lanes, g = threadIdx.x / lanes;
+  const int r0 = (int)((long)hw * chunk / COLMEAN_SPLIT), r1 = (int)((long)hw * (chunk + 1) / COLMEAN_SPLIT);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < groups)
+    for (int r = r0 + g; r < r1; r += groups) {
+      const float4 v = reinterpret_cast<const float4*>(x + ((size_t)p * hw + r) * D)[c];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[threadIdx.x] = s;
   __syncthreads();
-  if (rg == 0 && d < D) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t += part[i][threadIdx.x & 63];
-    out[(size_t)p * D + d] = t / (float)hw;
+  if (g == 0) {
+    for (int i = 1; i < groups; ++i) {
+      const float4 v = red[i * lanes + c];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(part + ((size_t)p * COLMEAN_SPLIT + chunk) * D)[c] = s;
   }
+}
+__global__ __launch_bounds__(256) void colmean_final_kernel(const float* __restrict__ part, int P, int hw, int D, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P * D) return;
+  const int p = i / D, d = i % D;
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < COLMEAN_SPLIT; ++k) t += part[((size_t)p * COLMEAN_SPLIT + k) * D + d];
+  out[i] = t / (float)hw;
 }
 
 // class prototypes = masked mean over the M supports, divisor clamped to >= 1 (prompt_encoder.py:738-745)
@@ -530,9 +550,11 @@ extern "C" int la_attn_small(const float* q, int ldq, const float* k, int ldk, c
   return 0;
 }
 
-extern "C" int la_colmean(const float* x, int P, int hw, int D, float* out, void* stream) {
-  LA_CHECK_ARG(x && out && P > 0 && hw > 0 && D > 0, "la_colmean: bad arguments");
-  hipLaunchKernelGGL(colmean_kernel, dim3((D + 63) / 64, P), dim3(1024), 0, (hipStream_t)stream, x, hw, D, out);
+extern "C" int la_colmean(const float* x, int P, int hw, int D, float* out, float* scratch, void* stream) {
+  LA_CHECK_ARG(x && out && scratch && P > 0 && hw > 0 && D > 0 && (D % 4) == 0 && D <= 1024, "la_colmean: bad arguments (D=%d must be a multiple of 4, <= 1024)", D);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colmean_partial_kernel, dim3(COLMEAN_SPLIT, P), dim3(256), 0, st, x, hw, D, scratch);
+  hipLaunchKernelGGL(colmean_final_kernel, dim3((P * D + 255) / 256), dim3(256), 0, st, scratch, P, hw, D, out);
   LA_CHECK_LAUNCH("la_colmean");
   return 0;
 }

@@ -616,7 +616,7 @@ class LamEngine:
                          self.ddti)
         self.two_way(pe_ + ".transformer", sp, pcount, ns, src32, src16, srcpe16, hw, pe32, "pe.tw", want_tokens=False)
         emb = self.f32("pe.emb", (pcount, d))
-        L.colmean(src32, pcount, hw, d, emb)
+        L.colmean(src32, pcount, hw, d, emb, self.f32("pe.colmean.part", (pcount, L.COLMEAN_SPLIT, d)))
         if cfg.class_attention:
             emb = self.attention_mlp_block(pe_ + ".class_attention", emb, b * m, c, "pe.ca")
         if cfg.example_attention:
