@@ -188,6 +188,18 @@ int la_confmat_update(const long long* pred, const long long* gt, int B, long HW
                       long long ignore_index, unsigned long long* confmat, unsigned long long* confbin,
                       unsigned long long* counters, void* stream);
 
+/* Image preprocessing on the device (the step before the path; data/transforms.py:14-46 via torchvision -> PIL).
+ * la_resample_u8: ONE axis of PIL's antialiased 8-bit resample (Image.resize, BILINEAR): in u8 [n_outer, in_size, inner] ->
+ * out u8 [n_outer, out_size, inner]; bounds int32 [out_size, 2] = (first tap, tap count), kk int32 [out_size, ksize] =
+ * coefficients with 22 fractional bits, both computed on the host exactly like PIL's precompute_coeffs /
+ * normalize_coeffs_8bpc.  Horizontal pass: (n_outer, in_size, inner) = (H, W, C); vertical: (1, H, W*C).  Bit-exact with PIL.
+ * la_u8_to_chw_norm: u8 HWC [h, w, 3] -> fp32 CHW [3, SH, SW]: ToTensor (x / 255), (x - mean) / std, zero padding on the
+ * right / bottom (CustomNormalize); mean3 / std3 are HOST pointers. */
+int la_resample_u8(const unsigned char* in, long n_outer, int in_size, int inner, int out_size, const int* bounds, const int* kk,
+                   int ksize, unsigned char* out, void* stream);
+int la_u8_to_chw_norm(const unsigned char* in, int h, int w, int SH, int SW, const float* mean3, const float* std3, float* out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ from PIL import Image
 from safetensors.torch import load_file, save_file
 
 from labelanything_amd.config import ENCODER_SPECS, EncoderSpec, LamConfig, register_encoder
+from labelanything_amd.image_prep import DevicePreprocessor
 from labelanything_amd.models import Lam, _hf5_to_hf4
 
 IMAGENET_DEFAULT = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])      # data/utils.py "default"
@@ -74,8 +75,12 @@ def _run(lam: Lam, directory: str, outfolder: str, last_block_dir: Optional[str]
         os.makedirs(last_block_dir, exist_ok=True)
     files = list_images(directory)
     n_done = 0
+    prep = DevicePreprocessor(side, custom_preprocess, mean, std, square, device=lam.engine().dev)
     for step, names in enumerate(_batches(files, batch_size)):
-        imgs = [load_image(os.path.join(directory, f), side, custom_preprocess, mean, std, square) for f in names]
+        # decode on the host, resize / normalise / pad on the device (bit-identical to load_image, which stays as the
+        # CPU statement of the reference's transform chain)
+        imgs = [prep(torch.from_numpy(np.asarray(Image.open(os.path.join(directory, f)).convert("RGB"), dtype=np.uint8).copy()))
+                for f in names]
         if len({tuple(i.shape) for i in imgs}) != 1:
             raise ValueError("images of one batch must share a size (use --custom_preprocess or --batch_size 1)")
         x = torch.stack(imgs)

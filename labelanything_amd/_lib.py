@@ -58,7 +58,7 @@ EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
-    "la_confmat_update",
+    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm",
 ]
 
 
@@ -244,6 +244,20 @@ def confmat_update(pred_i64, gt_i64, lut_i32, k: int, ignore_index: int, confmat
     _check(lib().la_confmat_update(_ptr(pred_i64), _ptr(gt_i64), C.c_int(b), C.c_long(hw), _ptr(lut_i32), C.c_int(ell), C.c_int(k),
                                    C.c_longlong(ignore_index), _ptr(confmat_u64), _ptr(confbin_u64), _ptr(counters_u64), _stream()),
            "la_confmat_update")
+
+
+def resample_u8(inp, n_outer: int, in_size: int, inner: int, out_size: int, bounds_i32, kk_i32, out) -> None:
+    _dev(inp)
+    _check(lib().la_resample_u8(_ptr(inp), C.c_long(n_outer), C.c_int(in_size), C.c_int(inner), C.c_int(out_size), _ptr(bounds_i32),
+                                _ptr(kk_i32), C.c_int(kk_i32.shape[1]), _ptr(out), _stream()), "la_resample_u8")
+
+
+def u8_to_chw_norm(inp, h: int, w: int, sh: int, sw: int, mean, std, out) -> None:
+    _dev(inp)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    _check(lib().la_u8_to_chw_norm(_ptr(inp), C.c_int(h), C.c_int(w), C.c_int(sh), C.c_int(sw), m3, s3, _ptr(out), _stream()),
+           "la_u8_to_chw_norm")
 
 
 def conv3x3_f32(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out32) -> None:

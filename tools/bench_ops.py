@@ -89,6 +89,21 @@ def main():
         m = SegmentationMeter(k)
         t = timeit(lambda: m.update(pred, gt))
         print(f"confmat 8x1024x1024 K=81 {name}: {t*1e6:8.1f} us  {gt.numel()*16/t/1e9:7.1f} GB/s")
+    # image preprocessing: COCO-size uint8 image -> 1024-long-side resize (PIL-exact) -> normalise -> pad, vs PIL + torch on the host
+    import numpy as np
+    import time
+    from PIL import Image
+    from labelanything_amd.image_prep import DevicePreprocessor
+    img = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    dp = DevicePreprocessor(1024, True, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], square=False)
+    dimg = torch.from_numpy(img).cuda()
+    t = timeit(lambda: dp(dimg))
+    t0 = time.perf_counter()
+    for _ in range(10):
+        x = torch.from_numpy(np.asarray(Image.fromarray(img).resize((1024, 768), Image.BILINEAR)).copy()).permute(2, 0, 1).float() / 255.0
+        x = torch.nn.functional.pad((x - torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1), (0, 0, 0, 256))
+    tc = (time.perf_counter() - t0) / 10
+    print(f"image prep 480x640 -> 3x1024x1024: device {t*1e6:8.1f} us ({(480*640*3 + 3*1024*1024*4)/t/1e9:6.1f} GB/s)   PIL + torch on one host core {tc*1e3:6.1f} ms")
 
 
 if __name__ == "__main__":
