@@ -200,6 +200,14 @@ int la_resample_u8(const unsigned char* in, long n_outer, int in_size, int inner
 int la_u8_to_chw_norm(const unsigned char* in, int h, int w, int SH, int SW, const float* mean3, const float* std3, float* out,
                       void* stream);
 
+/* PromptsProcessor.apply_masks + the mask branch of annotations_to_tensor (data/transforms.py:203-224, data/utils.py:219-223)
+ * for P prompt slots that share one image geometry: slot p ORs the instance masks index[first[p] .. first[p] + count[p])
+ * (u8 [n, H, W], non-zero = set), resizes nearest to (nh, nw), zero-pads to S x S and resizes nearest to Mo x Mo (torch
+ * "nearest" index rule); nh == 0 skips the first resize + pad (custom_preprocess off).  out fp32 [P, Mo, Mo] in {0, 1};
+ * flags u8 [P] (zeroed by the caller) is set to 1 where the slot's result has a set pixel. */
+int la_prompt_masks(const unsigned char* masks, const int* first, const int* count, const int* index, int P, int H, int W, int nh,
+                    int nw, int S, int Mo, float* out, unsigned char* flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,7 @@ EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
-    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm",
+    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks",
 ]
 
 
@@ -250,6 +250,12 @@ def resample_u8(inp, n_outer: int, in_size: int, inner: int, out_size: int, boun
     _dev(inp)
     _check(lib().la_resample_u8(_ptr(inp), C.c_long(n_outer), C.c_int(in_size), C.c_int(inner), C.c_int(out_size), _ptr(bounds_i32),
                                 _ptr(kk_i32), C.c_int(kk_i32.shape[1]), _ptr(out), _stream()), "la_resample_u8")
+
+
+def prompt_masks(masks_u8, first_i32, count_i32, index_i32, p: int, h: int, w: int, nh: int, nw: int, s: int, mo: int, out, flags_u8) -> None:
+    _dev(masks_u8)
+    _check(lib().la_prompt_masks(_ptr(masks_u8), _ptr(first_i32), _ptr(count_i32), _ptr(index_i32), C.c_int(p), C.c_int(h), C.c_int(w),
+                                 C.c_int(nh), C.c_int(nw), C.c_int(s), C.c_int(mo), _ptr(out), _ptr(flags_u8), _stream()), "la_prompt_masks")
 
 
 def u8_to_chw_norm(inp, h: int, w: int, sh: int, sw: int, mean, std, out) -> None:

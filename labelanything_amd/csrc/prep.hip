@@ -50,7 +50,63 @@ __global__ __launch_bounds__(256) void u8_to_chw_norm_kernel(const unsigned char
   }
 }
 
+// torch "nearest" source index (ATen UpSampleKernel nearest_idx): identity / exact halving shortcuts, else
+// min(floorf(dst * (float)in / out), in - 1) in fp32
+__device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
+  if (out_size == in_size) return dst;
+  if (out_size == 2 * in_size) return dst >> 1;
+  const float scale = (float)in_size / (float)out_size;
+  return min((int)floorf((float)dst * scale), in_size - 1);
+}
+
+// PromptsProcessor.apply_masks (data/transforms.py:203-224) for P prompt slots at once: OR of the slot's instance masks
+// (u8 [H, W] each, listed by [first, first + count) in `index`), nearest resize to (nh, nw), zero pad to S x S, nearest resize
+// to Mo x Mo - composed per output pixel.  nh == 0: no custom preprocessing (one resize (H, W) -> (Mo, Mo)).
+// out fp32 [P, Mo, Mo] in {0, 1}; flags u8 [P] = any pixel set (annotations_to_tensor, data/utils.py:219-223).
+__global__ __launch_bounds__(256) void prompt_mask_kernel(const unsigned char* __restrict__ masks, const int* __restrict__ first,
+                                                          const int* __restrict__ count, const int* __restrict__ index, int H, int W, int nh,
+                                                          int nw, int S, int Mo, float* __restrict__ out, unsigned char* __restrict__ flags) {
+  const int p = blockIdx.y;
+  const int f = first[p], n = count[p];
+  __shared__ int any_set;
+  if (threadIdx.x == 0) any_set = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Mo * Mo; i += gridDim.x * 256) {
+    const int ox = i % Mo, oy = i / Mo;
+    int sy, sx;
+    bool inside = true;
+    if (nh > 0) {
+      const int py = nearest_src(oy, S, Mo), px = nearest_src(ox, S, Mo);      // position on the padded S x S canvas
+      inside = py < nh && px < nw;
+      sy = nearest_src(min(py, nh - 1), H, nh);
+      sx = nearest_src(min(px, nw - 1), W, nw);
+    } else {
+      sy = nearest_src(oy, H, Mo);
+      sx = nearest_src(ox, W, Mo);
+    }
+    int v = 0;
+    if (inside)
+      for (int k = 0; k < n && !v; ++k) v = masks[((size_t)index[f + k] * H + sy) * W + sx] != 0;
+    out[(size_t)p * Mo * Mo + i] = (float)v;
+    mine |= v;
+  }
+  if (mine) atomicOr(&any_set, 1);
+  __syncthreads();
+  if (threadIdx.x == 0 && any_set) flags[p] = 1;        // flags are zeroed by the caller; several blocks may set the same 1
+}
+
 }  // namespace la
+
+extern "C" int la_prompt_masks(const unsigned char* masks, const int* first, const int* count, const int* index, int P, int H, int W, int nh,
+                               int nw, int S, int Mo, float* out, unsigned char* flags, void* stream) {
+  LA_CHECK_ARG(masks && first && count && index && out && flags, "la_prompt_masks: null pointer");
+  LA_CHECK_ARG(P > 0 && H > 0 && W > 0 && Mo > 0 && (nh == 0 || (nh > 0 && nw > 0 && S >= nh && S >= nw)), "la_prompt_masks: bad geometry");
+  hipLaunchKernelGGL(la::prompt_mask_kernel, dim3(16, P), dim3(256), 0, (hipStream_t)stream, masks, first, count, index, H, W, nh, nw, S, Mo, out,
+                     flags);
+  LA_CHECK_LAUNCH("la_prompt_masks");
+  return 0;
+}
 
 extern "C" int la_resample_u8(const unsigned char* in, long n_outer, int in_size, int inner, int out_size, const int* bounds, const int* kk,
                               int ksize, unsigned char* out, void* stream) {

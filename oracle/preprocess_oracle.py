@@ -45,3 +45,23 @@ def resize_numpy(img_u8: np.ndarray, nh: int, nw: int) -> np.ndarray:
     h, w = img_u8.shape[:2]
     t = _resample_axis(img_u8, nw, 1) if nw != w else img_u8
     return _resample_axis(t, nh, 0) if nh != h else t
+
+
+# ---- prompt masks (data/transforms.py:203-224) ------------------------------------------------------------------------------
+# torchvision's resize on a TENSOR with NEAREST interpolation is torch.nn.functional.interpolate(mode="nearest") on the uint8
+# tensor (torchvision/transforms/_functional_tensor.py: resize); restated with the real torch op, so this part is PINNED on
+# torch itself.
+def reference_apply_masks(masks, side: int = 1024, mask_side: int = 256, custom_preprocess: bool = True) -> torch.Tensor:
+    """masks: list of uint8 numpy arrays [H, W] (may be empty) -> uint8 tensor [1, mask_side, mask_side] (or [ms, ms] if empty)."""
+    import torch.nn.functional as F
+    if len(masks) == 0:
+        return torch.zeros((mask_side, mask_side), dtype=torch.uint8)
+    mask = torch.as_tensor(np.logical_or.reduce(masks).astype(np.uint8)).unsqueeze(0)
+
+    def nearest(t, size):
+        return F.interpolate(t.unsqueeze(0), size=size, mode="nearest")[0]
+    if custom_preprocess:
+        new_h, new_w = resize_shape(masks[0].shape[0], masks[0].shape[1], side, True, False)
+        mask = nearest(mask, (new_h, new_w))
+        mask = F.pad(mask, (0, side - new_w, 0, side - new_h))
+    return nearest(mask, (mask_side, mask_side))

@@ -44,3 +44,37 @@ def test_bad_inputs_raise():
         dp(torch.zeros(10, 10, 3))                       # not uint8
     with pytest.raises(ValueError):
         dp(torch.zeros(10, 10, 4, dtype=torch.uint8))    # not RGB
+
+
+@pytest.mark.parametrize("custom", [True, False])
+@pytest.mark.parametrize("hw", [(480, 640), (640, 427), (333, 500), (1024, 1024), (37, 53)])
+def test_prompt_masks_match_reference_apply_masks(custom, hw):
+    """OR of instance masks -> nearest resize -> pad -> nearest resize to 256 (data/transforms.py:203-224) + flag_masks."""
+    from labelanything_amd.prompts import prompt_masks_from_instances
+    rng = np.random.default_rng(hw[0] + custom)
+    n = 5
+    inst = np.zeros((n, *hw), dtype=np.uint8)
+    for i in range(n - 1):                                    # rectangles + sparse noise; the last instance stays empty
+        y0, x0 = rng.integers(0, hw[0] - 8), rng.integers(0, hw[1] - 8)
+        inst[i, y0:y0 + rng.integers(4, hw[0] - y0), x0:x0 + rng.integers(4, hw[1] - x0)] = 1
+        inst[i] |= (rng.random(hw) < 0.01).astype(np.uint8)
+    slots = [[0], [1, 2, 3], [], [4], [0, 4]]
+    got, flags = prompt_masks_from_instances(torch.from_numpy(inst).cuda(), slots, side=512, mask_side=256, custom_preprocess=custom)
+    for c, s in enumerate(slots):
+        ref = PO.reference_apply_masks([inst[i] for i in s], side=512, mask_side=256, custom_preprocess=custom).reshape(256, 256)
+        assert torch.equal(got[c].cpu(), ref.float()), f"slot {c}"
+        assert int(flags[c]) == int(ref.sum() > 0)
+    assert got.dtype == torch.float32 and flags.tolist() == [1, 1, 0, 0, 1]
+
+
+def test_coords_boxes_and_flags_merge():
+    from labelanything_amd.prompts import apply_boxes, apply_coords, flags_merge
+    pts = torch.tensor([[[10.0, 20.0], [639.0, 479.0]]])
+    out = apply_coords(pts, (480, 640), side=1024, custom_preprocess=True)
+    assert torch.allclose(out, torch.tensor([[[16.0, 32.0], [1022.4, 766.4]]]))
+    assert torch.allclose(apply_boxes(torch.tensor([[0.0, 0.0, 640.0, 480.0]]), (480, 640), 1024, False), torch.tensor([[0.0, 0.0, 1024.0, 1024.0]]))
+    fm = torch.tensor([[0, 1, 0], [0, 0, 0]], dtype=torch.uint8)
+    fp = torch.tensor([[[0, 0], [0, 0], [1, 0]], [[0, 0], [0, 0], [0, 0]]], dtype=torch.uint8)
+    assert flags_merge(fm, fp).tolist() == [[True, True, True], [True, False, False]]      # background column forced to 1
+    with pytest.raises(ValueError):
+        flags_merge()
