@@ -455,3 +455,39 @@ def test_gemm_window_partition_output_and_gather(L, dt, shape):
     torch.cuda.synchronize()
     merged = ao.float().view(b, nwy, nwx, ws, ws, e).permute(0, 1, 3, 2, 4, 5).reshape(b, nwy * ws, nwx * ws, e)[:, :h, :w].reshape(rows, e)
     assert rel_err(out, merged @ wp.float().t() + bias[:e] + res) < TOL16[dt]
+
+
+def test_gemm_shape_fuzz_all_kernel_paths(L):
+    """Seeded sweep over ragged shapes (M / N tails, every K granularity, fp32 and 16-bit, strided A) through every la_gemm
+    kernel (LA_GEMM_PATH is not forced: the dispatcher picks skinny / fallback / 128x128 / 256x128 / ping-pong by shape)."""
+    g = torch.Generator().manual_seed(1234)
+    shapes = []
+    for _ in range(36):
+        m = int(torch.randint(1, 700, (1,), generator=g))
+        n = int(torch.randint(1, 80, (1,), generator=g)) * 8
+        k = int(torch.randint(1, 24, (1,), generator=g)) * [8, 32, 64][int(torch.randint(0, 3, (1,), generator=g))]
+        shapes.append((m, n, k))
+    shapes += [(33, 8, 8), (257, 136, 72), (512, 512, 2048), (1025, 264, 64), (131072, 256, 64), (65536 + 17, 384, 128),
+               (4096, 1024, 2048), (131072, 1024, 2048)]       # the last: 512 ping-pong tiles (K >= 2048) -> gemm_pp_kernel
+    for idx, (m, n, k) in enumerate(shapes):
+        for dt in (torch.float16, torch.float32):
+            if dt == torch.float32 and (m * n * k > 3e9):
+                continue
+            lda = k + (8 if idx % 3 == 0 else 0)                   # padded row stride every third case
+            a_full = rnd(m, lda, seed=100 + idx).to(dt)
+            a = a_full[:, :k]
+            w = (rnd(n, k, seed=200 + idx) / math.sqrt(k)).to(dt)
+            bias = rnd(n, seed=300 + idx)
+            use_res = idx % 2 == 0
+            res = rnd(m, n, seed=400 + idx) if use_res else None
+            act = [L.ACT_NONE, L.ACT_RELU, L.ACT_GELU][idx % 3]
+            ref = a.float() @ w.float().t() + bias
+            ref = torch.relu(ref) if act == L.ACT_RELU else (F.gelu(ref) if act == L.ACT_GELU else ref)
+            if use_res:
+                ref = ref + res
+            o32 = torch.full((m, n), float("nan"), device="cuda")
+            L.gemm(a_full, w, bias=bias, res=res, out32=o32, act=act, lda=lda) if lda != k else L.gemm(a, w, bias=bias, res=res, out32=o32, act=act)
+            torch.cuda.synchronize()
+            tol = 2e-5 if dt == torch.float32 else 1e-3
+            assert torch.isfinite(o32).all(), (m, n, k, dt)
+            assert rel_err(o32, ref) < tol, (m, n, k, dt, float(rel_err(o32, ref)))
