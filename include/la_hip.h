@@ -208,6 +208,15 @@ int la_u8_to_chw_norm(const unsigned char* in, int h, int w, int SH, int SW, con
 int la_prompt_masks(const unsigned char* masks, const int* first, const int* count, const int* index, int P, int H, int W, int nh,
                     int nw, int S, int Mo, float* out, unsigned char* flags, void* stream);
 
+/* Training objective, first link: the focal term of LabelAnythingLoss with class weighting (loss/__init__.py:67-89,
+ * loss/focal.py:17-26, loss/utils.py:17-43) fused with its gradient.  logits fp32 [B, C, HW] (-inf padding allowed where the
+ * target is ignore_index), target int64 [B, HW]; loss fp32 [1] = scale * mean over ALL B*HW pixels of (1 - pt)^gamma * w[t] * ce;
+ * dlogits fp32 [B, C, HW] or NULL; class_weights fp32 [C] or NULL (the per-batch weights 1 / log(1.1 + share), 1 for absent
+ * classes; all 1 when class_weighting == 0).  scratch: device workspace, (C + 1) * 8 + 2048 * 8 bytes. */
+int la_focal_loss(const float* logits, const long long* target, int B, int C, long HW, float gamma, int class_weighting, float scale,
+                  long long ignore_index, float* loss, float* dlogits, float* class_weights, void* scratch, long scratch_bytes,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,7 @@ EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
-    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks",
+    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss",
 ]
 
 
@@ -256,6 +256,16 @@ def prompt_masks(masks_u8, first_i32, count_i32, index_i32, p: int, h: int, w: i
     _dev(masks_u8)
     _check(lib().la_prompt_masks(_ptr(masks_u8), _ptr(first_i32), _ptr(count_i32), _ptr(index_i32), C.c_int(p), C.c_int(h), C.c_int(w),
                                  C.c_int(nh), C.c_int(nw), C.c_int(s), C.c_int(mo), _ptr(out), _ptr(flags_u8), _stream()), "la_prompt_masks")
+
+
+def focal_loss(logits, target_i64, gamma: float, class_weighting: bool, scale: float, ignore_index: int, loss, dlogits, class_weights,
+               scratch) -> None:
+    _dev(logits)
+    b, c = logits.shape[0], logits.shape[1]
+    hw = logits.numel() // (b * c)
+    _check(lib().la_focal_loss(_ptr(logits), _ptr(target_i64), C.c_int(b), C.c_int(c), C.c_long(hw), C.c_float(gamma), C.c_int(int(class_weighting)),
+                               C.c_float(scale), C.c_longlong(ignore_index), _ptr(loss), _ptr(dlogits), _ptr(class_weights), _ptr(scratch),
+                               C.c_long(scratch.numel() * scratch.element_size()), _stream()), "la_focal_loss")
 
 
 def u8_to_chw_norm(inp, h: int, w: int, sh: int, sw: int, mean, std, out) -> None:
