@@ -217,6 +217,12 @@ int la_focal_loss(const float* logits, const long long* target, int B, int C, lo
                   long long ignore_index, float* loss, float* dlogits, float* class_weights, void* scratch, long scratch_bytes,
                   void* stream);
 
+/* One torch.optim.AdamW step on flat fp32 buffers of n elements (experiment/utils.py:53-76; decoupled weight decay, bias
+ * correction with the 1-based `step`), gradients scaled by grad_scale first (1 / world size after the data-parallel SUM
+ * all-reduce). */
+int la_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

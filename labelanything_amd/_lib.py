@@ -58,7 +58,7 @@ EXPORTS = [
     "la_gemm", "la_layernorm", "la_im2col_patch", "la_im2col_3x3", "la_relpos_terms", "la_attn_fwd",
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
-    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss",
+    "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
 ]
 
 
@@ -266,6 +266,17 @@ def focal_loss(logits, target_i64, gamma: float, class_weighting: bool, scale: f
     _check(lib().la_focal_loss(_ptr(logits), _ptr(target_i64), C.c_int(b), C.c_int(c), C.c_long(hw), C.c_float(gamma), C.c_int(int(class_weighting)),
                                C.c_float(scale), C.c_longlong(ignore_index), _ptr(loss), _ptr(dlogits), _ptr(class_weights), _ptr(scratch),
                                C.c_long(scratch.numel() * scratch.element_size()), _stream()), "la_focal_loss")
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+               grad_scale: float = 1.0) -> None:
+    _dev(params)
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != params.numel():
+            raise ValueError("adamw_step: flat contiguous fp32 buffers of equal length expected")
+    _check(lib().la_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_long(params.numel()), C.c_float(lr),
+                               C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), C.c_int(step),
+                               C.c_float(grad_scale), _stream()), "la_adamw_step")
 
 
 def u8_to_chw_norm(inp, h: int, w: int, sh: int, sw: int, mean, std, out) -> None:

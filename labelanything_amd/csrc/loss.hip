@@ -9,6 +9,8 @@
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
+#pragma clang fp contract(off)
+
 namespace la {
 
 constexpr int FL_MAXC = 64;
@@ -115,5 +117,43 @@ extern "C" int la_focal_loss(const float* logits, const long long* target, int B
                      ignore_index, counts, class_weights, dlogits, partial);
   hipLaunchKernelGGL(la::focal_fold_kernel, dim3(1), dim3(64), 0, st, partial, blocks, n, scale, loss);
   LA_CHECK_LAUNCH("la_focal_loss");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AdamW step on a flat fp32 parameter buffer (torch.optim.AdamW, the reference's optimizer: experiment/utils.py:53-76,
+// mae_noembs.yaml:32-33), same update order as torch's single-tensor path:
+//   p *= 1 - lr * wd;  m += (g - m) * (1 - b1);  v = v * b2 + (1 - b2) * g * g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// g is multiplied by grad_scale first (1 / world size after the SUM all-reduce of the data-parallel ranks).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace la {
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float grad_scale) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + ((1.0f - b2) * gi) * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+}  // namespace la
+
+extern "C" int la_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  LA_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "la_adamw_step: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(la::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+  LA_CHECK_LAUNCH("la_adamw_step");
   return 0;
 }

@@ -1,0 +1,69 @@
+"""Optimizer side of training: the reference trains with ``torch.optim.AdamW`` (defaults, lr 5e-5) and
+HF's ``constant_with_warmup`` schedule (``experiment/utils.py:53-100``, ``parameters/trainval/coco20i/mae_noembs.yaml:32-37``)
+under DDP, i.e. one gradient all-reduce per optimizer step.  Here the learnable parameters live in ONE flat fp32 buffer (the
+model's tensors become views of it), so a step is: one SUM all-reduce of the flat gradient over RCCL (``sum_over_ranks``) + one
+``la_adamw_step`` launch that also applies the 1 / world scaling.  The backward pass that would fill the gradient is not built.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from . import _lib as L
+from .parallel import sum_over_ranks
+
+
+def constant_with_warmup(step: int, num_warmup_steps: int) -> float:
+    """lr multiplier of transformers' ``get_constant_schedule_with_warmup`` after ``step`` scheduler steps."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1.0, num_warmup_steps))
+    return 1.0
+
+
+class FlatAdamW:
+    def __init__(self, params: Iterable[torch.Tensor], lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 num_warmup_steps: int = 0):
+        self.params: List[torch.Tensor] = [p for p in params]
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda" or any(p.dtype != torch.float32 or p.device != dev for p in self.params):
+            raise RuntimeError("FlatAdamW needs fp32 device parameters (there is no CPU path)")
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=dev)
+        self.grad = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        off = 0
+        self.views, self.grad_views = [], []
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            view = self.flat[off:off + k].view_as(p)
+            p.data = view                                    # the model now reads / the optimizer writes the same storage
+            self.views.append(view)
+            self.grad_views.append(self.grad[off:off + k].view_as(p))
+            off += k
+        self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.num_warmup_steps = int(num_warmup_steps)
+        self.steps = 0                 # optimizer steps taken
+        self.sched_steps = 0           # scheduler steps taken (the reference steps it per batch: mae_noembs.yaml:36)
+
+    @property
+    def lr(self) -> float:
+        return self.base_lr * constant_with_warmup(self.sched_steps, self.num_warmup_steps) if self.num_warmup_steps else self.base_lr
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def step(self, all_reduce: bool = True) -> None:
+        """Average ``self.grad`` over the data-parallel ranks (if a process group is up) and apply one AdamW update."""
+        world = 1
+        if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            sum_over_ranks(self.grad)
+        self.steps += 1
+        L.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                     self.steps, 1.0 / world)
+        self.sched_steps += 1

@@ -92,3 +92,32 @@ def test_confusion_matrix_all_reduce_two_ranks():
         expect = expect + MO.confusion_matrix(pp, gg, 4)
     assert res[0][1] == res[1][1] == expect.tolist()
     assert abs(res[0][2]["mIoU"] - MO.strict_mean_iou(expect)) < 1e-6
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from labelanything_amd.parallel import sum_over_ranks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7 + rank)
+    flat_grad = torch.randn(1000, generator=g)            # what FlatAdamW.grad holds after a backward pass
+    sum_over_ranks(flat_grad)
+    q.put((rank, (flat_grad / world).tolist()))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_two_ranks():
+    """SURVEY 8e, training: ONE all-reduce (sum, then / world) of the flat gradient buffer per optimizer step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    expect = sum(torch.randn(1000, generator=torch.Generator().manual_seed(7 + r)) for r in range(2)) / 2
+    assert res[0][1] == res[1][1]
+    assert float((torch.tensor(res[0][1]) - expect).abs().max()) < 1e-6
