@@ -6,7 +6,7 @@ import torch
 from labelanything_amd import _lib as L
 which = sys.argv[1] if len(sys.argv) > 1 else "lin2"
 dt = torch.float16
-shapes = {"lin2": (32768, 768, 3072), "lin1": (32768, 3072, 768), "qkv": (32768, 2304, 768)}
+shapes = {"lin2": (65536, 768, 3072), "lin1": (65536, 3072, 768), "qkv": (65536, 2304, 768)}      # 16-image encoder batch
 if which in shapes:
     m, n, k = shapes[which]
     a = torch.randn(m, k, device="cuda").to(dt)
@@ -21,7 +21,7 @@ else:
     qkv = torch.randn(b * t_, 3 * e, device="cuda").to(dt)
     vt = torch.randn(b * heads, 64, t_, device="cuda").to(dt)
     out = torch.empty(b * t_, e, device="cuda", dtype=dt)
-    relh = torch.randn(b * heads, t_, g, device="cuda"); relw = torch.randn(b * heads, t_, g, device="cuda")
-    for _ in range(5):
-        L.attn_fwd(qkv, vt, out, relh, relw, b, heads, t_, t_, g, e, 0.125, L.ATTN_RELPOS)
+    tab = torch.randn(2 * g - 1, 64, device="cuda").to(dt)
+    for _ in range(5):      # global SAM attention with the rel-pos terms computed in the kernel (the product path)
+        L.attn_fwd(qkv, vt, out, None, None, b, heads, t_, t_, g, e, 0.125, L.ATTN_RELPOS, tabh=tab, tabw=tab)
 torch.cuda.synchronize()
