@@ -585,13 +585,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   epilogue_lds<T, 4, 2, BN, NT>(reinterpret_cast<float*>(smem), acc, 2, wm, 0, wn * 64, m0, n0, M, N, e, tid);
 }
 
-static int tile_group_m() {
-  static int gm = -1;
-  if (gm < 0) {
+// row-panels per tile group (tile_coords); measured flat within +-2 % for 1..16 on the 256 x 128 / 128 x 128 kernels (default 8)
+// and ~2 % better at 1..4 for the 256 x 256 kernel (dflt = 2 there); LA_GEMM_GROUP_M overrides both
+static int tile_group_m(int dflt = 8) {
+  static int forced = -2;
+  if (forced == -2) {
     const char* v = getenv("LA_GEMM_GROUP_M");
-    gm = v ? atoi(v) : 8;
+    forced = v ? atoi(v) : -1;
   }
-  return gm;
+  return forced >= 0 ? forced : dflt;
 }
 
 template <typename T>
@@ -878,7 +880,7 @@ static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int
   }
   const int ntm = (M + PP_BM - 1) / PP_BM, ntn = (N + PP_BN - 1) / PP_BN;
   hipLaunchKernelGGL((gemm_pp_kernel<T>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
 }
 
 template <typename T, int BM_>
