@@ -610,6 +610,114 @@ static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, 
 }
 
 
+constexpr int PP_BM = 256, PP_BN = 256;
+constexpr int PP_STAGE = (PP_BM + PP_BN) * BK * 2;     // 64 KiB
+constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB half-tile
+
+// Epilogue of the 256 x 256 tile kernels (8 waves, wave (grp, wi) holds rows [128 grp, +128) x columns [64 wi, +64) as
+// acc[4][2]): four 64-row chunks staged through LDS (each wave's 128 rows span two chunks).
+template <typename T>
+__device__ __forceinline__ void epilogue_256(char* smem, const f32x16 (&acc)[4][2], int grp, int wrow, int m0, int n0, int M, int N,
+                                             const LaGemmEpilogue& e, int tid) {
+  constexpr int NT = 512;
+  const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  float* epi = reinterpret_cast<float*>(smem);
+  constexpr int LD = PP_BN + 4;
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  T* outT = reinterpret_cast<T*>(e.out16);
+  T* vt = reinterpret_cast<T*>(e.vt);
+  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk) {
+    if (chunk > 0) __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (grp * 2 + half != chunk) continue;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ti = half * 2 + t2;                 // static: accumulator row-tile of this wave
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          if (!vt_tile) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              epi[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + wrow + tj * 32 + fr] = acc[ti][tj][r];
+          } else {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
+              *reinterpret_cast<float4*>(&epi[(wrow + tj * 32 + fr) * (64 + 4) + t2 * 32 + 8 * g4 + 4 * fh]) = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int mrow0 = m0 + chunk * 64;
+    if (vt_tile) {      // transposed staging [col][64 rows + 4]: items = (col, 4-row group)
+      for (int it = tid; it < PP_BN * 16; it += NT) {
+        const int rg = it & 15, c = it >> 4;
+        const int col = n0 + c, row = mrow0 + rg * 4;
+        if (col >= N || row >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&epi[c * 68 + rg * 4]);
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const int cv = col - e.vt_col0;
+        int d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = (row + j < M) ? map_row(rm, row + j) : -1;
+        vt_store4<T>(vt, e, d, cv / e.vt_hd, cv % e.vt_hd, v, bias);
+      }
+      continue;
+    }
+    constexpr int CG = PP_BN / 8;
+    for (int it = tid; it < 64 * CG; it += NT) {
+      const int cg = it % CG, r = it / CG;
+      const int row = mrow0 + r, col0 = n0 + cg * 8;
+      if (row >= M || col0 >= N) continue;
+      float v[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8 + 4]);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      }
+      int dcol = col0, row_add = 0, bcol = col0;
+      if (e.map == LA_MAP_CONVT2X2) {
+        const int kyx = col0 / e.p2;
+        dcol = col0 % e.p2;
+        bcol = dcol;
+        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+      }
+      if (e.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (e.act == LA_ACT_GELU) {
+        if (!e.out32) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
+      } else if (e.act == LA_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      int drow = map_row(rm, row);
+      if (drow < 0) continue;
+      drow += row_add;
+      if (e.res) {
+        const int rr = e.res_mod ? drow % e.res_mod : drow;
+        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
+        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
+      if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
+    }
+  }}
+
 // =================================================================================================================
 // v6 "ping-pong": 256 x 256 x 64 tile, 8 waves = 2 groups of 4; group g owns rows [128 g, +128), wave i of a group the
 // columns [64 i, +64) -> 128 x 64 per wave (4 x 2 MFMA 32x32 accumulators).  Every SIMD hosts one wave of each group.
@@ -637,14 +745,10 @@ static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, 
 // Operand traffic per MFMA: 0.75 KiB of fragment reads + 0.25 KiB of DMA (vs 1.0 + 0.5 in the 128x128 kernel) and half
 // the L2 reads per FLOP.
 // =================================================================================================================
-constexpr int PP_BM = 256, PP_BN = 256;
-constexpr int PP_STAGE = (PP_BM + PP_BN) * BK * 2;     // 64 KiB
-constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB half-tile
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
                                                           int M, int N, int K, LaGemmEpilogue e, int gm) {
-  constexpr int NT = 512;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wi = wave & 3;
@@ -771,103 +875,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   if (grp == 0) bar();                     // re-align the two groups
   __syncthreads();
 
-  // ---- epilogue: four 64-row chunks staged through LDS (each wave's 128 rows span two chunks) -----------------------
-  float* epi = reinterpret_cast<float*>(smem);
-  constexpr int LD = PP_BN + 4;
-  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
-  T* outT = reinterpret_cast<T*>(e.out16);
-  T* vt = reinterpret_cast<T*>(e.vt);
-  const bool vt_tile = (vt != nullptr) && (n0 >= e.vt_col0);
-#pragma unroll
-  for (int chunk = 0; chunk < 4; ++chunk) {
-    if (chunk > 0) __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (grp * 2 + half != chunk) continue;
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int ti = half * 2 + t2;                 // static: accumulator row-tile of this wave
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          if (!vt_tile) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              epi[(t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + wrow + tj * 32 + fr] = acc[ti][tj][r];
-          } else {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-              const float4 v = make_float4(acc[ti][tj][g4 * 4], acc[ti][tj][g4 * 4 + 1], acc[ti][tj][g4 * 4 + 2], acc[ti][tj][g4 * 4 + 3]);
-              *reinterpret_cast<float4*>(&epi[(wrow + tj * 32 + fr) * (64 + 4) + t2 * 32 + 8 * g4 + 4 * fh]) = v;
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    const int mrow0 = m0 + chunk * 64;
-    if (vt_tile) {      // transposed staging [col][64 rows + 4]: items = (col, 4-row group)
-      for (int it = tid; it < PP_BN * 16; it += NT) {
-        const int rg = it & 15, c = it >> 4;
-        const int col = n0 + c, row = mrow0 + rg * 4;
-        if (col >= N || row >= M) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&epi[c * 68 + rg * 4]);
-        const float bias = e.bias ? e.bias[col] : 0.f;
-        const int cv = col - e.vt_col0;
-        int d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = (row + j < M) ? map_row(rm, row + j) : -1;
-        vt_store4<T>(vt, e, d, cv / e.vt_hd, cv % e.vt_hd, v, bias);
-      }
-      continue;
-    }
-    constexpr int CG = PP_BN / 8;
-    for (int it = tid; it < 64 * CG; it += NT) {
-      const int cg = it % CG, r = it / CG;
-      const int row = mrow0 + r, col0 = n0 + cg * 8;
-      if (row >= M || col0 >= N) continue;
-      float v[8];
-      {
-        const float4 a0 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&epi[r * LD + cg * 8 + 4]);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-      }
-      int dcol = col0, row_add = 0, bcol = col0;
-      if (e.map == LA_MAP_CONVT2X2) {
-        const int kyx = col0 / e.p2;
-        dcol = col0 % e.p2;
-        bcol = dcol;
-        row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
-      }
-      if (e.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
-        const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (e.act == LA_ACT_GELU) {
-        if (!e.out32) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
-        }
-      } else if (e.act == LA_ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      int drow = map_row(rm, row);
-      if (drow < 0) continue;
-      drow += row_add;
-      if (e.res) {
-        const int rr = e.res_mod ? drow % e.res_mod : drow;
-        const float4 r0 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol);
-        const float4 r1 = *reinterpret_cast<const float4*>(e.res + (size_t)rr * e.ldr + dcol + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-      }
-      if (e.out32) store8<float>(e.out32 + (size_t)drow * e.ld32 + dcol, v);
-      if (outT) store8<T>(outT + (size_t)drow * e.ld16 + dcol, v);
-    }
-  }
+  epilogue_256<T>(smem, acc, grp, wrow, m0, n0, M, N, e, tid);
 }
 
 template <typename T>
