@@ -33,18 +33,38 @@ import torch  # noqa: E402
 PEAK_MFMA_TFLOPS = 2500.0      # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
-def build_model(dtype, decoder_dtype=torch.float32):
+# BASELINE.json configs as bench workloads.  cfg2 is the one the metric is quoted on (the default and the only one the driver
+# runs); the others are extra data points (north_star: "throughput on synthetic 1024x1024 / 480x480 episodes").
+WORKLOADS = {
+    "cfg2": dict(desc="BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes (2 images each)",
+                 model=dict(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False),
+                 episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=16),
+    "cfg1": dict(desc="BASELINE cfg1 geometry on the GPU: ViT-MAE-B 480px encoder + decoder, 1-way 1-shot episodes (2 images each)",
+                 model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
+                            example_class_attention=False, custom_preprocess=False),
+                 episode=dict(n_ways=1, k_shots=1, image_size=480), default_episodes=32),
+    "cfg3": dict(desc="BASELINE cfg3 geometry, forward only: ViT-MAE-B 480px, 5-way 5-shot episodes (26 images, 150 prompt pairs each)",
+                 model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
+                            class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
+                 episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=2),
+    "cfg4": dict(desc="BASELINE cfg4 geometry: precomputed 256x64x64 embeddings (encoder bypassed), 2-way 5-shot episodes, decoder only",
+                 model=dict(encoder=None, use_vit=False, image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3,
+                            custom_preprocess=False),
+                 episode=dict(n_ways=2, k_shots=5, image_size=1024, embeddings_channels=256, grid=64), default_episodes=8),
+}
+
+
+def build_model(dtype, decoder_dtype=torch.float32, workload="cfg2"):
     from labelanything_amd.config import LamConfig
     from labelanything_amd.models import Lam
-    cfg = LamConfig(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3,
-                    custom_preprocess=False)
+    cfg = LamConfig(**WORKLOADS[workload]["model"])
     return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype), cfg
 
 
-def make_inputs(episodes: int, seed: int, device):
+def make_inputs(episodes: int, seed: int, device, workload="cfg2"):
     from labelanything_amd.episodes import make_episode
-    batch = make_episode(batch=episodes, n_ways=1, k_shots=1, image_size=1024, seed=seed, prompts=("mask",))
-    dev_keys = ("images", "prompt_masks")
+    batch = make_episode(batch=episodes, seed=seed, prompts=("mask",), **WORKLOADS[workload]["episode"])
+    dev_keys = ("images", "embeddings", "prompt_masks")
     return {k: (v.to(device) if k in dev_keys else v) for k, v in batch.items()}
 
 
@@ -143,14 +163,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=16, help="episodes per step per GPU (throughput grows 178 -> 301 -> 306 -> 310 "
-                    "episodes/s for 1 / 8 / 16 / 32: profiles/r01_gemm_ablation.md)")
+    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 16: throughput grows 178 -> "
+                    "301 -> 306 -> 310 episodes/s for 1 / 8 / 16 / 32: profiles/r01_gemm_ablation.md)")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the BASELINE metric (default); the others are "
+                    "extra data points with the geometry of the other BASELINE configs")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--decoder", default="f32", choices=["f32", "same"], help="operand type of the decoder-side GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
     a = ap.parse_args()
+    if a.episodes is None:
+        a.episodes = WORKLOADS[a.workload]["default_episodes"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -170,10 +194,10 @@ def main():
         else:
             dist.init_process_group(backend)
     dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
-    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None)
+    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None, a.workload)
     lam = lam.to(dev)
     lam.use_graphs = not a.no_graphs
-    batch = make_inputs(a.episodes, 1234 + rank, dev)
+    batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
 
     def barrier():
         torch.cuda.synchronize()
@@ -223,17 +247,18 @@ def main():
     if rank == 0:
         eps = a.episodes * world * a.steps / elapsed
         line = {
-            "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot", "value": round(eps, 3), "unit": "episodes/s",
+            "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot" if a.workload == "cfg2" else f"episodes/sec (forward) {a.workload}",
+            "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes "
-                                   "(2 images each), random-init weights, full-resolution logits",
-                       "episodes_per_step_per_gpu": a.episodes, "images_per_sec": round(eps * 2, 2),
+            "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
+                       "episodes_per_step_per_gpu": a.episodes,
+                       "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),
                        "parallelism": f"episode-sharded x{world}, no collective",
                        "launch": "eager" if a.no_graphs else "hipGraph replay"},
             "roofline": roof, "kernels_ms_per_step": kernels,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     if dist is not None:
