@@ -230,3 +230,26 @@ def test_hf_encoder_with_32_wide_heads_is_padded_to_64():
     register_encoder("hf_hd32", EncoderSpec("hf", dim=128, depth=2, heads=4, mlp=256, img_size=224))
     cfg = LamConfig(encoder="hf_hd32", image_size=160, image_embed_dim=128, embed_dim=64, spatial_convs=3, custom_preprocess=False)
     assert _encoder_vs_oracle(cfg, 2, 25) < 2e-3
+
+
+def test_cfg5_episode_shape_10way_5shot_matches_oracle():
+    """BASELINE cfg5 episode shape (10-way 5-shot: 51 images, 550 (support, class) pairs, 11 classes) on the reduced HF encoder:
+    the largest token counts of the path (550-token class_example_attention, 11-class decoder, mask + box + point prompts)."""
+    from labelanything_amd.config import LamConfig
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    cfg = LamConfig(encoder="hf_tiny", image_size=160, image_embed_dim=128, embed_dim=64, spatial_convs=3,
+                    class_encoder={"name": "RandomMatrixEncoder", "bank_size": 30, "embed_dim": 64}, custom_preprocess=False)
+    batch = make_episode(batch=1, n_ways=10, k_shots=5, image_size=160, seed=77, prompts=("mask", "point", "box"))
+    rows = torch.tensor([0, 2, 5, 7, 11, 13, 17, 19, 23, 26, 29])
+    lam = Lam(cfg, seed=9).cuda()
+    lam.selected_rows = rows
+    out = lam(batch)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.lam_forward(init_state_dict(cfg, 9), geometry_for(cfg), batch, selected_rows=rows)
+    assert out["logits"].shape == (1, 11, 160, 160)
+    assert out["class_examples_embeddings"].shape == (1, 50, 11, 64)
+    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
+    assert rel_err(out["logits"], ref["logits"]) < 4e-3
