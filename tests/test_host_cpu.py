@@ -97,3 +97,19 @@ def test_hf_key_renaming_from_transformers5():
     out = _hf5_to_hf4(sd)
     assert set(out) == {"image_encoder.encoder.layer.3.attention.attention.query.weight",
                         "image_encoder.encoder.layer.3.output.dense.bias"}
+
+
+def test_bench_workloads_describe_valid_models_and_episodes():
+    """bench.py --workload: every BASELINE geometry builds a LamConfig and a synthetic episode of the right shape (no GPU)."""
+    import bench
+    from labelanything_amd.config import LamConfig
+    from labelanything_amd.episodes import make_episode
+    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4"}
+    for name, w in bench.WORKLOADS.items():
+        cfg = LamConfig(**w["model"])
+        ep = dict(w["episode"])
+        small = make_episode(batch=1, seed=1, prompts=("mask",), **{**ep, "image_size": 64, **({"grid": 4} if "grid" in ep else {})})
+        m = ep["n_ways"] * ep["k_shots"]
+        key = "embeddings" if "embeddings_channels" in ep else "images"
+        assert small[key].shape[:2] == (1, m + 1) and small["prompt_masks"].shape[:3] == (1, m, ep["n_ways"] + 1)
+        assert (cfg.encoder_spec is None) == (name == "cfg4")
