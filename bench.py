@@ -54,11 +54,12 @@ WORKLOADS = {
 }
 
 
-def build_model(dtype, decoder_dtype=torch.float32, workload="cfg2"):
+def build_model(dtype, decoder_dtype=torch.float32, workload="cfg2", precise=None):
     from labelanything_amd.config import LamConfig
+    from labelanything_amd.engine import PRECISE_DEFAULT
     from labelanything_amd.models import Lam
     cfg = LamConfig(**WORKLOADS[workload]["model"])
-    return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype), cfg
+    return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype, precise=PRECISE_DEFAULT if precise is None else precise), cfg
 
 
 def make_inputs(episodes: int, seed: int, device, workload="cfg2"):
@@ -93,9 +94,12 @@ class KernelTimer:
                 e.record()
                 flops = 0.0
                 nbytes = 0.0
+                issued = 0.0
                 if _n == "gemm":
                     m = kw.get("M") or a[0].shape[0]
                     n, k = a[1].shape
+                    issued = 2.0 * m * n * k                     # MFMA work actually issued (split-precision planes count twice)
+                    k = kw.get("a_kmod") or k                    # algorithmic K: the [W_hi | W_lo] planes are ONE weight
                     flops = 2.0 * m * n * k
                     esz = a[0].element_size()
                     # algorithmic bytes: A and W read once, every output written once, the residual read once
@@ -109,7 +113,7 @@ class KernelTimer:
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
-                self.records.append((tag, flops, s, e, nbytes))
+                self.records.append((tag, flops, s, e, nbytes, issued if _n == "gemm" else flops))
             setattr(L, n, wrapped)
         return self
 
@@ -120,12 +124,13 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for n, fl, s, e, nb in self.records:
-            d = agg.setdefault(n, [0, 0.0, 0.0, 0.0])
+        for n, fl, s, e, nb, iss in self.records:
+            d = agg.setdefault(n, [0, 0.0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += fl
             d[3] += nb
+            d[4] += iss
         return agg
 
 
@@ -169,6 +174,9 @@ def main():
                     "extra data points with the geometry of the other BASELINE configs")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--decoder", default="f32", choices=["f32", "same"], help="operand type of the decoder-side GEMMs")
+    ap.add_argument("--precise", default="default", help="encoder GEMM groups in split precision: 'default' (the parity-tested "
+                    "configuration, engine.PRECISE_DEFAULT), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
+                    "or a comma list of groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
@@ -194,7 +202,8 @@ def main():
         else:
             dist.init_process_group(backend)
     dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
-    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None, a.workload)
+    precise = None if a.precise == "default" else (() if a.precise == "none" else tuple(a.precise.split(",")))
+    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None, a.workload, precise)
     lam = lam.to(dev)
     lam.use_graphs = not a.no_graphs
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
@@ -242,7 +251,9 @@ def main():
                     "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                     "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
-                    "share_of_kernel_time": round(g[1] / tot, 3)}
+                    "share_of_kernel_time": round(g[1] / tot, 3),
+                    # split-precision weights ([W_hi | W_lo]) issue two MFMA passes for one algorithmic product
+                    "mfma_issued_tflops": round(g[4] / g[1] / 1e12, 1)}
 
     if rank == 0:
         eps = a.episodes * world * a.steps / elapsed
@@ -250,7 +261,7 @@ def main():
             "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot" if a.workload == "cfg2" else f"episodes/sec (forward) {a.workload}",
             "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list(lam.precise), "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),

@@ -50,6 +50,11 @@ int la_version(void);
  *                          GEMM row m reads A[amap(m)] and writes row m.  With LA_MAP_WINDOW_PART the proj GEMM of a SAM
  *                          window block walks the H x W tokens only and gathers its input from the window-ordered
  *                          attention output, so neither window GEMM touches the 16 % padded tokens.
+ *  a_kmod > 0 (16-bit operands, a_kmod % 64 == 0, K % a_kmod == 0): the A columns REPEAT with period a_kmod while W runs over all
+ *                          K columns, i.e. C = A[:, :a_kmod] . (W[:, 0:a_kmod] + W[:, a_kmod:2 a_kmod] + ...)^T accumulated in fp32 with
+ *                          every partial product formed separately.  With W = [W_hi | W_lo] (W_hi = the 16-bit rounding of an fp32
+ *                          weight, W_lo = the 16-bit rounding of what it lost) the weights enter with ~22 mantissa bits: the
+ *                          split-precision mode that brings the encoder inside the 1e-3 logit tolerance.
  *  residual is fp32, indexed by (res_mod ? dst_row % res_mod : dst_row), dst_col.
  *  vt != NULL: columns >= vt_col0 are NOT written to out16 but transposed into
  *  vt[((row / vt_T) * vt_heads + head) * vt_hd + d][vt_Tpad] at token row % vt_T  (V operand of la_attn_fwd), row = dst_row.
@@ -70,6 +75,7 @@ typedef struct LaGemmEpilogue {
   int vt_col0, vt_T, vt_Tpad, vt_hd, vt_heads;
   int vt_ws;           /* > 0: token t of a ws x ws window goes to slot (t / ws) * 16 + t % ws of the V^T row (LA_ATTN_RELPOS_WIN16) */
   int amap;            /* source-row map (LA_MAP_NONE or LA_MAP_WINDOW_PART), see above */
+  int a_kmod;          /* > 0: period of the A columns (split-precision weights [W_hi | W_lo]), see above */
 } LaGemmEpilogue;
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.

@@ -30,7 +30,7 @@ class LaGemmEpilogue(C.Structure):
         ("act", C.c_int), ("map", C.c_int),
         ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int), ("p3", C.c_int), ("p4", C.c_int),
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_T", C.c_int), ("vt_Tpad", C.c_int),
-        ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int),
+        ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int), ("a_kmod", C.c_int),
     ]
 
 
@@ -88,8 +88,9 @@ def _dev(t: torch.Tensor) -> None:
 # ----------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, out32=None, out16=None,
          act=ACT_NONE, map=MAP_NONE, p=(0, 0, 0, 0, 0), vt=None, vt_col0=0, vt_T=0, vt_Tpad=0, vt_hd=64,
-         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE) -> None:
-    """C = epilogue(a @ w.T).  a: [M,K] 16-bit (row stride lda), w: [N,K] 16-bit."""
+         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0) -> None:
+    """C = epilogue(a @ w.T).  a: [M,K] 16-bit (row stride lda), w: [N,K] 16-bit.  a_kmod > 0: w is [N, j*a_kmod] (split-precision
+    planes [W_hi | W_lo]) and the columns of a repeat with period a_kmod."""
     _dev(a)
     m = a.shape[0] if M is None else M
     k = w.shape[1]
@@ -109,6 +110,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, ou
     e.vt_col0, e.vt_T, e.vt_Tpad, e.vt_hd, e.vt_heads = vt_col0, vt_T, vt_Tpad, vt_hd, vt_heads
     e.vt_ws = vt_ws
     e.amap = amap
+    e.a_kmod = a_kmod
     rc = lib().la_gemm(_ptr(a), C.c_int(a.stride(0) if lda is None else lda), _ptr(w), C.c_int(w.stride(0)),
                        C.c_int(m), C.c_int(n), C.c_int(k), C.byref(e), C.c_int(dt_of(a)), _stream())
     _check(rc, "la_gemm")

@@ -55,6 +55,10 @@ __device__ __forceinline__ int map_row(const RowMap& m, int row) {
   }
 }
 
+// k offset of the A operand for k-tile start k0: with a_kmod > 0 the A columns repeat with that period while W keeps running
+// (W = [W_hi | W_lo] against one A: split-precision weights, LaGemmEpilogue.a_kmod)
+__device__ __forceinline__ int a_koff(const LaGemmEpilogue& e, int k0) { return e.a_kmod > 0 ? k0 % e.a_kmod : k0; }
+
 // source row of GEMM row m (LaGemmEpilogue.amap)
 __device__ __forceinline__ int a_row(const LaGemmEpilogue& e, int m) {
   if (e.amap == LA_MAP_NONE) return m;
@@ -85,10 +89,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const T* __restrict__ A
   uint4 ra_[4], rw_[4];
   auto gload = [&](int kt) {
     const int k0 = kt * BK;
+    const int ka = a_koff(e, k0);
     const bool ok = (k0 + lc * 8) < K;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra_[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
+      ra_[i] = ok ? *reinterpret_cast<const uint4*>(a_ptr[i] + ka) : make_uint4(0, 0, 0, 0);
       rw_[i] = ok ? *reinterpret_cast<const uint4*>(w_ptr[i] + k0) : make_uint4(0, 0, 0, 0);
     }
   };
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(BM_ * 2, 2) void gemm_dma_kernel(const T* __restric
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16s((i < NA ? A : Wt) + kt * BK, soff[i], lds0 + stage * STAGE + ldsoff[i]);
+    for (int i = 0; i < NDMA; ++i) dma16s(i < NA ? A + a_koff(e, kt * BK) : Wt + kt * BK, soff[i], lds0 + stage * STAGE + ldsoff[i]);
   };
 
   f32x16 acc[2][2];
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) dma16s((i < NA ? A : Wt) + kt * BK_, soff[i], lds0 + stage * STAGE + ldsoff[i]);
+    for (int i = 0; i < NDMA; ++i) dma16s(i < NA ? A + a_koff(e, kt * BK_) : Wt + kt * BK_, soff[i], lds0 + stage * STAGE + ldsoff[i]);
   };
 
   f32x16 acc[4][2];
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
   auto dma_ht = [&](int kt, int o, int h) {
     if (kt >= nk) return;
     const unsigned base = lds0 + (kt & 1) * PP_STAGE + o * (2 * PP_HALF) + h * PP_HALF + wave * 1024;
-    const T* sb = (o ? Wt : A) + kt * BK;
+    const T* sb = o ? Wt + kt * BK : A + a_koff(e, kt * BK);
     dma16s(sb, soff[o][h][0], base);
     dma16s(sb, soff[o][h][1], base + 8 * 1024);
   };
@@ -1198,6 +1203,8 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   LA_CHECK_ARG((K % kq) == 0 && (lda % kq) == 0 && (ldw % kq) == 0, "la_gemm: K, lda, ldw must be multiples of %d (K=%d lda=%d ldw=%d)", kq, K,
                lda, ldw);
   LA_CHECK_ARG(epi->out32 || epi->out16 || epi->vt, "la_gemm: no output");
+  LA_CHECK_ARG(epi->a_kmod == 0 || (dt != LA_F32 && epi->a_kmod > 0 && (epi->a_kmod % 64) == 0 && (K % epi->a_kmod) == 0 && M > 32),
+               "la_gemm: a_kmod=%d must be a multiple of 64 that divides K=%d (16-bit operands, M > 32)", epi->a_kmod, K);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_gemm: bad dtype %d", dt);
   LA_CHECK_ARG(epi->amap == LA_MAP_NONE || (epi->amap == LA_MAP_WINDOW_PART && epi->map == LA_MAP_NONE && dt != LA_F32),
                "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
@@ -1225,12 +1232,12 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     // measured on MI355X (profiles/r01_gemm_variants.log): the 256x128 / 128x64-per-wave kernel wins by ~5 % on the short-K
     // (K = 768) shapes once there are >= 2 full waves of tiles; the 128x128 kernel wins on long K and small grids.
     const long tiles256 = (long)((M + 255) / 256) * ((N + la::BN - 1) / la::BN);
-    bool v4 = (K <= 1024) && (tiles256 >= 512);
+    bool v4 = (K <= 1536) && (tiles256 >= 512);
     if (force && force[0] == '4') v4 = true;
     if (force && force[0] == '2') v4 = false;
     // long-K shapes with >= 2 full waves of 256 x 256 tiles: the ping-pong kernel (+15 % on 65536x768x3072)
     const long tiles_pp = (long)((M + la::PP_BM - 1) / la::PP_BM) * ((N + la::PP_BN - 1) / la::PP_BN);
-    bool pp = (K >= 2048) && (tiles_pp >= 512);
+    bool pp = (K > 1536) && (tiles_pp >= 512);
     if (force) pp = force[0] == '6';
     pp = pp && (!epi->vt || (epi->vt_col0 % la::PP_BN) == 0);
     if (pp) {

@@ -21,12 +21,17 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     const float* src = img + (((long)b * 3 + c) * S + (py * p + ky)) * S + px * p + kx;
     const float4 v0 = *reinterpret_cast<const float4*>(src);
     const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-    uint4 o;
-    o.x = pack2<T>(v0.x, v0.y);
-    o.y = pack2<T>(v0.z, v0.w);
-    o.z = pack2<T>(v1.x, v1.y);
-    o.w = pack2<T>(v1.z, v1.w);
-    *reinterpret_cast<uint4*>(out + row * K + k) = o;
+    if constexpr (sizeof(T) == 4) {        // fp32 patches for the exact-fp32 patch-embed GEMM (split-precision group "patch")
+      reinterpret_cast<float4*>(out + row * K + k)[0] = v0;
+      reinterpret_cast<float4*>(out + row * K + k)[1] = v1;
+    } else {
+      uint4 o;
+      o.x = pack2<T>(v0.x, v0.y);
+      o.y = pack2<T>(v0.z, v0.w);
+      o.z = pack2<T>(v1.x, v1.y);
+      o.w = pack2<T>(v1.z, v1.w);
+      *reinterpret_cast<uint4*>(out + row * K + k) = o;
+    }
   }
 }
 
@@ -57,6 +62,7 @@ extern "C" int la_im2col_patch(const float* img, int Bn, int S, int patch, void*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dt == LA_F16) hipLaunchKernelGGL(la::im2col_patch_kernel<la::f16_t>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (la::f16_t*)out16);
   else if (dt == LA_BF16) hipLaunchKernelGGL(la::im2col_patch_kernel<la::bf16_t>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (la::bf16_t*)out16);
+  else if (dt == LA_F32) hipLaunchKernelGGL(la::im2col_patch_kernel<float>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (float*)out16);
   else LA_CHECK_ARG(false, "la_im2col_patch: bad dtype %d", dt);
   LA_CHECK_LAUNCH("la_im2col_patch");
   return 0;

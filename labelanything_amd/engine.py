@@ -53,14 +53,28 @@ class Arena:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+# Encoder GEMM groups that run in split precision by default (tools/error_budget.py): the 16-bit rounding of
+# the WEIGHTS is the same perturbation for every token, so its effect survives attention and pooling instead of averaging
+# out like the activation roundings, and the necks / patch embedding have no residual stream to dilute their error.
+#   "qkv", "proj", "lin1", "lin2": weights as two 16-bit planes [W_hi | W_lo] (la_gemm a_kmod), activations 16-bit;
+#   "patch", "neck": exact-fp32 MFMA (1 % of the FLOPs).
+PRECISE_DEFAULT = ("patch", "qkv", "proj", "lin2", "neck")
+PRECISE_GROUPS = ("patch", "qkv", "proj", "lin1", "lin2", "neck")
+
+
 class LamEngine:
     def __init__(self, cfg: LamConfig, weights: Dict[str, Tensor], device: torch.device, dtype: torch.dtype = torch.float16,
-                 decoder_dtype: Optional[torch.dtype] = torch.float32):
+                 decoder_dtype: Optional[torch.dtype] = torch.float32, precise=PRECISE_DEFAULT):
         """dtype: MFMA operand type of the image encoder and necks (>99% of the FLOPs).  decoder_dtype: operand type of the
         prompt encoder / mask decoder GEMMs - fp32 by default (exact-fp32 MFMA; ~1% of the FLOPs but the stage where
-        16-bit operand rounding would dominate the logit error), or None to follow ``dtype``."""
+        16-bit operand rounding would dominate the logit error), or None to follow ``dtype``.  precise: encoder GEMM groups
+        that run in split precision (see PRECISE_DEFAULT); () = every encoder GEMM with plain 16-bit operands."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
+        self.precise = frozenset(precise or ())
+        if not self.precise <= set(PRECISE_GROUPS):
+            raise ValueError(f"unknown precise groups {sorted(self.precise - set(PRECISE_GROUPS))}; known: {PRECISE_GROUPS}")
+        self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
         L.lib()  # fail loudly if the HIP extension is missing
@@ -83,6 +97,22 @@ class LamEngine:
 
     def _hd(self, t: Tensor) -> Tensor:
         return t.to(self.ddt).contiguous()
+
+    def _hw(self, key: str, t: Tensor, group: str) -> None:
+        """Pack an encoder GEMM weight [N, K]: one 16-bit plane, or [W_hi | W_lo] when its group is precise."""
+        t = t.contiguous()
+        if group in self.precise and t.shape[1] % 64 == 0:
+            hi = t.to(self.dt)
+            lo = (t - hi.float()).to(self.dt)
+            self.p[key] = torch.cat([hi, lo], dim=1).contiguous()
+            self.kmod[key] = t.shape[1]
+        else:
+            self.p[key] = t.to(self.dt)
+            self.kmod.pop(key, None)
+
+    def gemm_w(self, a: Tensor, key: str, **kw) -> None:
+        """la_gemm against the packed encoder weight ``key`` (split-precision aware)."""
+        L.gemm(a, self.p[key], a_kmod=self.kmod.get(key, 0), **kw)
 
     @property
     def head_pad(self) -> int:
@@ -139,25 +169,27 @@ class LamEngine:
 
     def _pack_conv_neck(self, pre: str) -> None:
         w = self.w32
-        self.p[pre + ".0.w"] = self._h(w[pre + ".0.weight"].flatten(1))
-        self.p[pre + ".2.w"] = self._h(w[pre + ".2.weight"].permute(0, 2, 3, 1).flatten(1))   # [Cout, (ky,kx,cin)]
+        cast = (lambda t: t.contiguous()) if "neck" in self.precise else self._h
+        self.p[pre + ".0.w"] = cast(w[pre + ".0.weight"].flatten(1))
+        self.p[pre + ".2.w"] = cast(w[pre + ".2.weight"].permute(0, 2, 3, 1).flatten(1))   # [Cout, (ky,kx,cin)]
 
     def _pack(self) -> None:
         cfg, w, p = self.cfg, self.w32, self.p
         spec = cfg.encoder_spec
         if spec is not None and spec.kind == "sam":
             pre = "image_encoder"
-            p[pre + ".patch.w"] = self._h(w[pre + ".patch_embed.proj.weight"].flatten(1))
+            pw = w[pre + ".patch_embed.proj.weight"].flatten(1)
+            p[pre + ".patch.w"] = pw.contiguous() if "patch" in self.precise else self._h(pw)
             p[pre + ".pos"] = w[pre + ".pos_embed"].reshape(-1, spec.dim).contiguous()
             g = spec.img_size // spec.patch
             hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 bp = f"{pre}.blocks.{i}"
-                p[bp + ".qkv.w"] = self._h(self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp))
+                self._hw(bp + ".qkv.w", self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp), "qkv")
                 p[bp + ".qkv.b"] = self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp)
-                p[bp + ".proj.w"] = self._h(self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp))
-                p[bp + ".lin1.w"] = self._h(w[bp + ".mlp.lin1.weight"])
-                p[bp + ".lin2.w"] = self._h(w[bp + ".mlp.lin2.weight"])
+                self._hw(bp + ".proj.w", self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp), "proj")
+                self._hw(bp + ".lin1.w", w[bp + ".mlp.lin1.weight"], "lin1")
+                self._hw(bp + ".lin2.w", w[bp + ".mlp.lin2.weight"], "lin2")
                 size = g if i in spec.global_idx else spec.window
                 for ax in ("h", "w"):
                     tab = w[f"{bp}.attn.rel_pos_{ax}"]
@@ -167,7 +199,8 @@ class LamEngine:
             self._pack_conv_neck(pre + ".neck")
         elif spec is not None and spec.kind == "hf":
             pre = "image_encoder"
-            p[pre + ".patch.w"] = self._h(w[pre + ".embeddings.patch_embeddings.projection.weight"].flatten(1))
+            pw = w[pre + ".embeddings.patch_embeddings.projection.weight"].flatten(1)
+            p[pre + ".patch.w"] = pw.contiguous() if "patch" in self.precise else self._h(pw)
             hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 lp = f"{pre}.encoder.layer.{i}"
@@ -175,11 +208,11 @@ class LamEngine:
                                    w[lp + ".attention.attention.value.weight"]])
                 qkv_b = torch.cat([w[lp + ".attention.attention.query.bias"], w[lp + ".attention.attention.key.bias"],
                                    w[lp + ".attention.attention.value.bias"]])
-                p[lp + ".qkv.w"] = self._h(self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp))
+                self._hw(lp + ".qkv.w", self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp), "qkv")
                 p[lp + ".qkv.b"] = self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp)
-                p[lp + ".o.w"] = self._h(self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp))
-                p[lp + ".fc1.w"] = self._h(w[lp + ".intermediate.dense.weight"])
-                p[lp + ".fc2.w"] = self._h(w[lp + ".output.dense.weight"])
+                self._hw(lp + ".o.w", self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp), "proj")
+                self._hw(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], "lin1")
+                self._hw(lp + ".fc2.w", w[lp + ".output.dense.weight"], "lin2")
         if cfg.lam_neck:
             self._pack_conv_neck("neck")
         pe = "prompt_encoder"
@@ -244,10 +277,23 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     # conv neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d on NHWC rows (image_encoder.py:92-108, build_lam.py:150-171)
     # ------------------------------------------------------------------------------------------------
-    def conv_neck(self, pre: str, x16: Tensor, bn: int, g: int, tag: str) -> Tensor:
+    def conv_neck(self, pre: str, x16: Optional[Tensor], bn: int, g: int, tag: str, x32: Optional[Tensor] = None) -> Tensor:
         cout = self.p[pre + ".0.w"].shape[0]
         rows = bn * g * g
         a = self.f32(tag + ".n0", (rows, cout))
+        if "neck" in self.precise:      # exact-fp32 MFMA on the fp32 stream itself (no 16-bit copy of the input at all)
+            L.gemm(x32, self.p[pre + ".0.w"], out32=a)
+            a1 = self.f32(tag + ".n1f", (rows, cout))
+            L.layernorm(a, self.w32[pre + ".1.weight"], self.w32[pre + ".1.bias"], 1e-6, out32=a1, dt=L.LA_F32)
+            if cout % 32 == 0:
+                L.conv3x3_f32(a1, bn, g, g, cout, self.p[pre + ".2.w"], None, cout, a)
+            else:
+                col = self.f32(tag + ".colf", (rows, 9 * cout))
+                L.im2col_3x3(a1, bn, g, g, cout, col)
+                L.gemm(col, self.p[pre + ".2.w"], out32=a)
+            out = self.f32(tag + ".out", (rows, cout))
+            L.layernorm(a, self.w32[pre + ".3.weight"], self.w32[pre + ".3.bias"], 1e-6, out32=out, dt=L.LA_F32)
+            return out
         L.gemm(x16, self.p[pre + ".0.w"], out32=a)
         a16 = self.buf(tag + ".n1", (rows, cout))
         self.ln(a, pre + ".1", 1e-6, out16=a16)
@@ -283,7 +329,7 @@ class LamEngine:
         ea = heads * hdp                # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
         w, p = self.w32, self.p
         images = images.contiguous()
-        a = self.buf("enc.patchA", (rows, 3 * spec.patch * spec.patch))
+        a = self.buf("enc.patchA", (rows, 3 * spec.patch * spec.patch), torch.float32 if "patch" in self.precise else None)
         L.im2col_patch(images, spec.patch, a)
         res = self.f32("enc.res", (rows, e))
         L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res)
@@ -309,8 +355,8 @@ class LamEngine:
             # the 16 % padded rows here too, but it breaks the V^T stores into 14-token runs and measured slower.)
             qkv = self.buf("enc.qkv." + tag, (arows, 3 * ea))
             vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
-            L.gemm(xin, p[bp + ".qkv.w"], bias=p[bp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t,
-                   vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
+            self.gemm_w(xin, bp + ".qkv.w", bias=p[bp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t,
+                        vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
             ao = self.buf("enc.ao." + tag, (arows, ea))
             if win16:
                 L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16,
@@ -324,21 +370,21 @@ class LamEngine:
                 L.relpos_terms(qkv, nb, heads, gg, ea, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
                 L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS)
             if is_global:
-                L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
+                self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
             else:       # window_unpartition as a row gather on the A operand: again only the real tokens are computed
-                L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res, M=rows,
-                       amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, g, g))
+                self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res, M=rows,
+                            amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, g, g))
             self.ln(res, bp + ".norm2", 1e-6, out16=x16)
             hbuf = self.buf("enc.mlp", (rows, spec.mlp))
-            L.gemm(x16, p[bp + ".lin1.w"], bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
-            if i == spec.depth - 1:
+            self.gemm_w(x16, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
+            if i == spec.depth - 1 and not (self.cfg.use_vit_sam_neck and "neck" in self.precise):
                 last16 = self.buf("enc.last16", (rows, e))
-                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=last16)
+                self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=last16)
             else:
-                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
+                self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
         if not self.cfg.use_vit_sam_neck:
             return (res, last16, e) if not want_last_block else ((res, last16, e), res)
-        out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck")
+        out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck", x32=res)
         if want_last_block:
             return (out, None, spec.out_chans), res
         return out, None, spec.out_chans
@@ -375,7 +421,7 @@ class LamEngine:
         pos = self._hf_pos(g)
         cls_row = self._hfpos_cache[-g]
         images = images.contiguous()
-        a = self.buf("hf.patchA", (bn * hw, 3 * spec.patch * spec.patch))
+        a = self.buf("hf.patchA", (bn * hw, 3 * spec.patch * spec.patch), torch.float32 if "patch" in self.precise else None)
         L.im2col_patch(images, spec.patch, a)
         res = self.f32("hf.res", (rows, e))
         res.view(bn, t, e)[:, 0].copy_(cls_row)      # CLS row = cls_token + pos[0] (weights only; plain copy)
@@ -393,13 +439,13 @@ class LamEngine:
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
-            L.gemm(x16, p[lp + ".qkv.w"], bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t, vt_Tpad=tpad,
-                   vt_hd=hdp, vt_heads=heads)
+            self.gemm_w(x16, lp + ".qkv.w", bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t, vt_Tpad=tpad,
+                        vt_hd=hdp, vt_heads=heads)
             L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
-            L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
+            self.gemm_w(ao, lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
             self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
-            L.gemm(x16, p[lp + ".fc1.w"], bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)
-            L.gemm(hbuf, p[lp + ".fc2.w"], bias=w[lp + ".output.dense.bias"], res=res, out32=res)
+            self.gemm_w(x16, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)
+            self.gemm_w(hbuf, lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=res, out32=res)
         fin = self.f32("hf.final", (rows, e))
         fin16 = self.buf("hf.final16", (rows, e))
         self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16)
@@ -422,6 +468,8 @@ class LamEngine:
         return out32, out16, c, images.shape[-1] // spec.patch
 
     def lam_neck(self, emb32: Tensor, emb16: Optional[Tensor], bn: int, g: int) -> Tensor:
+        if "neck" in self.precise:
+            return self.conv_neck("neck", None, bn, g, "lamneck", x32=emb32)
         if emb16 is None:
             emb16 = self.buf("neck.in16", tuple(emb32.shape))
             L.add_cast(emb32, out16=emb16, dt=self.dti)

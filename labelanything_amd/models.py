@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .config import LamConfig, ENCODER_SPECS, config_from_kwargs
-from .engine import LamEngine
+from .engine import LamEngine, PRECISE_DEFAULT
 from .weights import model_shapes, init_state_dict
 from . import _lib as L
 
@@ -63,13 +63,14 @@ class Lam(nn.Module):
     image_format: str = "RGB"
 
     def __init__(self, cfg: LamConfig, seed: Optional[int] = None, compute_dtype: torch.dtype = torch.float16,
-                 decoder_dtype: Optional[torch.dtype] = torch.float32):
+                 decoder_dtype: Optional[torch.dtype] = torch.float32, precise=PRECISE_DEFAULT):
         super().__init__()
         self.cfg = cfg
         self.image_size = cfg.image_size
         self.custom_preprocess = cfg.custom_preprocess
         self.compute_dtype = compute_dtype
         self.decoder_dtype = decoder_dtype
+        self.precise = tuple(precise or ())      # encoder GEMM groups in split precision (engine.PRECISE_DEFAULT)
         self.class_embeddings = None
         sd = init_state_dict(cfg, 0 if seed is None else seed)
         for k, v in sd.items():
@@ -103,10 +104,10 @@ class Lam(nn.Module):
             raise RuntimeError("labelanything_amd runs on an MI355X only: move the model to 'cuda' (no CPU fallback)")
         if self._plist is None:
             self._plist = list(self.parameters()) + list(self.buffers())
-        key = (dev, self.compute_dtype, self.decoder_dtype, sum(p._version for p in self._plist))
+        key = (dev, self.compute_dtype, self.decoder_dtype, self.precise, sum(p._version for p in self._plist))
         if self._engine is None or self._engine_key != key:
             self._graphs = {}
-            self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype, self.decoder_dtype)
+            self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype, self.decoder_dtype, self.precise)
             self._engine_key = key
         return self._engine
 

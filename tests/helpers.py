@@ -41,3 +41,13 @@ def argmax_disagreement(logits: torch.Tensor, ref_argmax: torch.Tensor, ref_logi
     margin = top2[:, 0] - top2[:, 1]
     scale = float(rl[torch.isfinite(rl)].abs().max())
     return n_diff, int((diff & (margin > margin_rel * scale)).sum())
+
+
+def reference_logits(case: dict, gold: dict, batch: dict) -> torch.Tensor:
+    """Full-resolution reference logits of a golden case: the stored ones, or (full-size cases keep only the low-res logits)
+    the oracle's post-processing (pinned on the reference like the rest of it) applied to the stored low-res logits."""
+    if "logits" in gold:
+        return gold["logits"].float()
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    return O.postprocess(geometry_for(case["cfg"]), gold["low_res_logits"].float(), batch["dims"], batch.get("flag_gts"))

@@ -1,8 +1,17 @@
 """GPU: the HIP path (through the C ABI) against the golden fixtures captured from the reference.
 
-Tolerances are max|a-b| / max|b| per tensor and are stated per dtype in TOL below; argmax is compared through the
-fraction of differing pixels (random-weight models have near-tied class logits almost everywhere, so exact argmax
-equality is only asserted for the index kernel itself: fused argmax == torch.argmax of the same logits).
+north_star tolerance: <= 1e-3 relative (max|a-b| / max|b|) on the logits with fp16/bf16 MFMA operands, argmax bit-exact.
+The parity configuration is the DEFAULT one - fp16 operands, split-precision weight planes for the qkv / proj / lin2
+GEMMs, exact-fp32 patch embedding, necks and decoder (engine.PRECISE_DEFAULT) - and it is held to 1e-3 on
+EVERY stage below (measured 3.6e-4 .. 6.1e-4 on the logits of the six cases, profiles/r02_parity.log).
+
+Argmax: the fused argmax must equal torch.argmax of the logits the same launch wrote, bit for bit, and it must equal the
+REFERENCE's argmax at every pixel whose reference top-2 margin exceeds 2 x the logit tolerance (two logits that each move
+by <= tol can only swap when they were closer than 2 tol).  Random-weight models put 0.02-0.2 % of the pixels inside that
+band; those are reported, not asserted.
+
+bf16 operands (8 mantissa bits) are a supported switch, NOT the parity configuration: their activation roundings alone
+cost 3-6e-3 on the logits, so they are held to their own measured bound (x1.5) and documented as such.
 """
 import pytest
 import torch
@@ -10,19 +19,15 @@ import torch
 from labelanything_amd.episodes import make_episode
 from labelanything_amd.models import Lam
 from tests.cases import CASES
-from tests.helpers import load_golden, rel_err
+from tests.helpers import argmax_disagreement, load_golden, reference_logits, rel_err
 
 pytestmark = pytest.mark.gpu
 
-# Tolerances (max|a-b| / max|b|) for: query embedding, class embeddings, low-res logits, final logits, and the fraction
-# of pixels whose argmax differs.  north_star asks for 1e-3 on logits in fp16/bf16; measured on MI355X with the
-# fp16 encoder + exact-fp32 decoder (the default): embeddings 0.5-1.1e-3, class prototypes 0.7-6e-4, logits 0.6-1.5e-3
-# (profiles/r01_parity.log).  The bounds below are ~1.5x the worst measured value.  bf16 operands carry 8 mantissa
-# bits (8x the fp16 rounding error) and are accepted at 8x the fp16 bound.
 TOL = {
-    torch.float16: dict(emb=1.6e-3, cls=1.0e-3, low=2.5e-3, logits=2.5e-3, argmax=0.02),
-    torch.bfloat16: dict(emb=1.3e-2, cls=8e-3, low=2e-2, logits=2e-2, argmax=0.12),
+    torch.float16: dict(emb=1e-3, cls=1e-3, low=1e-3, logits=1e-3),
+    torch.bfloat16: dict(emb=6.5e-3, cls=1.5e-3, low=9e-3, logits=8e-3),
 }
+ARGMAX_MARGIN = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # 2 x the logit tolerance
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
@@ -47,13 +52,34 @@ def test_episode_matches_reference_fixture(name, dt):
     assert rel_err(pe["class_embeddings"], gold["class_embeddings"]) <= tol["cls"]
     assert rel_err(pe["class_examples_embeddings"], gold["class_examples_embeddings"]) <= tol["cls"]
     assert rel_err(seg, gold["low_res_logits"]) <= tol["low"]
-    if "logits" in gold:
-        assert rel_err(out["logits"], gold["logits"]) <= tol["logits"]
+    ref_logits = reference_logits(case, gold, batch)            # stored, or oracle post-processing of the stored low-res logits
+    assert rel_err(out["logits"], ref_logits) <= tol["logits"]
     am = out["argmax"].cpu()
-    assert float((am != gold["argmax"].long()).float().mean()) <= tol["argmax"]
     # the index kernel itself is exact: fused argmax == argmax of the logits it wrote
     assert torch.equal(out["logits"].argmax(dim=1).cpu(), am)
+    # and equals the reference's argmax wherever the reference's top-2 margin is outside the tolerance band
+    n_diff, n_real = argmax_disagreement(out["logits"], gold["argmax"].long(), ref_logits, margin_rel=ARGMAX_MARGIN[dt])
+    assert n_real == 0, f"{n_real} of {n_diff} differing pixels have a reference margin above the tolerance band"
+    assert n_diff <= 0.02 * am.numel()
     assert out["logits"].shape == (b, gold["class_embeddings"].shape[1], *gold["argmax"].shape[-2:])
+
+
+def test_plain_16bit_operands_are_faster_but_coarser():
+    """precise=() (every encoder GEMM with single 16-bit planes) stays within 2e-3 - the round-1 configuration, kept as a
+    switch; the split-precision default must be the tighter of the two."""
+    name = "sam_tiny_2w2s_all_prompts"
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    errs = []
+    for precise in ((), None):
+        kw = {} if precise is None else {"precise": precise}
+        lam = Lam(case["cfg"], seed=case["weight_seed"], **kw).cuda()
+        lam.selected_rows = gold.get("selected_rows")
+        errs.append(rel_err(lam(batch)["logits"], gold["logits"]))
+    assert errs[0] <= 2.5e-3 and errs[1] <= 1e-3 and errs[1] < errs[0]
+    with pytest.raises(ValueError, match="unknown precise groups"):
+        Lam(case["cfg"], seed=1, precise=("mlp",)).cuda().engine()
 
 
 def test_predict_with_cached_class_embeddings_matches_forward():

@@ -491,3 +491,32 @@ def test_gemm_shape_fuzz_all_kernel_paths(L):
             tol = 2e-5 if dt == torch.float32 else 1e-3
             assert torch.isfinite(o32).all(), (m, n, k, dt)
             assert rel_err(o32, ref) < tol, (m, n, k, dt, float(rel_err(o32, ref)))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 200, 768),          # 128x128 LDS-DMA kernel
+                                 (256 * 80, 1024, 768),     # >= 512 tiles of 256x128: 256x128 kernel (K = 1536 with two planes)
+                                 (256 * 48, 3072, 1024),    # >= 512 tiles of 256x256, K = 2048: ping-pong kernel
+                                 (40, 72, 64)])             # unaligned N: register-staged kernel
+def test_gemm_split_precision_weights(L, dt, mnk):
+    """a_kmod: W = [W_hi | W_lo] against ONE 16-bit A -> the weights enter with ~2x the mantissa bits.
+    The result must match the fp32-weight product to accumulation accuracy, i.e. far below the 16-bit weight rounding."""
+    m, n, k = mnk
+    a = rnd(m, k, seed=21).to(dt)
+    w32 = rnd(n, k, seed=22) / math.sqrt(k)
+    hi = w32.to(dt)
+    lo = (w32 - hi.float()).to(dt)
+    w2 = torch.cat([hi, lo], dim=1).contiguous()
+    bias = rnd(n, seed=23)
+    ref = a.float() @ w32.t() + bias
+    o32 = torch.empty(m, n, device="cuda")
+    L.gemm(a, w2, bias=bias, out32=o32, a_kmod=k)
+    o1 = torch.empty(m, n, device="cuda")
+    L.gemm(a, hi, bias=bias, out32=o1)
+    torch.cuda.synchronize()
+    e2, e1 = rel_err(o32, ref), rel_err(o1, ref)
+    bound = 2e-6 if dt == torch.float16 else 2e-5        # fp16 planes: 22 bits; bf16 planes: 16 bits
+    assert e2 < bound, (e2, e1)
+    assert e1 > 4 * e2                                    # and the single plane really is the coarser one
+    with pytest.raises(RuntimeError, match="a_kmod"):
+        L.gemm(a, w2, out32=o32, a_kmod=k + 8)

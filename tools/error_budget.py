@@ -1,0 +1,230 @@
+"""Error budget of the 16-bit MFMA operand roundings of the image encoder (CPU emulation; diagnostic tool, not product).
+
+The HIP encoder keeps an fp32 residual stream and fp32 accumulators; what it rounds to 16 bit are the MFMA OPERANDS:
+the A side (LayerNorm output, q/k/v, softmax probabilities, attention output, GELU output, im2col patches) and the B side
+(weights, rel-pos tables).  This tool re-runs the oracle's encoder on CPU in fp32 with exactly those roundings inserted
+(``x.half().float()``), one group at a time or all but one, and reports max|d|/max|ref| on the embeddings and on the
+low-res logits of the full episode, against the un-rounded oracle.  It is how the split-precision groups of
+``LamEngine(precise=...)`` were chosen.
+
+    python tools/error_budget.py sam_tiny_2w2s_all_prompts [--dtype f16|bf16] [--only GROUPS] [--loo] [--split GROUPS]
+
+Modes per rounding point: "r" = rounded to 16 bit, "x" = exact, "s" = hi/lo split (hi = r16(x), lo = r16(x - hi); both
+kept, i.e. ~22 mantissa bits).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from labelanything_amd.episodes import make_episode  # noqa: E402
+from labelanything_amd.weights import init_state_dict  # noqa: E402
+from oracle import lam_oracle as O  # noqa: E402
+from tests.cases import CASES, geometry_for  # noqa: E402
+
+# rounding points (A = activation operand, W = weight operand)
+POINTS = ["patch.A", "patch.W", "qkv.A", "qk.W", "v.W", "attn.QK", "attn.V", "attn.T", "attn.P", "proj.A", "proj.W",
+          "lin1.A", "lin1.W", "lin2.A", "lin2.W", "neck.A", "neck.W"]
+
+
+class Policy:
+    def __init__(self, dtype, modes):
+        self.dt = dtype
+        self.modes = modes          # point -> "r" | "x" | "s"   (optionally "point@block" overrides)
+
+    def r16(self, x):
+        return x.to(self.dt).float()
+
+    def __call__(self, point, x, block=None):
+        m = self.modes.get(f"{point}@{block}", self.modes.get(point, "x"))
+        if m == "x":
+            return x
+        hi = self.r16(x)
+        if m == "r":
+            return hi
+        return hi + self.r16(x - hi)
+
+
+def lin(pol, point, w, name, x, block=None):
+    wt = pol(point + ".W", w[name + ".weight"], block)
+    return F.linear(pol(point + ".A", x, block), wt, w.get(name + ".bias"))
+
+
+def sam_attention(pol, w, pre, x, heads, blk):
+    n, gh, gw, e = x.shape
+    hd = e // heads
+    t = gh * gw
+    wq = w[pre + ".qkv.weight"]
+    wq = torch.cat([pol("qk.W", wq[:2 * e], blk), pol("v.W", wq[2 * e:], blk)])
+    qkv = F.linear(pol("qkv.A", x.reshape(n, t, e), blk), wq, w[pre + ".qkv.bias"])
+    qkv = qkv.view(n, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = pol("attn.QK", qkv[0], blk), pol("attn.QK", qkv[1], blk), pol("attn.V", qkv[2], blk)
+    scores = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
+    rh = pol("attn.T", O.rel_pos_table(gh, gh, w[pre + ".rel_pos_h"]), blk)
+    rw = pol("attn.T", O.rel_pos_table(gw, gw, w[pre + ".rel_pos_w"]), blk)
+    qg = q.reshape(n, heads, gh, gw, hd)
+    bias_h = torch.einsum("nhyxc,ykc->nhyxk", qg, rh)
+    bias_w = torch.einsum("nhyxc,xkc->nhyxk", qg, rw)
+    scores = scores.view(n, heads, gh, gw, gh, gw) + bias_h[..., :, None] + bias_w[..., None, :]
+    scores = scores.view(n, heads, t, t)
+    # flash form: P = exp(s - max) rounded to 16 bit for the PV MFMA, the row sum taken from the UN-rounded fp32 values
+    mx = scores.max(dim=-1, keepdim=True).values
+    pe = torch.exp(scores - mx)
+    o = (pol("attn.P", pe, blk) @ v) / pe.sum(dim=-1, keepdim=True)
+    o = o.transpose(1, 2).reshape(n, gh, gw, e)
+    return lin(pol, "proj", w, pre + ".proj", o, blk)
+
+
+def sam_encoder(pol, w, geo, images, pre="image_encoder"):
+    x = F.conv2d(pol("patch.A", images), pol("patch.W", w[pre + ".patch_embed.proj.weight"]),
+                 w[pre + ".patch_embed.proj.bias"], stride=geo.patch).permute(0, 2, 3, 1)
+    x = x + w[pre + ".pos_embed"]
+    for i in range(geo.enc_depth):
+        bp = f"{pre}.blocks.{i}"
+        win = 0 if i in geo.global_idx else geo.window
+        y = O.layer_norm(w, bp + ".norm1", x, 1e-6)
+        if win > 0:
+            h, wd = y.shape[1], y.shape[2]
+            y, padded = O.window_split(y, win)
+            y = sam_attention(pol, w, bp + ".attn", y, geo.enc_heads, i)
+            y = O.window_merge(y, win, padded, (h, wd))
+        else:
+            y = sam_attention(pol, w, bp + ".attn", y, geo.enc_heads, i)
+        x = x + y
+        z = O.layer_norm(w, bp + ".norm2", x, 1e-6)
+        z = lin(pol, "lin2", w, bp + ".mlp.lin2", O.gelu(lin(pol, "lin1", w, bp + ".mlp.lin1", z, i)), i)
+        x = x + z
+    last = x.permute(0, 3, 1, 2)
+    if not geo.sam_neck:
+        return last
+    return conv_neck(pol, w, pre + ".neck", last)
+
+
+def conv_neck(pol, w, pre, x):
+    x = F.conv2d(pol("neck.A", x), pol("neck.W", w[pre + ".0.weight"]))
+    x = O.layer_norm_2d(w, pre + ".1", x)
+    x = F.conv2d(pol("neck.A", x), pol("neck.W", w[pre + ".2.weight"]), padding=1)
+    return O.layer_norm_2d(w, pre + ".3", x)
+
+
+def hf_encoder(pol, w, geo, images, pre="image_encoder"):
+    bn = images.shape[0]
+    g = images.shape[-1] // geo.patch
+    e, heads = geo.enc_dim, geo.enc_heads
+    hd = e // heads
+    x = F.conv2d(pol("patch.A", images), pol("patch.W", w[pre + ".embeddings.patch_embeddings.projection.weight"]),
+                 w[pre + ".embeddings.patch_embeddings.projection.bias"], stride=geo.patch)
+    x = x.flatten(2).transpose(1, 2)
+    x = torch.cat([w[pre + ".embeddings.cls_token"].expand(bn, -1, -1), x], dim=1)
+    x = x + O.hf_pos_embed(w, pre, g, geo.hf_pos_grid)
+    t = x.shape[1]
+    for i in range(geo.enc_depth):
+        lp = f"{pre}.encoder.layer.{i}"
+        y = O.layer_norm(w, lp + ".layernorm_before", x, 1e-12)
+        ya = pol("qkv.A", y, i)
+        q, k, v = (F.linear(ya, pol("v.W" if n == "value" else "qk.W", w[f"{lp}.attention.attention.{n}.weight"], i),
+                            w[f"{lp}.attention.attention.{n}.bias"]).view(bn, t, heads, hd).transpose(1, 2)
+                   for n in ("query", "key", "value"))
+        q, k, v = pol("attn.QK", q, i), pol("attn.QK", k, i), pol("attn.V", v, i)
+        scores = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        mx = scores.max(dim=-1, keepdim=True).values
+        pe = torch.exp(scores - mx)
+        o = (pol("attn.P", pe, i) @ v) / pe.sum(dim=-1, keepdim=True)
+        o = o.transpose(1, 2).reshape(bn, t, e)
+        x = x + lin(pol, "proj", w, lp + ".attention.output.dense", o, i)
+        y = O.layer_norm(w, lp + ".layernorm_after", x, 1e-12)
+        y = O.gelu(lin(pol, "lin1", w, lp + ".intermediate.dense", y, i))
+        x = x + lin(pol, "lin2", w, lp + ".output.dense", y, i)
+    x = O.layer_norm(w, pre + ".layernorm", x, 1e-12)
+    return x[:, 1:, :].reshape(bn, g, g, e).permute(0, 3, 1, 2).contiguous()
+
+
+def run(pol, w, geo, batch, rows):
+    """Oracle forward with the emulated encoder; returns (embeddings, low_res_logits, logits)."""
+    if "images" in batch:
+        im = batch["images"]
+        b, n = im.shape[:2]
+        enc = sam_encoder if geo.encoder == "sam" else hf_encoder
+        e = enc(pol, w, geo, im.flatten(0, 1))
+    else:
+        e = batch["embeddings"]
+        b, n = e.shape[:2]
+        e = e.flatten(0, 1)
+    if geo.lam_neck:
+        e = conv_neck(pol, w, "neck", e)
+    emb = e.view(b, n, *e.shape[1:])
+    pts, bxs, msk = O.select_prompts(batch)
+    pe = O.prompt_encoder(w, geo, emb[:, 1:], pts, bxs, msk, batch["flag_examples"], rows)
+    low = O.mask_decoder(w, geo, emb[:, 0], pe["class_embeddings"])
+    return emb, low, pe["class_embeddings"]
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def rms(a, b):
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("case")
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--one-in", action="store_true", help="round ONE point at a time")
+    ap.add_argument("--loo", action="store_true", help="round all points but one")
+    ap.add_argument("--split", default="", help="comma list of points kept as hi/lo pairs (others rounded)")
+    ap.add_argument("--exact", default="", help="comma list of points kept exact (others rounded)")
+    ap.add_argument("--threads", type=int, default=0)
+    a = ap.parse_args()
+    if a.threads:
+        torch.set_num_threads(a.threads)
+    dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
+    case = CASES[a.case]
+    cfg = case["cfg"]
+    geo = geometry_for(cfg)
+    w = init_state_dict(cfg, seed=case["weight_seed"])
+    batch = make_episode(**case["episode"])
+    rows = None
+    if cfg.bank_size:
+        from tests.helpers import load_golden
+        rows = load_golden(a.case)[0].get("selected_rows")
+
+    def report(tag, modes):
+        t0 = time.time()
+        emb, low, cls = run(Policy(dt, modes), w, geo, batch, rows)
+        print(f"{tag:34s} emb {rel(emb, ref[0]):.3e} (rms {rms(emb, ref[0]):.3e})  cls {rel(cls, ref[2]):.3e}  "
+              f"low {rel(low, ref[1]):.3e} (rms {rms(low, ref[1]):.3e})   [{time.time() - t0:.1f}s]", flush=True)
+
+    with torch.no_grad():
+        t0 = time.time()
+        ref = run(Policy(dt, {}), w, geo, batch, rows)
+        print(f"reference run {time.time() - t0:.1f}s")
+        allr = {p: "r" for p in POINTS}
+        modes = dict(allr)
+        for p in filter(None, a.split.split(",")):
+            modes[p] = "s"
+        for p in filter(None, a.exact.split(",")):
+            modes[p] = "x"
+        report("all rounded" if modes == allr else f"split={a.split} exact={a.exact}", modes)
+        if a.one_in:
+            for p in POINTS:
+                report("only " + p, {p: "r"})
+        if a.loo:
+            for p in POINTS:
+                m = dict(allr)
+                m[p] = "x"
+                report("all but " + p, m)
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        main()

@@ -6,17 +6,23 @@ import torch
 from labelanything_amd.models import Lam
 from labelanything_amd.episodes import make_episode
 from tests.cases import CASES
-from tests.helpers import load_golden, rel_err
+from labelanything_amd.engine import PRECISE_DEFAULT
+from tests.helpers import load_golden, rel_err, reference_logits, argmax_disagreement
 
 
 def main():
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
-    for dt, ddt in ((torch.float16, torch.float32), (torch.float16, None), (torch.bfloat16, torch.float32)):
+    variants = [(torch.float16, torch.float32, PRECISE_DEFAULT), (torch.float16, torch.float32, ()),
+                (torch.float16, torch.float32, ("patch", "qkv", "proj", "lin1", "lin2", "neck")),
+                (torch.float16, None, PRECISE_DEFAULT), (torch.bfloat16, torch.float32, PRECISE_DEFAULT)]
+    if "--quick" in sys.argv:
+        variants = variants[:2]
+    for dt, ddt, precise in variants:
         for name, case in CASES.items():
             if only and name not in only:
                 continue
             gold, meta = load_golden(name)
-            lam = Lam(case["cfg"], seed=case["weight_seed"], compute_dtype=dt, decoder_dtype=ddt).cuda()
+            lam = Lam(case["cfg"], seed=case["weight_seed"], compute_dtype=dt, decoder_dtype=ddt, precise=precise).cuda()
             lam.selected_rows = gold.get("selected_rows")
             batch = make_episode(**case["episode"])
             t0 = time.time()
@@ -50,7 +56,12 @@ def main():
             errs["argmax_mismatch_frac"] = mism / ref_am.numel()
             am2 = out["logits"].argmax(1).cpu()
             errs["fused_argmax_vs_torch"] = int((am2 != am).sum())
-            print(f"[{name} enc={str(dt)[6:]} dec={str(ddt)[6:] if ddt else 'same'}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
+            ref_logits = reference_logits(case, gold, batch)
+            errs["logits_vs_ref"] = rel_err(out["logits"], ref_logits)
+            n_diff, n_real = argmax_disagreement(out["logits"], ref_am, ref_logits, margin_rel=2e-3)
+            errs["argmax_diff_outside_2e-3_margin"] = n_real
+            ptag = "default" if tuple(precise) == tuple(PRECISE_DEFAULT) else ("none" if not precise else "+".join(precise))
+            print(f"[{name} enc={str(dt)[6:]} dec={str(ddt)[6:] if ddt else 'same'} precise={ptag}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
             del lam
             torch.cuda.empty_cache()
 
