@@ -896,6 +896,151 @@ static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
 }
 
+// =================================================================================================================
+// v7 "t256": 256 x 256 x 32 tile, 8 waves (2 x 4, 128 x 64 per wave = 4 x 2 MFMA 32x32 accumulators), symmetric waves,
+// one barrier per k-step, LDS-DMA ring with counted vmcnt, and NPL weight PLANES per k-step:
+//   NPL = 1  C = A . W^T                                   ring of 4 stages x 32 KiB
+//   NPL = 2  C = A . W_hi^T + A . W_lo^T  (split precision) ring of 3 stages x 48 KiB
+// With two planes every A fragment feeds TWO MFMAs, so a k-step carries 32 MFMAs per wave against 16 fragment reads and
+// 6 DMA pieces: 24 B/clk/CU of operand stream at the full matrix rate against the ~30 B/clk/CU LDS-DMA ceiling
+// (profiles/r01_gemm_ablation.md 7) - the shape at which the split-precision GEMMs are matrix-pipe bound instead of
+// stream bound, which is what makes the second plane cheaper than a second GEMM.  W = [W_hi | W_lo] per row (ldw = 2 K).
+// Rows are 64 B (BK = 32): chunk c of row r lives in slot c ^ ((r >> 2) & 3) (same image as the 256 x 128 kernel).
+// =================================================================================================================
+template <typename T, int NPL>
+__global__ __launch_bounds__(512, 2) void gemm_t256_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                            int M, int N, int K, LaGemmEpilogue e, int gm) {
+  constexpr int BK_ = 32;
+  constexpr int OPB = 256 * BK_ * 2;                 // 16 KiB per operand tile
+  constexpr int STAGE = OPB * (1 + NPL);
+  constexpr int NST = (NPL == 2) ? 3 : 4;
+  constexpr int NP = 2 * (1 + NPL);                  // DMA pieces per wave per k-step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wi = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ntn = (N + 255) / 256, ntm = (M + 255) / 256;
+  int tm_, tn_;
+  tile_coords(xcd_remap(blockIdx.x, ntm * ntn), ntm, ntn, gm, tm_, tn_);
+  const int m0 = tm_ * 256, n0 = tn_ * 256;
+
+  // DMA plan: operand o (0 = A, 1 = W_hi, 2 = W_lo), piece i of this wave = tile rows [(wave + 8 i) 16, +16)
+  unsigned soff[1 + NPL][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave + 8 * i) * 16 + (lane >> 2);
+    const int ch = ((lane & 3) ^ ((r >> 2) & 3)) << 3;
+    soff[0][i] = (unsigned)(((size_t)a_row(e, min(m0 + r, M - 1)) * lda + ch) * sizeof(T));
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) soff[1 + pl][i] = (unsigned)(((size_t)min(n0 + r, N - 1) * ldw + pl * K + ch) * sizeof(T));
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma = [&](int kt, int stage) {
+    const unsigned base = lds0 + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int o = 0; o < 1 + NPL; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16s((o ? Wt : A) + kt * BK_, soff[o][i], base + o * OPB + i * 8192);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- main loop: the two wave groups (one wave of each per SIMD) run ONE BARRIER OUT OF PHASE -------------------------
+  //   interval      2t      2t+1     2t+2     2t+3          L(t): issue the DMA pieces of k-step t + NST - 1, fetch ALL
+  //   group 0      L(t)     M(t)    L(t+1)   M(t+1)               fragments of k-step t, retire the reads (lgkmcnt 0)
+  //   group 1     M(t-1)    L(t)     M(t)    L(t+1)         M(t): the 16 NPL MFMAs of the k-step, nothing else
+  // so each SIMD's matrix pipe always has exactly one wave feeding it while the other wave does the memory work.
+  // Hazards (every interval ends with a workgroup barrier):
+  //   RAW  k-step t+1 is first read in interval 2t+2 (group 0): every wave retires ITS pieces of t+1 with a counted vmcnt
+  //        before the barrier closing interval 2t+1 - group 0 at the end of M(t), group 1 at the end of L(t).
+  //   WAR  the stage of k-step t is last read in interval 2t+1 (group 1's L(t), reads retired before its barrier) and is
+  //        restaged with k-step t + NST by L(t+1), i.e. from interval 2t+2 on.
+  const int nk = K / BK_;
+  uint4 af[2][4], wf[2][NPL][2];
+  auto load_frags = [&](int stage) {
+    const char* sa = smem + stage * STAGE;
+    const char* sw = sa + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const uint4*>(sa + swz64_off(grp * 128 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[ks][pl][j] = *reinterpret_cast<const uint4*>(sw + pl * OPB + swz64_off(wi * 64 + j * 32 + fr, ks * 2 + fh));
+    }
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // retire this wave's pieces of k-step kt + 1: the (up to NST - 2) younger k-steps may stay in flight
+  auto retire_next = [&](int kt) {
+    const int younger = min(NST - 2, nk - 2 - kt);
+    if (younger >= 2) dma_wait<2 * NP>();
+    else if (younger == 1) dma_wait<NP>();
+    else dma_wait<0>();
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) dma(s, s);
+  retire_next(-1);                                   // k-step 0 resident ...
+  bar();                                             // ... for everybody
+  if (grp == 1) bar();                               // group 1 runs one interval behind
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- L(kt) ------------------------------------------------------------------------------------------------------
+    {
+      int ps = stage + NST - 1;
+      if (ps >= NST) ps -= NST;
+      if (kt + NST - 1 < nk) dma(kt + NST - 1, ps);
+    }
+    load_frags(stage);
+    if (grp == 1) retire_next(kt);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    // ---- M(kt) ------------------------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[ks][i], wf[ks][pl][j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) retire_next(kt);
+    bar();
+    stage = (stage == NST - 1) ? 0 : stage + 1;
+  }
+  if (grp == 0) bar();                               // re-align the two groups
+  __syncthreads();
+  epilogue_256<T>(smem, acc, grp, wi * 64, m0, n0, M, N, e, tid);
+}
+
+template <typename T, int NPL>
+static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = (NPL == 2) ? 3 * 49152 : 4 * 32768;      // 144 / 128 KiB (epilogue chunk: 68 KiB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256_kernel<T, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  const int ntm = (M + 255) / 256, ntn = (N + 255) / 256;
+  hipLaunchKernelGGL((gemm_t256_kernel<T, NPL>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
+}
+
 template <typename T, int BM_>
 static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = fast_lds_bytes<BM_>();
@@ -1240,7 +1385,20 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     bool pp = (K > 1536) && (tiles_pp >= 512);
     if (force) pp = force[0] == '6';
     pp = pp && (!epi->vt || (epi->vt_col0 % la::PP_BN) == 0);
-    if (pp) {
+    // two weight planes against one A ([W_hi | W_lo], a_kmod = K / 2): the 256 x 256 two-plane kernel, which reuses every A fragment
+    // for both planes; LA_GEMM_PATH=7 also sends single-plane shapes through its NPL = 1 form (A/B experiments)
+    const bool planes2 = epi->a_kmod > 0 && K == 2 * epi->a_kmod;
+    bool t256 = planes2 && tiles_pp >= 128 && (!epi->vt || (epi->vt_col0 % 256) == 0);
+    if (force) t256 = (force[0] == '7') && (planes2 || epi->a_kmod == 0) && (!epi->vt || (epi->vt_col0 % 256) == 0);
+    if (t256) {
+      if (planes2) {
+        if (dt == LA_F16) la::launch_t256<la::f16_t, 2>(A, lda, W, ldw, M, N, K / 2, *epi, st);
+        else la::launch_t256<la::bf16_t, 2>(A, lda, W, ldw, M, N, K / 2, *epi, st);
+      } else {
+        if (dt == LA_F16) la::launch_t256<la::f16_t, 1>(A, lda, W, ldw, M, N, K, *epi, st);
+        else la::launch_t256<la::bf16_t, 1>(A, lda, W, ldw, M, N, K, *epi, st);
+      }
+    } else if (pp) {
       if (dt == LA_F16) la::launch_pp<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
       else la::launch_pp<la::bf16_t>(A, lda, W, ldw, M, N, K, *epi, st);
     } else if (v4) {
