@@ -896,6 +896,222 @@ static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
 }
 
+// Epilogue of gemm_t256_kernel: the tile leaves in four 64-row chunks (wave group g holds rows [128 g, +128) = chunks 2g, 2g+1)
+// through TWO staging buffers, in the order g0/h0, g1/h0, g0/h1, g1/h1: while every thread turns chunk p into 16-byte global
+// stores, the owning group already writes chunk p+1 into the other buffer - one barrier per chunk, and the residual rows of
+// a chunk are requested before that barrier.  A thread owns 8 consecutive columns (bias, column mapping: per-thread
+// constants for the whole tile) of rows r0 + 16 k.  Transposed-V tiles take the column-major path of epilogue_256.
+//
+// CODE SIZE is what this epilogue is tuned for: it runs once per tile, so every instruction of it is an instruction-cache
+// miss (a fully unrolled generic version made the kernel 147 KB and cost 8-20 us per tile, more than the data movement).
+// The chunk loop is a real loop, and EPI specialises the per-element work at compile time for the four hot GEMMs:
+//   EPI 1  bias -> 16-bit                  (qkv)          EPI 3  bias + fp32 residual -> fp32 [+ 16-bit]   (proj, lin2)
+//   EPI 2  bias -> GELU -> 16-bit          (lin1)         EPI 0  everything at run time (maps, ReLU, res_mod, ...)
+template <int EPI> struct EpiTraits {
+  static constexpr bool generic = (EPI == 0);
+};
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_t256(char* smem, const f32x16 (&acc)[4][2], int grp, int wcol, int m0, int n0, int M, int N,
+                                              const LaGemmEpilogue& e, int tid) {
+  constexpr bool GEN = (EPI == 0);
+  // LDS-only barrier: __syncthreads() would also wait for every outstanding global store / residual load (its fence drains
+  // vmcnt), i.e. each chunk would pay a full store round trip; here only the LDS traffic has to be ordered
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  T* vt = reinterpret_cast<T*>(e.vt);
+  if (GEN && vt != nullptr && n0 >= e.vt_col0) {
+    epilogue_256<T>(smem, acc, grp, wcol, m0, n0, M, N, e, tid);
+    return;
+  }
+  if (EPI == 1 && vt != nullptr && n0 >= e.vt_col0) {
+    // Transposed-V tile, identity row map: the same two-buffer chunk pipeline with COLUMN-major staging [256 cols][64 rows + 4],
+    // so that 4 consecutive tokens of one V column are one float4 and leave as one 8-byte store into vt[(b, head, d)][slot].
+    constexpr int LDT = 64 + 4;
+    constexpr int BUFT = 256 * LDT;                   // floats per buffer (69 632 B)
+    float* epi = reinterpret_cast<float*>(smem);
+    const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+    auto stageT0 = [&](float* buf) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<float4*>(&buf[(wcol + tj * 32 + fr) * LDT + t2 * 32 + 8 * g4 + 4 * fh]) =
+                make_float4(acc[t2][tj][g4 * 4], acc[t2][tj][g4 * 4 + 1], acc[t2][tj][g4 * 4 + 2], acc[t2][tj][g4 * 4 + 3]);
+    };
+    auto stageT1 = [&](float* buf) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<float4*>(&buf[(wcol + tj * 32 + fr) * LDT + t2 * 32 + 8 * g4 + 4 * fh]) =
+                make_float4(acc[2 + t2][tj][g4 * 4], acc[2 + t2][tj][g4 * 4 + 1], acc[2 + t2][tj][g4 * 4 + 2], acc[2 + t2][tj][g4 * 4 + 3]);
+    };
+    if (grp == 0) stageT0(epi);
+    const bool quad_ok = (e.vt_T & 3) == 0;
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+      const int mrow0 = m0 + 128 * (p & 1) + 64 * (p >> 1);
+      const float* buf = epi + (p & 1) * BUFT;
+      lds_barrier();
+      if (p + 1 < 4 && grp == ((p + 1) & 1)) {
+        float* nb = epi + ((p + 1) & 1) * BUFT;
+        if (p + 1 < 2) stageT0(nb);
+        else stageT1(nb);
+      }
+#pragma unroll 2
+      for (int it = tid; it < 256 * 16; it += 512) {
+        const int rg = it & 15, c = it >> 4;
+        const int col = n0 + c, row = mrow0 + rg * 4;
+        if (col >= N || row >= M) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&buf[c * LDT + rg * 4]);
+        const float bias = e.bias ? e.bias[col] : 0.f;
+        const int cv = col - e.vt_col0;
+        const int vhead = cv / e.vt_hd, vd = cv % e.vt_hd;
+        const int b = row / e.vt_T, t = row % e.vt_T;
+        T* rowp = vt + ((size_t)(b * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad;
+        T* dst = rowp + vt_slot(t, e.vt_ws);
+        if (quad_ok && row + 3 < M && (e.vt_ws == 0 || (e.vt_ws & 3) == 0 || (t % e.vt_ws) <= e.vt_ws - 4)) {
+          store4v<T>(dst, v.x + bias, v.y + bias, v.z + bias, v.w + bias);      // 4 consecutive tokens, contiguous slots
+        } else if (quad_ok && row + 3 < M && e.vt_ws > 0 && (e.vt_ws & 1) == 0) {
+          store2<T>(dst, v.x + bias, v.y + bias);                               // the quad straddles a window row: two pairs
+          store2<T>(rowp + vt_slot(t + 2, e.vt_ws), v.z + bias, v.w + bias);
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4; ++j) {
+            const int rj = row + j;
+            if (rj >= M) break;
+            const int bj = rj / e.vt_T, tj2 = rj % e.vt_T;
+            vt[((size_t)(bj * e.vt_heads + vhead) * e.vt_hd + vd) * e.vt_Tpad + vt_slot(tj2, e.vt_ws)] = (T)(vv[j] + bias);
+          }
+        }
+      }
+    }
+    return;
+  }
+  constexpr int LD = 256 + 4;
+  constexpr int BUF = 64 * LD;                        // floats per staging buffer (66 560 B)
+  float* epi = reinterpret_cast<float*>(smem);
+  const int lane = tid & 63, fr = lane & 31, fh = lane >> 5;
+  const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+  T* outT = reinterpret_cast<T*>(e.out16);
+  float* out32 = (GEN || EPI == 3) ? e.out32 : nullptr;
+  const float* res = (GEN || EPI == 3) ? e.res : nullptr;
+  const int act = GEN ? e.act : (EPI == 2 ? LA_ACT_GELU : LA_ACT_NONE);
+  const int cg = tid & 31, r0 = tid >> 5;             // 8 columns cg*8.., rows r0 + 16 k of every chunk
+  const int col0 = n0 + cg * 8;
+  const bool col_ok = col0 < N;
+  int dcol = col0, row_add = 0, bcol = col0;
+  if (GEN && e.map == LA_MAP_CONVT2X2) {
+    const int kyx = col0 / e.p2;
+    dcol = col0 % e.p2;
+    bcol = dcol;
+    row_add = (kyx >> 1) * 2 * e.p0 + (kyx & 1);
+  }
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e.bias && col_ok) {
+    const float4 b0 = *reinterpret_cast<const float4*>(e.bias + bcol);
+    const float4 b1 = *reinterpret_cast<const float4*>(e.bias + bcol + 4);
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+  }
+  const bool fast_gelu = !out32;                      // the result only survives as a 16-bit value
+  // this wave's rows [64 half, +64) of its 128 -> buf rows 0..63 (the half is static: accumulator registers cannot be indexed at
+  // run time).  One opaque per-lane base + compile-time offsets: without the asm the compiler hoists all 64 addresses of both
+  // buffers out of the chunk loop and spills them.
+  auto stage0 = [&](float* buf) {
+    float* wb = buf + (4 * fh) * LD + wcol + fr;
+    asm volatile("" : "+v"(wb));
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wb[(t2 * 32 + (r & 3) + 8 * (r >> 2)) * LD + tj * 32] = acc[t2][tj][r];
+  };
+  auto stage1 = [&](float* buf) {
+    float* wb = buf + (4 * fh) * LD + wcol + fr;
+    asm volatile("" : "+v"(wb));
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wb[(t2 * 32 + (r & 3) + 8 * (r >> 2)) * LD + tj * 32] = acc[2 + t2][tj][r];
+  };
+  float4 rv[4][2];
+  auto dest_row = [&](int p, int k) {
+    const int row = m0 + 128 * (p & 1) + 64 * (p >> 1) + r0 + 16 * k;
+    int d = (row < M && col_ok) ? ((!GEN || rm.mode == LA_MAP_NONE) ? row : map_row(rm, row)) : -1;
+    if (GEN && d >= 0) d += row_add;
+    return d;
+  };
+  auto fetch_res = [&](int d, float4 (&r_)[2]) {
+    r_[0] = r_[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res && d >= 0) {
+      const int rr = (GEN && e.res_mod) ? d % e.res_mod : d;
+      r_[0] = *reinterpret_cast<const float4*>(res + (size_t)rr * e.ldr + dcol);
+      r_[1] = *reinterpret_cast<const float4*>(res + (size_t)rr * e.ldr + dcol + 4);
+    }
+  };
+  if (grp == 0) stage0(epi);
+#pragma unroll 1
+  for (int p = 0; p < 4; ++p) {
+    const float* buf = epi + (p & 1) * BUF + r0 * LD + cg * 8;      // this thread's first item (opaque: see stage0)
+    asm volatile("" : "+v"(buf));
+    if (GEN || EPI == 3) {                             // residual rows of this chunk, requested in front of the barrier
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fetch_res(dest_row(p, k), rv[k]);
+    }
+    lds_barrier();                                     // chunk p staged; buffer (p+1)&1 no longer read by anyone
+    if (p + 1 < 4 && grp == ((p + 1) & 1)) {
+      float* nb = epi + ((p + 1) & 1) * BUF;
+      if (p + 1 < 2) stage0(nb);
+      else stage1(nb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int d = dest_row(p, k);
+      float v[8];
+      {
+        const float4 a0 = *reinterpret_cast<const float4*>(&buf[16 * k * LD]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&buf[16 * k * LD + 4]);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += bv[j];
+      if (act == LA_ACT_GELU) {
+        if (!GEN || fast_gelu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf_fast(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+        }
+      } else if (GEN && act == LA_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (GEN || EPI == 3) {
+        v[0] += rv[k][0].x; v[1] += rv[k][0].y; v[2] += rv[k][0].z; v[3] += rv[k][0].w;
+        v[4] += rv[k][1].x; v[5] += rv[k][1].y; v[6] += rv[k][1].z; v[7] += rv[k][1].w;
+      }
+      if (d >= 0) {
+        if (out32) store8<float>(out32 + (size_t)d * e.ld32 + dcol, v);
+        if (outT) store8<T>(outT + (size_t)d * e.ld16 + dcol, v);
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep the items apart: interleaving all four costs registers (spills)
+    }
+  }
+}
+
 // =================================================================================================================
 // v7 "t256": 256 x 256 x 32 tile, 8 waves (2 x 4, 128 x 64 per wave = 4 x 2 MFMA 32x32 accumulators), symmetric waves,
 // one barrier per k-step, LDS-DMA ring with counted vmcnt, and NPL weight PLANES per k-step:
@@ -907,7 +1123,7 @@ static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int
 // stream bound, which is what makes the second plane cheaper than a second GEMM.  W = [W_hi | W_lo] per row (ldw = 2 K).
 // Rows are 64 B (BK = 32): chunk c of row r lives in slot c ^ ((r >> 2) & 3) (same image as the 256 x 128 kernel).
 // =================================================================================================================
-template <typename T, int NPL>
+template <typename T, int NPL, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_t256_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
                                                             int M, int N, int K, LaGemmEpilogue e, int gm) {
   constexpr int BK_ = 32;
@@ -1025,20 +1241,30 @@ __global__ __launch_bounds__(512, 2) void gemm_t256_kernel(const T* __restrict__
   }
   if (grp == 0) bar();                               // re-align the two groups
   __syncthreads();
-  epilogue_256<T>(smem, acc, grp, wi * 64, m0, n0, M, N, e, tid);
+  epilogue_t256<T, EPI>(smem, acc, grp, wi * 64, m0, n0, M, N, e, tid);
 }
 
-template <typename T, int NPL>
-static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-  constexpr int LDS = (NPL == 2) ? 3 * 49152 : 4 * 32768;      // 144 / 128 KiB (epilogue chunk: 68 KiB)
+template <typename T, int NPL, int EPI>
+static void launch_t256_epi(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = (NPL == 2) ? 3 * 49152 : 136 * 1024;     // ring 144 / 128 KiB; epilogue: two staging buffers of 65 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256_kernel<T, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256_kernel<T, NPL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   const int ntm = (M + 255) / 256, ntn = (N + 255) / 256;
-  hipLaunchKernelGGL((gemm_t256_kernel<T, NPL>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+  hipLaunchKernelGGL((gemm_t256_kernel<T, NPL, EPI>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
+}
+
+// pick the compile-time epilogue variant that covers this call (see epilogue_t256)
+template <typename T, int NPL>
+static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  const bool plain = e.map == LA_MAP_NONE && e.res_mod == 0;
+  if (plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) launch_t256_epi<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
+  else if (plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) launch_t256_epi<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
+  else if (plain && e.act == LA_ACT_NONE && e.res && e.out32 && !e.vt) launch_t256_epi<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);
+  else launch_t256_epi<T, NPL, 0>(A, lda, W, ldw, M, N, K, e, st);
 }
 
 template <typename T, int BM_>
@@ -1388,7 +1614,9 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     // two weight planes against one A ([W_hi | W_lo], a_kmod = K / 2): the 256 x 256 two-plane kernel, which reuses every A fragment
     // for both planes; LA_GEMM_PATH=7 also sends single-plane shapes through its NPL = 1 form (A/B experiments)
     const bool planes2 = epi->a_kmod > 0 && K == 2 * epi->a_kmod;
-    bool t256 = planes2 && tiles_pp >= 128 && (!epi->vt || (epi->vt_col0 % 256) == 0);
+    // ... and, measured on MI355X (tools/gemm_planes_bench.py), its single-plane form beats the 256 x 128, the 128 x 128 and the older
+    // ping-pong kernel on every shape with >= 2 full rounds of 256 x 256 tiles (K = 768: +10-15 %, K = 3072: equal)
+    bool t256 = ((planes2 && tiles_pp >= 128) || (epi->a_kmod == 0 && tiles_pp >= 512)) && (!epi->vt || (epi->vt_col0 % 256) == 0);
     if (force) t256 = (force[0] == '7') && (planes2 || epi->a_kmod == 0) && (!epi->vt || (epi->vt_col0 % 256) == 0);
     if (t256) {
       if (planes2) {
