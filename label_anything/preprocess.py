@@ -140,7 +140,8 @@ def preprocess_images_to_embeddings_huggingface(model_name, directory, batch_siz
                        mlp=hc["intermediate_size"], patch=hc.get("patch_size", 16), img_size=hc.get("image_size", 224))
     name = "hf:" + os.path.abspath(model_name)
     register_encoder(name, spec)
-    lam = Lam(LamConfig(encoder=name, image_size=image_resolution, image_embed_dim=spec.dim), compute_dtype=compute_dtype)
+    lam = Lam(LamConfig(encoder=name, image_size=image_resolution, image_embed_dim=spec.dim, vit_patch_size=spec.patch),
+              compute_dtype=compute_dtype)
     wpath = os.path.join(model_name, "model.safetensors")
     sd = load_file(wpath) if os.path.exists(wpath) else torch.load(os.path.join(model_name, "pytorch_model.bin"), map_location="cpu")
     sd = {(k[len("vit."):] if k.startswith("vit.") else k): v for k, v in sd.items() if not k.startswith("decoder.")}

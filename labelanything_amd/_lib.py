@@ -81,8 +81,13 @@ def dt_of(t: torch.Tensor) -> int:
 
 
 def _dev(t: torch.Tensor) -> None:
+    """Every launch goes to the CURRENT device's current stream: refuse tensors that live elsewhere instead of enqueueing a
+    kernel on another GPU's stream (single-process multi-GPU hosts must wrap calls in ``torch.cuda.device(t.device)``)."""
     if not t.is_cuda:
         raise RuntimeError("labelanything_amd kernels need device tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           "wrap the call in `with torch.cuda.device(tensor.device)`")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -105,7 +105,7 @@ class LamConfig:
 
 
 _OFF_PATH_DEFAULTS = dict(
-    checkpoint=None, use_sam_checkpoint=False, class_embedding_dim=None,
+    class_embedding_dim=None,
     encoder_attention_downsample_rate=2, decoder_attention_downsample_rate=2,
     classification_layer_downsample_rate=8, use_support_features_in_prompt_encoder=True,
     fusion_transformer="TwoWayTransformer", few_type="Prototype", class_fusion="sum",
@@ -120,7 +120,7 @@ def config_from_kwargs(**kw) -> LamConfig:
     for k, dflt in _OFF_PATH_DEFAULTS.items():
         if k in kw:
             v = kw.pop(k)
-            if k in ("checkpoint", "use_sam_checkpoint", "dropout"):
+            if k == "dropout":          # dropout is an inference no-op (eval mode); accepted like the reference does
                 continue
             if v != dflt:
                 raise NotImplementedError(f"{k}={v!r} is an off-path ablation of the reference; only {dflt!r} is built")

@@ -58,6 +58,22 @@ class _EncoderHandle(_Tree):
         return owner.encode_images_nchw(x, return_last_block_state=return_last_block_state)
 
 
+def _on_model_device(fn):
+    """Run a Lam entry point with the model's GPU as the current device: every kernel is enqueued on the CURRENT device's
+    stream (labelanything_amd._lib), so a model living on cuda:N must not launch from a host thread whose current device is
+    another GPU (single-process multi-GPU hosts)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        dev = self._device()
+        if dev.type != "cuda":
+            return fn(self, *a, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *a, **kw)
+    return wrapper
+
+
 class Lam(nn.Module):
     mask_threshold: float = 0.0
     image_format: str = "RGB"
@@ -129,6 +145,11 @@ class Lam(nn.Module):
         return super()._apply(fn, *a, **kw)
 
     # -- reference API --------------------------------------------------------------------------------
+    def init_pretrained_weights(self, weights) -> None:
+        """Seed the encoder and the SAM-shaped decoder parts from a Segment-Anything state dict (models/lam.py:241-319)."""
+        init_pretrained_weights(self, weights)
+
+    @_on_model_device
     def get_dense_pe(self) -> torch.Tensor:
         eng = self.engine()
         g = self.cfg.grid
@@ -282,6 +303,7 @@ class Lam(nn.Module):
         graph.replay()
         return {k: v.clone() for k, v in out.items()}
 
+    @_on_model_device
     @torch.no_grad()
     def _forward(self, batched_input):
         """(low-res logits, prompt-encoder result) like the reference's Lam._forward (lam.py:115-136)."""
@@ -289,6 +311,7 @@ class Lam(nn.Module):
         out = self._run(inp, plan, False, want_post=False)
         return out["low_res_logits"], out
 
+    @_on_model_device
     @torch.no_grad()
     def forward(self, batched_input: Dict[str, Any], want_argmax: bool = False) -> Dict[str, torch.Tensor]:
         inp, plan = self._prepare(batched_input)
@@ -302,9 +325,11 @@ class Lam(nn.Module):
         """forward + the caller's ``logits.argmax(dim=1)`` (experiment/run.py:697) fused into the last kernel."""
         return self.forward(batched_input, want_argmax=True)
 
+    @_on_model_device
     def postprocess_masks(self, masks: torch.Tensor, original_sizes: torch.Tensor) -> torch.Tensor:
         return self.engine().postprocess(masks.to(self._device(), torch.float32).contiguous(), original_sizes)
 
+    @_on_model_device
     @torch.no_grad()
     def generate_class_embeddings(self, example_dict, chunk_size=None):
         """Supports only: every image of the dict is a support (lam.py:349-360).  chunk_size is accepted and ignored
@@ -320,6 +345,7 @@ class Lam(nn.Module):
         res["class_examples_src"] = src
         return res
 
+    @_on_model_device
     @torch.no_grad()
     def predict(self, batched_input, class_embeddings=None):
         """Query-only encode + decode against cached prototypes (lam.py:362-381)."""
@@ -334,6 +360,7 @@ class Lam(nn.Module):
         seg = eng.mask_decoder(query, b, g, class_embeddings["class_embeddings"])
         return eng.postprocess(seg, batched_input["dims"].unsqueeze(1))
 
+    @_on_model_device
     @torch.no_grad()
     def encode_images_nchw(self, images: torch.Tensor, return_last_block_state: bool = False):
         """``model.image_encoder(images)`` of the reference: (Bn,3,S,S) -> (Bn,C,g,g) fp32
@@ -391,27 +418,93 @@ def _hf5_to_hf4(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 # ----------------------------------------------------------------------------------------------------
 def has_config(func):
-    """Capture constructor kwargs as ``self.config`` (models/hfhub.py:50-67)."""
-    signature = inspect.signature(func)
+    """Constructor decorator of the reference's hub wrapper (models/hfhub.py:50-67): the arguments the object was built with -
+    explicit ones over declared defaults, a ``config=dict`` argument merged in first - are kept as ``self.config`` (what
+    ``save_pretrained`` writes to config.json and ``from_pretrained`` feeds back)."""
+    sig = inspect.signature(func)
 
     def wrapper(self, *args, **kwargs):
-        if "config" in kwargs:
-            config = kwargs.pop("config")
-            kwargs.update(**config)
-        self.config = {k: (v.default if (i - 1) >= len(args) else args[i - 1])
-                       for i, (k, v) in enumerate(signature.parameters.items()) if v.default is not inspect.Parameter.empty}
-        self.config.update(**kwargs)
-        func(self, *args, **kwargs)
+        merged = dict(kwargs.pop("config", None) or {})
+        merged.update(kwargs)
+        bound = sig.bind(self, *args, **merged)
+        bound.apply_defaults()
+        self.config = {k: v for k, v in list(bound.arguments.items())[1:]}
+        func(*bound.args, **bound.kwargs)
+    wrapper.__wrapped__ = func
     return wrapper
 
 
+SAM_EMBED_DIM = 256     # width of a Segment-Anything checkpoint's prompt encoder / mask decoder (models/common.py)
+
+# Segment-Anything checkpoint -> LabelAnything modules (Lam.init_pretrained_weights, models/lam.py:241-319): source prefix in the
+# SAM state dict -> destination prefixes here.  SAM's mask-decoder transformer seeds BOTH two-way transformers.
+_SAM_INIT_MAP = (
+    ("prompt_encoder.pe_layer.", ("prompt_encoder.pe_layer.",)),
+    ("prompt_encoder.point_embeddings.", ("prompt_encoder.point_embeddings.",)),
+    ("prompt_encoder.not_a_point_embed.", ("prompt_encoder.not_a_point_embed.",)),
+    ("prompt_encoder.mask_downscaling.", ("prompt_encoder.mask_downscaling.",)),
+    ("prompt_encoder.no_mask_embed.", ("prompt_encoder.no_mask_embed.",)),
+    ("mask_decoder.transformer.", ("prompt_encoder.transformer.", "mask_decoder.transformer.")),
+    ("mask_decoder.output_upscaling.", ("mask_decoder.output_upscaling.",)),
+)
+
+
+def init_pretrained_weights(lam: Lam, weights: Dict[str, torch.Tensor]) -> None:
+    """Initialise a Lam from a Segment-Anything checkpoint (``use_sam_checkpoint=True``; models/lam.py:241-319): the image
+    encoder always (every ``image_encoder.*`` tensor, strictly), and - only when the model has SAM's width (D = 256) - the
+    positional-encoding matrix, point / not-a-point / no-mask embeddings, mask_downscaling, both two-way transformers and the
+    mask decoder's output_upscaling.  Everything else (class attention blocks, class_mlp, spatial convs, LAM neck, class
+    encoder) keeps its fresh initialisation.  Like the reference, every destination module is loaded strictly: a missing or
+    mis-shaped tensor raises."""
+    own = lam.state_dict()
+    picked: Dict[str, torch.Tensor] = {}
+
+    def take(src_prefix: str, dst_prefix: str) -> None:
+        dst_keys = [k for k in own if k.startswith(dst_prefix)]
+        src = {k[len(src_prefix):]: v for k, v in weights.items() if k.startswith(src_prefix)}
+        missing = [k for k in dst_keys if k[len(dst_prefix):] not in src]
+        extra = [k for k in src if dst_prefix + k not in own]
+        if missing or extra:
+            raise RuntimeError(f"SAM checkpoint does not match {dst_prefix}*: missing {missing[:4]}, unexpected {extra[:4]}")
+        for k in dst_keys:
+            v = src[k[len(dst_prefix):]]
+            if tuple(v.shape) != tuple(own[k].shape):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(own[k].shape)}")
+            picked[k] = v
+
+    if lam.image_encoder is not None:
+        take("image_encoder.", "image_encoder.")
+    if lam.cfg.embed_dim == SAM_EMBED_DIM:
+        for src, dsts in _SAM_INIT_MAP:
+            for dst in dsts:
+                take(src, dst)
+    nn.Module.load_state_dict(lam, picked, strict=False)
+    lam._engine = None
+
+
 def build_lam(encoder: Optional[str] = "vit_b", seed: Optional[int] = None, compute_dtype=torch.float16,
-              checkpoint: Optional[str] = None, **kwargs) -> Lam:
+              checkpoint: Optional[str] = None, use_sam_checkpoint: bool = False, ignore_encoder_checkpoint: bool = False,
+              **kwargs) -> Lam:
+    """``build_lam`` of the reference (build_lam.py:180-236).  checkpoint + use_sam_checkpoint: Segment-Anything weights seed
+    the encoder and the SAM-shaped decoder parts (init_pretrained_weights); otherwise the checkpoint is a full LabelAnything
+    state dict, loaded strictly - with ignore_encoder_checkpoint only ``image_encoder.*`` keys may be absent
+    (utils/utils.py:111-139)."""
     cfg = config_from_kwargs(encoder=encoder, **kwargs)
     lam = Lam(cfg, seed=seed, compute_dtype=compute_dtype)
     lam.eval()
     if checkpoint is not None:
-        lam.load_state_dict(_load_any(checkpoint))
+        sd = _load_any(checkpoint)
+        if use_sam_checkpoint:
+            init_pretrained_weights(lam, sd)
+        elif ignore_encoder_checkpoint:
+            res = lam.load_state_dict(sd, strict=False)
+            missing = [k for k in res.missing_keys if "image_encoder" not in k]
+            if missing:
+                raise RuntimeError(f"Missing keys: {missing}")
+            if res.unexpected_keys:
+                raise RuntimeError(f"Unexpected keys: {list(res.unexpected_keys)}")
+        else:
+            lam.load_state_dict(sd)
     return lam
 
 
@@ -460,6 +553,9 @@ class LabelAnything(nn.Module, PyTorchModelHubMixin):
         if enc is not None and enc not in ENCODER_SPECS:
             raise KeyError(f"unknown encoder {enc!r}; available: {sorted(ENCODER_SPECS)}")
         self.model = build_lam(encoder=enc if cfg.get("use_vit", True) else None, **cfg)
+
+    def init_pretrained_weights(self, weights) -> None:
+        init_pretrained_weights(self.model, weights)
 
     def forward(self, *args, **kwargs):
         return self.model(*args, **kwargs)

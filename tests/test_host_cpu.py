@@ -113,3 +113,58 @@ def test_bench_workloads_describe_valid_models_and_episodes():
         key = "embeddings" if "embeddings_channels" in ep else "images"
         assert small[key].shape[:2] == (1, m + 1) and small["prompt_masks"].shape[:3] == (1, m, ep["n_ways"] + 1)
         assert (cfg.encoder_spec is None) == (name == "cfg4")
+
+
+def test_sam_checkpoint_initialisation_and_encoder_less_checkpoints(tmp_path):
+    """use_sam_checkpoint (models/lam.py:241-319): encoder + the SAM-shaped decoder parts come from the checkpoint, SAM's
+    mask-decoder transformer seeds BOTH two-way transformers, everything else keeps its own initialisation; mismatches raise.
+    ignore_encoder_checkpoint (utils/utils.py:111-139): only image_encoder.* keys may be missing."""
+    import torch
+    from safetensors.torch import save_file
+    from labelanything_amd.config import EncoderSpec, register_encoder
+    from labelanything_amd.models import build_lam
+    register_encoder("sam_micro", EncoderSpec("sam", dim=64, depth=1, heads=1, mlp=128, img_size=64, global_idx=(0,), window=0, out_chans=256))
+    kw = dict(encoder="sam_micro", image_size=64, image_embed_dim=256, embed_dim=256, spatial_convs=3)
+    donor = build_lam(seed=5, **kw)
+    sam = {k: v.clone() for k, v in donor.state_dict().items()
+           if k.startswith(("image_encoder.", "prompt_encoder.pe_layer.", "prompt_encoder.point_embeddings.", "prompt_encoder.not_a_point_embed.",
+                            "prompt_encoder.mask_downscaling.", "prompt_encoder.no_mask_embed.", "mask_decoder.transformer.",
+                            "mask_decoder.output_upscaling."))}
+    path = str(tmp_path / "sam_like.safetensors")
+    save_file({k: v.contiguous() for k, v in sam.items()}, path)
+    fresh = build_lam(seed=6, **kw).state_dict()
+    lam = build_lam(seed=6, checkpoint=path, use_sam_checkpoint=True, **kw)
+    got = lam.state_dict()
+    for k in ("image_encoder.blocks.0.attn.qkv.weight", "prompt_encoder.mask_downscaling.0.weight", "mask_decoder.output_upscaling.3.bias"):
+        assert torch.equal(got[k], sam[k])
+    t = "transformer.layers.1.cross_attn_image_to_token.k_proj.weight"
+    assert torch.equal(got["prompt_encoder." + t], sam["mask_decoder." + t])          # SAM's decoder transformer seeds both
+    assert torch.equal(got["mask_decoder." + t], sam["mask_decoder." + t])
+    for k in ("mask_decoder.class_mlp.layers.0.weight", "prompt_encoder.class_example_attention.attn.q_proj.weight", "mask_decoder.spatial_convs.0.weight"):
+        assert torch.equal(got[k], fresh[k])                                            # not part of a SAM checkpoint
+    # a checkpoint that lacks part of a seeded module is an error, as in the reference's strict per-module loads
+    bad = {k: v for k, v in sam.items() if k != "mask_decoder.output_upscaling.3.bias"}
+    badp = str(tmp_path / "bad.safetensors")
+    save_file({k: v.contiguous() for k, v in bad.items()}, badp)
+    with pytest.raises(RuntimeError, match="output_upscaling"):
+        build_lam(seed=6, checkpoint=badp, use_sam_checkpoint=True, **kw)
+    # ignore_encoder_checkpoint: decoder-only checkpoint accepted, anything else missing is an error
+    dec = {k: v.contiguous() for k, v in donor.state_dict().items() if not k.startswith("image_encoder.")}
+    decp = str(tmp_path / "decoder_only.safetensors")
+    save_file(dec, decp)
+    lam2 = build_lam(seed=7, checkpoint=decp, ignore_encoder_checkpoint=True, **kw)
+    assert torch.equal(lam2.state_dict()["mask_decoder.class_mlp.layers.0.weight"], dec["mask_decoder.class_mlp.layers.0.weight"])
+    with pytest.raises(RuntimeError):
+        build_lam(seed=7, checkpoint=decp, **kw)                                        # strict by default
+    dec.pop("mask_decoder.class_mlp.layers.0.weight")
+    save_file(dec, decp)
+    with pytest.raises(RuntimeError, match="Missing keys"):
+        build_lam(seed=7, checkpoint=decp, ignore_encoder_checkpoint=True, **kw)
+
+
+def test_has_config_records_arguments():
+    from labelanything_amd.models import LabelAnything
+    m = LabelAnything(encoder=None, use_vit=False, image_size=256, embed_dim=64, image_embed_dim=64, spatial_convs=3)
+    assert m.config["embed_dim"] == 64 and m.config["use_vit"] is False and m.config["class_attention"] is False
+    m2 = LabelAnything(config=dict(m.config))
+    assert m2.config == m.config
