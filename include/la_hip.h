@@ -229,6 +229,45 @@ int la_focal_loss(const float* logits, const long long* target, int B, int C, lo
 int la_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- backward kernels of the decoder-side training step (fp32 like the decoder forward).  Together with the forward
+ * entry points above they are the autograd graph of label_anything/models/{common,transformer,prompt_encoder,mask_decoder,lam}.py
+ * under experiment/utils.py:266-303 (WrapperModule: model forward + LabelAnythingLoss) and experiment/run.py:359-361 (backward). ---- */
+
+/* dW[N,K] += dY[M,N]^T . X[M,K]: weight gradient of nn.Linear / 1x1 conv / k = s conv(-transpose) (exact-fp32 MFMA, split over M with
+ * atomic accumulation: the caller zero-fills or pre-loads dW). */
+int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream);
+
+/* Backward of la_layernorm (nn.LayerNorm / LayerNorm2d common.py:42-54, optionally followed by GELU): x, dy fp32 [rows, E] contiguous ->
+ * dx (written), dgamma / dbeta fp32 [E] (ACCUMULATED). */
+int la_layernorm_bwd(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
+                     float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* y = act(x) and dx = dy * act'(x), act = LA_ACT_GELU (erf form) or LA_ACT_RELU, n contiguous fp32 elements. */
+int la_act_fwd(const float* x, float* y, long n, int kind, void* stream);
+int la_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream);
+
+/* Row statistics lse[(b * Nq + q) * heads + h] = log sum_j exp(q . k_j / sqrt(hd)) of la_attn_small (needed by the backward when
+ * the QUERIES are the few tokens). */
+int la_attn_small_lse(const float* q, int ldq, const float* k, int ldk, int B, int Nq, int Nk, int heads, int hd, float* lse, void* stream);
+
+/* Backward of la_attn_small (Attention of models/common.py:57-148, score scale 1/sqrt(hd)): layouts as in the forward; dq / dk / dv have
+ * the leading dimensions of q / k / v.  Nk <= 256 (and Nk <= Nq or Nq > 256): dq is written, dk / dv ACCUMULATED (zero-fill them);
+ * otherwise Nq <= 256, o (saved forward output) and lse are required, dk / dv are written and dq ACCUMULATED. */
+int la_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* dout, int ldo,
+                      const float* lse, int B, int Nq, int Nk, int heads, int hd, float* dq, float* dk, float* dv, void* stream);
+
+/* Adjoint of la_bilinear (F.interpolate bilinear, align_corners=False): dx[n, ih, iw] += taps * dy[n, oh, ow]; plane strides and row
+ * strides explicit so that cropped sources / padded destinations of Lam.postprocess_masks (lam.py:405-449) need no copies. */
+int la_bilinear_bwd(const float* dy, int n, int oh, int ow, long dy_plane, int dy_ld, float* dx, int ih, int iw, long dx_plane, int dx_ld,
+                    void* stream);
+
+/* Backward of la_classify: dfeat[b, pix, f] (written), dprotos[b, c, f] (ACCUMULATED).  C <= 32, cf in {8, 16, 32, 64}. */
+int la_classify_bwd(const float* dseg, const float* feat, const float* protos, int B, int npix, int C, int cf, float* dfeat, float* dprotos,
+                    void* stream);
+
+/* out[(g * rep + r), :] = scale * src[g, :]  (backward of the mean over the hw axis, prompt_encoder.py:696-701). */
+int la_row_broadcast(const float* src, long groups, int rep, int D, float scale, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
+    "la_gemm_tn", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_classify_bwd", "la_row_broadcast",
 ]
 
 
@@ -298,3 +300,68 @@ def conv3x3_f32(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out3
     _dev(x32)
     _check(lib().la_conv3x3_f32(_ptr(x32), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(cin), _ptr(wt), _ptr(bias), C.c_int(cout),
                                 _ptr(out32), _stream()), "la_conv3x3_f32")
+
+
+# ---- backward kernels (training step, csrc/train.hip) ------------------------------------------------------------------------
+def _f32c(*ts) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        _dev(t)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("contiguous fp32 device tensors expected")
+
+
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
+    """dw[N,K] += dy[M,N]^T @ x[M,K]."""
+    _f32c(dy, x, dw)
+    m, n = dy.shape
+    k = x.shape[1]
+    _check(lib().la_gemm_tn(_ptr(dy), C.c_int(n), _ptr(x), C.c_int(k), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n), C.c_int(k), _stream()),
+           "la_gemm_tn")
+
+
+def layernorm_bwd(x, dy, gamma, beta, eps: float, gelu: bool, dx, dgamma, dbeta) -> None:
+    _f32c(x, dy, gamma, beta, dx, dgamma, dbeta)
+    rows, e = x.shape
+    _check(lib().la_layernorm_bwd(_ptr(x), _ptr(dy), C.c_long(rows), C.c_int(e), _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(int(gelu)),
+                                  _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()), "la_layernorm_bwd")
+
+
+def act_fwd(x, y, kind: int) -> None:
+    _f32c(x, y)
+    _check(lib().la_act_fwd(_ptr(x), _ptr(y), C.c_long(x.numel()), C.c_int(kind), _stream()), "la_act_fwd")
+
+
+def act_bwd(x, dy, dx, kind: int) -> None:
+    _f32c(x, dy, dx)
+    _check(lib().la_act_bwd(_ptr(x), _ptr(dy), _ptr(dx), C.c_long(x.numel()), C.c_int(kind), _stream()), "la_act_bwd")
+
+
+def attn_small_lse(q, k, b: int, nq: int, nk: int, heads: int, hd: int, lse) -> None:
+    _check(lib().la_attn_small_lse(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), C.c_int(b), C.c_int(nq), C.c_int(nk),
+                                   C.c_int(heads), C.c_int(hd), _ptr(lse), _stream()), "la_attn_small_lse")
+
+
+def attn_small_bwd(q, k, v, o, dout, lse, b: int, nq: int, nk: int, heads: int, hd: int, dq, dk, dv) -> None:
+    _check(lib().la_attn_small_bwd(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), _ptr(v), C.c_int(v.stride(0)), _ptr(o),
+                                   _ptr(dout), C.c_int(dout.stride(0)), _ptr(lse), C.c_int(b), C.c_int(nq), C.c_int(nk), C.c_int(heads),
+                                   C.c_int(hd), _ptr(dq), _ptr(dk), _ptr(dv), _stream()), "la_attn_small_bwd")
+
+
+def bilinear_bwd(dy, n: int, oh: int, ow: int, dy_plane: int, dy_ld: int, dx, ih: int, iw: int, dx_plane: int, dx_ld: int) -> None:
+    _dev(dy)
+    _check(lib().la_bilinear_bwd(_ptr(dy), C.c_int(n), C.c_int(oh), C.c_int(ow), C.c_long(dy_plane), C.c_int(dy_ld), _ptr(dx), C.c_int(ih),
+                                 C.c_int(iw), C.c_long(dx_plane), C.c_int(dx_ld), _stream()), "la_bilinear_bwd")
+
+
+def classify_bwd(dseg, feat, protos, b: int, npix: int, c: int, cf: int, dfeat, dprotos) -> None:
+    _f32c(dseg, feat, protos, dfeat, dprotos)
+    _check(lib().la_classify_bwd(_ptr(dseg), _ptr(feat), _ptr(protos), C.c_int(b), C.c_int(npix), C.c_int(c), C.c_int(cf), _ptr(dfeat),
+                                 _ptr(dprotos), _stream()), "la_classify_bwd")
+
+
+def row_broadcast(src, groups: int, rep: int, d: int, scale: float, out) -> None:
+    _f32c(src, out)
+    _check(lib().la_row_broadcast(_ptr(src), C.c_long(groups), C.c_int(rep), C.c_int(d), C.c_float(scale), _ptr(out), _stream()),
+           "la_row_broadcast")

@@ -1,0 +1,313 @@
+"""Differentiable decoder ops: ``torch.autograd.Function`` shells whose forward AND backward are HIP kernels of libla_hip.so.
+
+Training side of the hot path.  torch.autograd only records the graph and moves data (views, permutes, cat,
+index_select, expand); every arithmetic node of the prompt encoder / mask decoder / necks is one of the functions below:
+
+    linear        la_gemm (exact-fp32 MFMA)            bwd: la_gemm (dX), la_gemm_tn (dW, db)
+    layer_norm    la_layernorm                         bwd: la_layernorm_bwd           (nn.LayerNorm, LayerNorm2d in NHWC, +GELU)
+    act           la_act_fwd                           bwd: la_act_bwd                 (GELU erf, ReLU)
+    attention     la_attn_small                        bwd: la_attn_small_lse + la_attn_small_bwd
+    add_rows      la_add_cast (row-periodic operand)   bwd: identity / la_gemm_tn-free row fold via torch view-sum
+    mean_rows     la_colmean                           bwd: la_row_broadcast
+    conv3x3       la_conv3x3_f32 (implicit GEMM)       bwd: la_conv3x3_f32 with the transposed taps (dX), la_im2col_3x3 + la_gemm_tn (dW)
+    classify      la_classify                          bwd: la_classify_bwd
+    bilinear      la_bilinear                          bwd: la_bilinear_bwd
+
+All tensors are fp32, contiguous, on the device; 2-D activations are [rows, channels] (NHWC rows), as in the inference engine.
+Reference graph: label_anything/models/{common,transformer,prompt_encoder,mask_decoder}.py under experiment/utils.py:266-303.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+_ONES: Dict[tuple, Tensor] = {}
+
+
+def _ones(m: int, dev) -> Tensor:
+    key = (m, dev)
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) > 64:
+            _ONES.clear()
+        t = torch.ones(m, 1, device=dev)
+        _ONES[key] = t
+    return t
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _c(x), _c(w)
+        y = x.new_empty(x.shape[0], w.shape[0])
+        L.gemm(x, w, bias=b, out32=y)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.gemm(dy, _c(w.t()), out32=dx)                  # dY . W   (W^T handed over in nn.Linear layout)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            L.gemm_tn(dy, x, dw)                             # dY^T . X
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.new_zeros(dy.shape[1], 1)
+            L.gemm_tn(dy, _ones(dy.shape[0], dy.device), db)  # column sums of dY
+            db = db.view(-1)
+        return dx, dw, db
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    return _Linear.apply(x, w, b)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, gelu):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.layernorm(x, gamma, beta, eps, gelu=gelu, out32=y, dt=L.LA_F32)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps, ctx.gelu = eps, gelu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+        L.layernorm_bwd(x, _c(dy), _c(gamma), _c(beta), ctx.eps, ctx.gelu, dx, dg, db)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, gelu: bool = False) -> Tensor:
+    return _LayerNorm.apply(x, gamma, beta, float(eps), bool(gelu))
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.act_fwd(x, y, kind)
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.act_bwd(x, _c(dy), dx, ctx.kind)
+        return dx, None
+
+
+def gelu(x: Tensor) -> Tensor:
+    return _Act.apply(x, L.ACT_GELU)
+
+
+def relu(x: Tensor) -> Tensor:
+    return _Act.apply(x, L.ACT_RELU)
+
+
+class _Attention(Function):
+    """softmax(q k^T / sqrt(hd)) v per (group, head).  q [groups*nq, heads*hd], k / v [groups*nk, heads*hd]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, groups, nq, nk, heads):
+        q, k, v = _c(q), _c(k), _c(v)
+        hd = q.shape[1] // heads
+        o = torch.empty_like(q)
+        L.attn_small(q, k, v, groups, nq, nk, heads, hd, out32=o, dt=L.LA_F32)
+        ctx.save_for_backward(q, k, v, o)
+        ctx.dims = (groups, nq, nk, heads, hd)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        groups, nq, nk, heads, hd = ctx.dims
+        do = _c(do)
+        fewkeys = nk <= 256 and (nk <= nq or nq > 256)
+        if fewkeys:
+            dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+            L.attn_small_bwd(q, k, v, o, do, None, groups, nq, nk, heads, hd, dq, dk, dv)
+        else:
+            lse = q.new_empty(groups * nq * heads)
+            L.attn_small_lse(q, k, groups, nq, nk, heads, hd, lse)
+            dq, dk, dv = torch.zeros_like(q), torch.empty_like(k), torch.empty_like(v)
+            L.attn_small_bwd(q, k, v, o, do, lse, groups, nq, nk, heads, hd, dq, dk, dv)
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, groups: int, nq: int, nk: int, heads: int) -> Tensor:
+    return _Attention.apply(q, k, v, groups, nq, nk, heads)
+
+
+class _AddRows(Function):
+    """x [rows, D] + y [ymod, D] repeated with period ymod (ymod == rows: plain add)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        out = torch.empty_like(x)
+        L.add_cast(x, y, y.shape[0] if y.shape[0] != x.shape[0] else 0, out32=out, dt=L.LA_F32)
+        ctx.ymod, ctx.rows = y.shape[0], x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        dy = None
+        if ctx.needs_input_grad[1]:
+            dy = d if ctx.ymod == ctx.rows else d.reshape(ctx.rows // ctx.ymod, ctx.ymod, -1).sum(dim=0)
+        return (d if ctx.needs_input_grad[0] else None), dy
+
+
+def add_rows(x: Tensor, y: Tensor) -> Tensor:
+    if x.shape[0] % y.shape[0]:
+        raise ValueError("add_rows: the row count of y must divide that of x")
+    return _AddRows.apply(x, y)
+
+
+class _MeanRows(Function):
+    """[groups*rep, D] -> [groups, D]: mean over the rep rows of every group (average pooling over hw)."""
+
+    @staticmethod
+    def forward(ctx, x, groups, rep):
+        x = _c(x)
+        d = x.shape[1]
+        out = x.new_empty(groups, d)
+        L.colmean(x, groups, rep, d, out, x.new_empty(groups, L.COLMEAN_SPLIT, d))
+        ctx.dims = (groups, rep, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        groups, rep, d = ctx.dims
+        dx = dy.new_empty(groups * rep, d)
+        L.row_broadcast(_c(dy), groups, rep, d, 1.0 / rep, dx)
+        return dx, None, None
+
+
+def mean_rows(x: Tensor, groups: int, rep: int) -> Tensor:
+    return _MeanRows.apply(x, groups, rep)
+
+
+def _conv3x3_raw(x: Tensor, wk: Tensor, b: Optional[Tensor], bsz: int, h: int, wd: int, cin: int, cout: int) -> Tensor:
+    """x [B*H*W, cin], wk [cout, (ky, kx, cin)]: implicit GEMM when cin % 32 == 0, im2col + la_gemm otherwise."""
+    y = x.new_empty(x.shape[0], cout)
+    if cin % 32 == 0:
+        L.conv3x3_f32(x, bsz, h, wd, cin, wk, b, cout, y)
+    else:
+        col = x.new_empty(x.shape[0], 9 * cin)
+        L.im2col_3x3(x, bsz, h, wd, cin, col)
+        L.gemm(col, wk, bias=b, out32=y)
+    return y
+
+
+class _Conv3x3(Function):
+    """3x3 / pad 1 convolution on an NHWC map [B*H*W, Cin]; w is the nn.Conv2d weight (Cout, Cin, 3, 3)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, bsz, h, wd):
+        x = _c(x)
+        cout, cin = w.shape[0], w.shape[1]
+        wk = _c(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin))              # [Cout, (ky, kx, cin)]
+        y = _conv3x3_raw(x, wk, b, bsz, h, wd, cin, cout)
+        ctx.save_for_backward(x, w)
+        ctx.dims = (bsz, h, wd, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        bsz, h, wd, has_bias = ctx.dims
+        cout, cin = w.shape[0], w.shape[1]
+        dy = _c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX = conv3x3(dY, taps flipped, channels transposed)
+            wt = _c(w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout))
+            dx = _conv3x3_raw(dy, wt, None, bsz, h, wd, cout, cin)
+        if ctx.needs_input_grad[1]:
+            col = x.new_empty(x.shape[0], 9 * cin)
+            L.im2col_3x3(x, bsz, h, wd, cin, col)
+            dwk = x.new_zeros(cout, 9 * cin)
+            L.gemm_tn(dy, col, dwk)
+            dw = dwk.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.new_zeros(cout, 1)
+            L.gemm_tn(dy, _ones(dy.shape[0], dy.device), db)
+            db = db.view(-1)
+        return dx, dw, db, None, None, None
+
+
+def conv3x3(x: Tensor, w: Tensor, b: Optional[Tensor], bsz: int, h: int, wd: int) -> Tensor:
+    return _Conv3x3.apply(x, w, b, bsz, h, wd)
+
+
+class _Classify(Function):
+    """seg[b, c, pix] = protos[b, c, :] . feat[b, pix, :]."""
+
+    @staticmethod
+    def forward(ctx, feat, protos, bsz, npix, c):
+        feat, protos = _c(feat), _c(protos)
+        cf = feat.shape[1]
+        seg = feat.new_empty(bsz, c, npix)
+        L.classify(feat, protos, bsz, npix, c, cf, seg)
+        ctx.save_for_backward(feat, protos)
+        ctx.dims = (bsz, npix, c, cf)
+        return seg
+
+    @staticmethod
+    def backward(ctx, dseg):
+        feat, protos = ctx.saved_tensors
+        bsz, npix, c, cf = ctx.dims
+        dfeat, dprotos = torch.empty_like(feat), torch.zeros_like(protos)
+        L.classify_bwd(_c(dseg), feat, protos, bsz, npix, c, cf, dfeat, dprotos)
+        return dfeat, dprotos, None, None, None
+
+
+def classify(feat: Tensor, protos: Tensor, bsz: int, npix: int, c: int) -> Tensor:
+    return _Classify.apply(feat, protos, bsz, npix, c)
+
+
+class _Bilinear(Function):
+    """[N, H, W] -> [N, OH, OW], F.interpolate(mode="bilinear", align_corners=False)."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        x = _c(x)
+        n, h, w = x.shape
+        out = x.new_empty(n, oh, ow)
+        L.bilinear(x, n, h, w, oh, ow, out)
+        ctx.dims = (n, h, w, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, oh, ow = ctx.dims
+        dy = _c(dy)
+        dx = dy.new_zeros(n, h, w)
+        L.bilinear_bwd(dy, n, oh, ow, oh * ow, ow, dx, h, w, h * w, w)
+        return dx, None, None
+
+
+def bilinear(x: Tensor, oh: int, ow: int) -> Tensor:
+    return _Bilinear.apply(x, oh, ow)

@@ -1,0 +1,583 @@
+// Backward kernels of the decoder-side training step: everything the forward kernels of dec.hip / gemm.hip /
+// norm.hip / post.hip need to be differentiated - fp32 throughout, like the decoder forward.
+//   la_gemm_tn          dW[N,K] += dY[M,N]^T . X[M,K]      (weight gradient of every nn.Linear / 1x1 / k=s conv: fp32 MFMA 32x32x2, operands
+//                                                            straight from row-major global memory, split over M with atomic accumulation)
+//   la_layernorm_bwd    LayerNorm / LayerNorm2d (+ fused GELU) backward: dx, dgamma, dbeta
+//   la_act_fwd / _bwd   GELU(erf) / ReLU
+//   la_attn_small_lse / la_attn_small_bwd   softmax attention backward of the decoder attentions (one side is a handful of tokens)
+//   la_bilinear_bwd     adjoint of F.interpolate(mode="bilinear", align_corners=False) (post-processing, mask resize)
+//   la_classify_bwd     prototype classification backward
+//   la_row_broadcast    backward of the mean over the hw axis
+// Reference: the autograd graph of label_anything/models/{common,transformer,prompt_encoder,mask_decoder,lam}.py under
+// experiment/utils.py:266-303 (WrapperModule) + loss/__init__.py:67-89.
+#include "la_common.h"
+#include "../../include/la_hip.h"
+
+namespace la {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dW[n][k] += sum_m dY[m][n] X[m][k].  The 32x32x2 fp32 MFMA takes A[i][kk] / B[kk][j] with lane l holding (i or j = l & 31,
+// kk = l >> 5): for a reduction over ROWS of two row-major matrices that is one coalesced 128-byte read of row m + (l >> 5) per
+// half-wave and operand - no LDS, no transposes.  Workgroup = 4 waves (2 x 2) of 64 x 64 -> a 128 x 128 tile of dW over one
+// M-chunk; chunks are folded with fp32 atomics (the summation order is therefore not fixed; 1e-7-level run-to-run noise).
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                      float* __restrict__ dw, int ldw, int M, int N, int K, int mchunk, int tiles_k) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * 128 + (wave >> 1) * 64, k0 = tk * 128 + (wave & 1) * 64;
+  const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // clamped column indices + validity masks (loads never fault, invalid lanes contribute zeros)
+  int cn[2], ck[2];
+  float vn[2], vk[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = n0 + i * 32 + fr, k = k0 + i * 32 + fr;
+    vn[i] = n < N ? 1.f : 0.f;
+    vk[i] = k < K ? 1.f : 0.f;
+    cn[i] = min(n, N - 1);
+    ck[i] = min(k, K - 1);
+  }
+  for (int m = mbeg; m < mend; m += 8) {
+    float a[4][2], b[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = m + 2 * u + fh;
+      const float vr = row < mend ? 1.f : 0.f;
+      const size_t rc = (size_t)min(row, M - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[u][i] = dy[rc * ldy + cn[i]] * (vr * vn[i]);
+        b[u][i] = x[rc * ldx + ck[i]] * (vr * vk[i]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + j * 32 + fr;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (n < N) atomicAdd(&dw[(size_t)n * ldw + k], acc[i][j][r]);
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row (E <= 2048): y = [GELU](xhat * gamma + beta), xhat = (x - mu) * rstd.
+//   dz = dy [* GELU'(z)];  dgamma += dz * xhat;  dbeta += dz;  g = dz * gamma;
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// dgamma / dbeta: every lane keeps the partial sums of its columns over all the rows its wave walks, one atomic per column and
+// wave at the end.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float z) {
+  const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+  return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows, int E,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            int gelu, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  float gm[VPL], bt[VPL], sg[VPL], sb[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    gm[v] = c < E ? gamma[c] : 0.f;
+    bt[v] = c < E ? beta[c] : 0.f;
+    sg[v] = sb[v] = 0.f;
+  }
+  const float inv_e = 1.0f / (float)E;
+  for (long r = wave; r < rows; r += nwaves) {
+    float xv[VPL], dv[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      xv[v] = c < E ? x[r * E + c] : 0.f;
+      dv[v] = c < E ? dy[r * E + c] : 0.f;
+      s += xv[v];
+    }
+    const float mu = wave_sum(s) * inv_e;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      const float d = c < E ? xv[v] - mu : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_e + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      const float xh = c < E ? (xv[v] - mu) * rstd : 0.f;
+      float dz = dv[v];
+      if (gelu) dz *= gelu_grad(xh * gm[v] + bt[v]);
+      sg[v] += dz * xh;
+      sb[v] += dz;
+      const float g = dz * gm[v];
+      s1 += g;
+      s2 += g * xh;
+      xv[v] = xh;
+      dv[v] = g;
+    }
+    s1 = wave_sum(s1) * inv_e;
+    s2 = wave_sum(s2) * inv_e;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < E) dx[r * E + c] = rstd * (dv[v] - s1 - xv[v] * s2);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < E) {
+      atomicAdd(&dgamma[c], sg[v]);
+      atomicAdd(&dbeta[c], sb[v]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = kind == LA_ACT_GELU ? gelu_erf(v) : fmaxf(v, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n,
+                                                      int kind) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    dx[i] = dy[i] * (kind == LA_ACT_GELU ? gelu_grad(v) : (v > 0.f ? 1.f : 0.f));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Attention backward.  Layout as la_attn_small: q [B, Nq, ldq] (head h at column h * HD), k / v [B, Nk, ld], o / do [B, Nq, ldo],
+// scores = q.k * scale.  One side of every decoder attention is a handful of tokens:
+//   few keys  (Nk <= 256): one thread per (b, query, head); the softmax is local to the thread (three passes over the keys,
+//                          nothing stored); dq is written directly, dk / dv are reduced over the wave and added atomically.
+//   few queries (Nq <= 256): one thread per (b, key, head); needs the row statistics lse[b, head, q] (la_attn_small_lse) and the
+//                          saved output o (delta = do . o); dk / dv are written directly, dq is reduced over the wave.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+  const float *q, *k, *v, *o, *dout, *lse;
+  float *dq, *dk, *dv;
+  int ldq, ldk, ldv, ldo;        // dq / dk / dv use the same leading dimensions as q / k / v
+  int B, Nq, Nk, heads;
+  float scale;
+};
+
+template <int HDIM>
+__global__ __launch_bounds__(256) void attn_lse_kernel(AttnBwdArgs a, float* __restrict__ lse) {
+  // one workgroup per (b, q, head): lse = log sum_j exp(q.k_j scale)
+  __shared__ float red[2][4];
+  const int i = blockIdx.x;
+  const int h = i % a.heads, bq = i / a.heads, b = bq / a.Nq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float qv[HDIM];
+#pragma unroll
+  for (int d = 0; d < HDIM; ++d) qv[d] = a.q[(size_t)bq * a.ldq + h * HDIM + d] * a.scale;
+  const float* kp = a.k + (size_t)b * a.Nk * a.ldk + h * HDIM;
+  float m = -3.0e38f, l = 0.f;
+  for (int j = tid; j < a.Nk; j += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) s += qv[d] * kp[(size_t)j * a.ldk + d];
+    const float mn = fmaxf(m, s);
+    l = l * expf(m - mn) + expf(s - mn);
+    m = mn;
+  }
+  const float mw = wave_max(m);
+  l = wave_sum(l * expf(m - mw));
+  if (lane == 0) {
+    red[0][wave] = mw;
+    red[1][wave] = l;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float mg = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    float lt = 0.f;
+    for (int w = 0; w < 4; ++w) lt += red[1][w] * expf(red[0][w] - mg);
+    lse[i] = mg + logf(lt);       // index (b * Nq + q) * heads + h
+  }
+}
+
+template <int HDIM>
+__global__ __launch_bounds__(256) void attn_bwd_fewkeys_kernel(AttnBwdArgs a) {
+  // thread = (b, head, query) with the query fastest; each b is padded to a multiple of 64 threads so that a wave never mixes two
+  // batch items.  A wave may still span several heads (Nq < 64): the dk / dv reduction below runs once per head present.
+  const int per_b = a.heads * a.Nq;
+  const int per_b_pad = (per_b + 63) / 64 * 64;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = (int)(i / per_b_pad);
+  if (b >= a.B) return;                           // whole waves leave together
+  const int rb = (int)(i % per_b_pad);
+  const bool live = rb < per_b;
+  const int h = min(rb, per_b - 1) / a.Nq, qi = live ? rb % a.Nq : 0;
+  const long bq = (long)b * a.Nq + qi;
+  float qv[HDIM], dov[HDIM], dqv[HDIM];
+  const float lv = live ? 1.f : 0.f;
+#pragma unroll
+  for (int d = 0; d < HDIM; ++d) {
+    qv[d] = a.q[bq * a.ldq + h * HDIM + d];
+    dov[d] = a.dout[bq * a.ldo + h * HDIM + d] * lv;
+    dqv[d] = 0.f;
+  }
+  const float* kp = a.k + (size_t)b * a.Nk * a.ldk + h * HDIM;
+  const float* vp = a.v + (size_t)b * a.Nk * a.ldv + h * HDIM;
+  float mx = -3.0e38f;
+  for (int j = 0; j < a.Nk; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) s += qv[d] * kp[(size_t)j * a.ldk + d];
+    mx = fmaxf(mx, s * a.scale);
+  }
+  float l = 0.f, delta = 0.f;      // delta = sum_j p_j (do . v_j) = do . o
+  for (int j = 0; j < a.Nk; ++j) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) {
+      s += qv[d] * kp[(size_t)j * a.ldk + d];
+      dp += dov[d] * vp[(size_t)j * a.ldv + d];
+    }
+    const float pe = expf(s * a.scale - mx);
+    l += pe;
+    delta += pe * dp;
+  }
+  const float inv = 1.0f / l;
+  delta *= inv;
+  // heads present in this wave (h is non-decreasing with the lane; padded lanes carry the last head with zero gradients)
+  const int h_first = __shfl(h, 0, 64), h_last = __shfl(h, 63, 64);
+  for (int j = 0; j < a.Nk; ++j) {
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) {
+      s += qv[d] * kp[(size_t)j * a.ldk + d];
+      dp += dov[d] * vp[(size_t)j * a.ldv + d];
+    }
+    const float p = expf(s * a.scale - mx) * inv;
+    const float ds = p * (dp - delta) * a.scale;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) dqv[d] += ds * kp[(size_t)j * a.ldk + d];
+    for (int hh = h_first; hh <= h_last; ++hh) {
+      const float sel = (hh == h) ? 1.f : 0.f;
+#pragma unroll
+      for (int d = 0; d < HDIM; ++d) {
+        const float gk = wave_sum(ds * qv[d] * sel);
+        const float gv = wave_sum(p * dov[d] * sel);
+        if ((threadIdx.x & 63) == 0) {
+          atomicAdd(&a.dk[((size_t)b * a.Nk + j) * a.ldk + hh * HDIM + d], gk);
+          atomicAdd(&a.dv[((size_t)b * a.Nk + j) * a.ldv + hh * HDIM + d], gv);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) a.dq[bq * a.ldq + h * HDIM + d] = dqv[d];
+  }
+}
+
+template <int HDIM>
+__global__ __launch_bounds__(256) void attn_bwd_fewqueries_kernel(AttnBwdArgs a) {
+  // thread = (b, head, key) with the key fastest, padded per (b, head) to a multiple of 64 so that a wave never mixes heads
+  const int kpad = (a.Nk + 63) / 64 * 64;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kj = (int)(i % kpad);
+  const long bh = i / kpad;
+  if (bh >= (long)a.B * a.heads) return;       // whole waves leave together (kpad % 64 == 0)
+  const int h = (int)(bh % a.heads), b = (int)(bh / a.heads);
+  const bool live = kj < a.Nk;
+  const float lv = live ? 1.f : 0.f;
+  const size_t krow = (size_t)b * a.Nk + (live ? kj : 0);
+  float kv[HDIM], vv[HDIM], dkv[HDIM], dvv[HDIM];
+#pragma unroll
+  for (int d = 0; d < HDIM; ++d) {
+    kv[d] = a.k[krow * a.ldk + h * HDIM + d];
+    vv[d] = a.v[krow * a.ldv + h * HDIM + d];
+    dkv[d] = dvv[d] = 0.f;
+  }
+  for (int t = 0; t < a.Nq; ++t) {
+    const size_t qrow = (size_t)b * a.Nq + t;
+    const float* qp = a.q + qrow * a.ldq + h * HDIM;
+    const float* dop = a.dout + qrow * a.ldo + h * HDIM;
+    const float* op = a.o + qrow * a.ldo + h * HDIM;
+    float s = 0.f, dp = 0.f, delta = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) {
+      s += qp[d] * kv[d];
+      dp += dop[d] * vv[d];
+      delta += dop[d] * op[d];
+    }
+    const float p = expf(s * a.scale - a.lse[qrow * a.heads + h]) * lv;
+    const float ds = p * (dp - delta) * a.scale;
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) {
+      dvv[d] += p * dop[d];
+      dkv[d] += ds * qp[d];
+      const float gq = wave_sum(ds * kv[d]);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&a.dq[qrow * a.ldq + h * HDIM + d], gq);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) {
+      a.dk[krow * a.ldk + h * HDIM + d] = dkv[d];
+      a.dv[krow * a.ldv + h * HDIM + d] = dvv[d];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Adjoint of bilinear resampling (align_corners = False, no antialias; index arithmetic identical to bilinear_kernel of
+// post.hip): dx[n, iy, ix] += w * dy[n, oy, ox] over the four taps of every output pixel.  Explicit plane strides so that a
+// cropped source region / padded destination frame (Lam.postprocess_masks, lam.py:405-449) needs no copies.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy, int n, int oh, int ow, long dy_plane, int dy_ld,
+                                                           float* __restrict__ dx, int ih, int iw, long dx_plane, int dx_ld) {
+  const long total = (long)n * oh * ow;
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+    const long pl = i / ((long)ow * oh);
+    const float g = dy[pl * dy_plane + (long)oy * dy_ld + ox];
+    if (g == 0.f) continue;
+    float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+    const int y0 = min((int)fy, ih - 1), x0 = min((int)fx, iw - 1);
+    const int y1 = min(y0 + 1, ih - 1), x1 = min(x0 + 1, iw - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    float* base = dx + pl * dx_plane;
+    atomicAdd(&base[(long)y0 * dx_ld + x0], g * (1.f - ly) * (1.f - lx));
+    atomicAdd(&base[(long)y0 * dx_ld + x1], g * (1.f - ly) * lx);
+    atomicAdd(&base[(long)y1 * dx_ld + x0], g * ly * (1.f - lx));
+    atomicAdd(&base[(long)y1 * dx_ld + x1], g * ly * lx);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// seg[b, c, pix] = sum_f protos[b, c, f] feat[b, pix, f]  ->  dfeat[b, pix, f] = sum_c dseg[b, c, pix] protos[b, c, f],
+// dprotos[b, c, f] += sum_pix dseg[b, c, pix] feat[b, pix, f]  (wave reduction + one atomic per wave).  C <= 32, CF <= 64.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int CF>
+__global__ __launch_bounds__(256) void classify_bwd_kernel(const float* __restrict__ dseg, const float* __restrict__ feat,
+                                                           const float* __restrict__ protos, int B, int npix, int C, float* __restrict__ dfeat,
+                                                           float* __restrict__ dprotos) {
+  __shared__ float pr[32 * CF];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < C * CF; i += 256) pr[i] = protos[(size_t)b * C * CF + i];
+  __syncthreads();
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const bool live = pix < npix;
+  const int pc = live ? pix : 0;
+  float f[CF], df[CF];
+#pragma unroll
+  for (int d = 0; d < CF; ++d) {
+    f[d] = live ? feat[((size_t)b * npix + pc) * CF + d] : 0.f;
+    df[d] = 0.f;
+  }
+  for (int c = 0; c < C; ++c) {
+    const float g = live ? dseg[((size_t)b * C + c) * npix + pc] : 0.f;
+#pragma unroll
+    for (int d = 0; d < CF; ++d) {
+      df[d] += g * pr[c * CF + d];
+      const float gp = wave_sum(g * f[d]);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&dprotos[((size_t)b * C + c) * CF + d], gp);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < CF; ++d) dfeat[((size_t)b * npix + pix) * CF + d] = df[d];
+  }
+}
+
+__global__ __launch_bounds__(256) void row_broadcast_kernel(const float* __restrict__ src, long groups, int rep, int D, float scale,
+                                                            float* __restrict__ out) {
+  const long total = groups * rep * (long)(D / 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (D / 4));
+    const long g = i / ((long)(D / 4) * rep);
+    float4 v = reinterpret_cast<const float4*>(src + g * D)[c4];
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+static int grid_for_n(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+}  // namespace la
+
+extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream) {
+  LA_CHECK_ARG(dy && x && dw, "la_gemm_tn: null pointer");
+  LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && ldw >= K, "la_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+  const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
+  // enough M-chunks for ~2048 workgroups, chunks of at least 256 rows (multiple of 8)
+  int chunks = 2048 / (tiles_n * tiles_k);
+  if (chunks < 1) chunks = 1;
+  int mchunk = (M + chunks - 1) / chunks;
+  if (mchunk < 256) mchunk = 256;
+  mchunk = (mchunk + 7) / 8 * 8;
+  chunks = (M + mchunk - 1) / mchunk;
+  hipLaunchKernelGGL(la::gemm_tn_kernel, dim3(tiles_n * tiles_k, chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, ldy, x, ldx,
+                     dw, ldw, M, N, K, mchunk, tiles_k);
+  LA_CHECK_LAUNCH("la_gemm_tn");
+  return 0;
+}
+
+extern "C" int la_layernorm_bwd(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
+                                float* dx, float* dgamma, float* dbeta, void* stream) {
+  LA_CHECK_ARG(x && dy && gamma && beta && dx && dgamma && dbeta, "la_layernorm_bwd: null pointer");
+  LA_CHECK_ARG(rows > 0 && E > 0 && E <= 2048, "la_layernorm_bwd: E=%d out of range (1..2048)", E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  long blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks), block(256);
+#define LA_LNB(V) hipLaunchKernelGGL(la::layernorm_bwd_kernel<V>, grid, block, 0, st, x, dy, rows, E, gamma, beta, eps, gelu, dx, dgamma, dbeta)
+  if (E <= 64) LA_LNB(1);
+  else if (E <= 128) LA_LNB(2);
+  else if (E <= 256) LA_LNB(4);
+  else if (E <= 512) LA_LNB(8);
+  else if (E <= 1024) LA_LNB(16);
+  else LA_LNB(32);
+#undef LA_LNB
+  LA_CHECK_LAUNCH("la_layernorm_bwd");
+  return 0;
+}
+
+extern "C" int la_act_fwd(const float* x, float* y, long n, int kind, void* stream) {
+  LA_CHECK_ARG(x && y && n > 0 && (kind == LA_ACT_GELU || kind == LA_ACT_RELU), "la_act_fwd: bad arguments");
+  hipLaunchKernelGGL(la::act_fwd_kernel, dim3(la::grid_for_n(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n, kind);
+  LA_CHECK_LAUNCH("la_act_fwd");
+  return 0;
+}
+
+extern "C" int la_act_bwd(const float* x, const float* dy, float* dx, long n, int kind, void* stream) {
+  LA_CHECK_ARG(x && dy && dx && n > 0 && (kind == LA_ACT_GELU || kind == LA_ACT_RELU), "la_act_bwd: bad arguments");
+  hipLaunchKernelGGL(la::act_bwd_kernel, dim3(la::grid_for_n(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, dy, dx, n, kind);
+  LA_CHECK_LAUNCH("la_act_bwd");
+  return 0;
+}
+
+extern "C" int la_attn_small_lse(const float* q, int ldq, const float* k, int ldk, int B, int Nq, int Nk, int heads, int hd, float* lse,
+                                 void* stream) {
+  LA_CHECK_ARG(q && k && lse && B > 0 && Nq > 0 && Nk > 0 && heads > 0, "la_attn_small_lse: bad arguments");
+  la::AttnBwdArgs a{};
+  a.q = q; a.k = k; a.ldq = ldq; a.ldk = ldk; a.B = B; a.Nq = Nq; a.Nk = Nk; a.heads = heads;
+  a.scale = 1.0f / sqrtf((float)hd);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(B * Nq * heads), block(256);
+  switch (hd) {
+    case 4: hipLaunchKernelGGL(la::attn_lse_kernel<4>, grid, block, 0, st, a, lse); break;
+    case 8: hipLaunchKernelGGL(la::attn_lse_kernel<8>, grid, block, 0, st, a, lse); break;
+    case 16: hipLaunchKernelGGL(la::attn_lse_kernel<16>, grid, block, 0, st, a, lse); break;
+    case 32: hipLaunchKernelGGL(la::attn_lse_kernel<32>, grid, block, 0, st, a, lse); break;
+    case 64: hipLaunchKernelGGL(la::attn_lse_kernel<64>, grid, block, 0, st, a, lse); break;
+    default: LA_CHECK_ARG(false, "la_attn_small_lse: unsupported head dim %d (4, 8, 16, 32, 64)", hd);
+  }
+  LA_CHECK_LAUNCH("la_attn_small_lse");
+  return 0;
+}
+
+extern "C" int la_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* dout,
+                                 int ldo, const float* lse, int B, int Nq, int Nk, int heads, int hd, float* dq, float* dk, float* dv,
+                                 void* stream) {
+  LA_CHECK_ARG(q && k && v && dout && dq && dk && dv, "la_attn_small_bwd: null pointer");
+  LA_CHECK_ARG(B > 0 && Nq > 0 && Nk > 0 && heads > 0, "la_attn_small_bwd: bad shape");
+  la::AttnBwdArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.Nq = Nq; a.Nk = Nk; a.heads = heads;
+  a.scale = 1.0f / sqrtf((float)hd);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool fewkeys = Nk <= 256 && (Nk <= Nq || Nq > 256);
+  if (fewkeys) {
+    // dq is written, dk / dv are accumulated: the caller zero-fills dk / dv
+    const long per_b = ((long)heads * Nq + 63) / 64 * 64;
+    const long total = per_b * B;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (hd) {
+      case 4: hipLaunchKernelGGL(la::attn_bwd_fewkeys_kernel<4>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(la::attn_bwd_fewkeys_kernel<8>, grid, block, 0, st, a); break;
+      case 16: hipLaunchKernelGGL(la::attn_bwd_fewkeys_kernel<16>, grid, block, 0, st, a); break;
+      case 32: hipLaunchKernelGGL(la::attn_bwd_fewkeys_kernel<32>, grid, block, 0, st, a); break;
+      case 64: hipLaunchKernelGGL(la::attn_bwd_fewkeys_kernel<64>, grid, block, 0, st, a); break;
+      default: LA_CHECK_ARG(false, "la_attn_small_bwd: unsupported head dim %d (4, 8, 16, 32, 64)", hd);
+    }
+  } else {
+    LA_CHECK_ARG(Nq <= 256, "la_attn_small_bwd: one side of the attention must have <= 256 rows (Nq=%d Nk=%d)", Nq, Nk);
+    LA_CHECK_ARG(o && lse, "la_attn_small_bwd: the few-queries form needs the saved output and la_attn_small_lse statistics");
+    // dk / dv are written, dq is accumulated: the caller zero-fills dq
+    const long kpad = (Nk + 63) / 64 * 64;
+    const long total = kpad * B * heads;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    switch (hd) {
+      case 4: hipLaunchKernelGGL(la::attn_bwd_fewqueries_kernel<4>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(la::attn_bwd_fewqueries_kernel<8>, grid, block, 0, st, a); break;
+      case 16: hipLaunchKernelGGL(la::attn_bwd_fewqueries_kernel<16>, grid, block, 0, st, a); break;
+      case 32: hipLaunchKernelGGL(la::attn_bwd_fewqueries_kernel<32>, grid, block, 0, st, a); break;
+      case 64: hipLaunchKernelGGL(la::attn_bwd_fewqueries_kernel<64>, grid, block, 0, st, a); break;
+      default: LA_CHECK_ARG(false, "la_attn_small_bwd: unsupported head dim %d (4, 8, 16, 32, 64)", hd);
+    }
+  }
+  LA_CHECK_LAUNCH("la_attn_small_bwd");
+  return 0;
+}
+
+extern "C" int la_bilinear_bwd(const float* dy, int n, int oh, int ow, long dy_plane, int dy_ld, float* dx, int ih, int iw, long dx_plane,
+                               int dx_ld, void* stream) {
+  LA_CHECK_ARG(dy && dx && n > 0 && oh > 0 && ow > 0 && ih > 0 && iw > 0, "la_bilinear_bwd: bad arguments");
+  hipLaunchKernelGGL(la::bilinear_bwd_kernel, dim3(la::grid_for_n((long)n * oh * ow)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, n,
+                     oh, ow, dy_plane, dy_ld, dx, ih, iw, dx_plane, dx_ld);
+  LA_CHECK_LAUNCH("la_bilinear_bwd");
+  return 0;
+}
+
+extern "C" int la_classify_bwd(const float* dseg, const float* feat, const float* protos, int B, int npix, int C, int cf, float* dfeat,
+                               float* dprotos, void* stream) {
+  LA_CHECK_ARG(dseg && feat && protos && dfeat && dprotos, "la_classify_bwd: null pointer");
+  LA_CHECK_ARG(B > 0 && npix > 0 && C > 0 && C <= 32, "la_classify_bwd: C=%d out of range (1..32)", C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((npix + 255) / 256, B), block(256);
+  switch (cf) {
+    case 8: hipLaunchKernelGGL(la::classify_bwd_kernel<8>, grid, block, 0, st, dseg, feat, protos, B, npix, C, dfeat, dprotos); break;
+    case 16: hipLaunchKernelGGL(la::classify_bwd_kernel<16>, grid, block, 0, st, dseg, feat, protos, B, npix, C, dfeat, dprotos); break;
+    case 32: hipLaunchKernelGGL(la::classify_bwd_kernel<32>, grid, block, 0, st, dseg, feat, protos, B, npix, C, dfeat, dprotos); break;
+    case 64: hipLaunchKernelGGL(la::classify_bwd_kernel<64>, grid, block, 0, st, dseg, feat, protos, B, npix, C, dfeat, dprotos); break;
+    default: LA_CHECK_ARG(false, "la_classify_bwd: unsupported feature width %d (8, 16, 32, 64)", cf);
+  }
+  LA_CHECK_LAUNCH("la_classify_bwd");
+  return 0;
+}
+
+extern "C" int la_row_broadcast(const float* src, long groups, int rep, int D, float scale, float* out, void* stream) {
+  LA_CHECK_ARG(src && out && groups > 0 && rep > 0 && D > 0 && (D % 4) == 0, "la_row_broadcast: bad arguments (D %% 4 == 0)");
+  hipLaunchKernelGGL(la::row_broadcast_kernel, dim3(la::grid_for_n(groups * rep * (D / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     src, groups, rep, D, scale, out);
+  LA_CHECK_LAUNCH("la_row_broadcast");
+  return 0;
+}

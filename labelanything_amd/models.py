@@ -127,6 +127,14 @@ class Lam(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def invalidate(self) -> None:
+        """Drop the packed-weight engine (and its captured graphs): call after ANY out-of-band parameter update - an optimizer
+        that writes through raw pointers (FlatAdamW / la_adamw_step) does not bump the tensors' version counters, so the cache key
+        of ``engine()`` cannot see it.  The next forward re-packs from the live parameters."""
+        self._engine = None
+        self._engine_key = None
+        self._graphs = {}
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         sd = dict(state_dict)
         # tolerate accelerate / DDP wrappers like the reference's loader (utils/utils.py:119-142)

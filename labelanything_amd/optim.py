@@ -57,13 +57,32 @@ class FlatAdamW:
     def zero_grad(self) -> None:
         self.grad.zero_()
 
-    def step(self, all_reduce: bool = True) -> None:
-        """Average ``self.grad`` over the data-parallel ranks (if a process group is up) and apply one AdamW update."""
+    def step(self, all_reduce: bool = True, active=None) -> None:
+        """Average ``self.grad`` over the data-parallel ranks (if a process group is up) and apply one AdamW update.
+
+        active: optional per-parameter flags "this tensor received a gradient in this step".  torch.optim.AdamW skips tensors whose
+        ``.grad`` is None - no moment update and NO weight decay - which is what happens to the parameters the reference's forward
+        never reaches (DDP ``find_unused_parameters``, experiment/run.py:123); contiguous runs of active tensors are updated with
+        one launch each (one launch in the usual case: never-used tensors are kept at the tail by LamTrainer)."""
         world = 1
         if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size()
             sum_over_ranks(self.grad)
         self.steps += 1
-        L.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                     self.steps, 1.0 / world)
+        spans = [(0, self.flat.numel())]
+        if active is not None:
+            spans, off, cur = [], 0, None
+            for p, a in zip(self.params, active):
+                k = p.numel()
+                if a:
+                    cur = [off, off + k] if cur is None else [cur[0], off + k]
+                elif cur is not None:
+                    spans.append(tuple(cur))
+                    cur = None
+                off += k
+            if cur is not None:
+                spans.append(tuple(cur))
+        for a, b in spans:
+            L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.lr, self.betas[0], self.betas[1],
+                         self.eps, self.weight_decay, self.steps, 1.0 / world)
         self.sched_steps += 1

@@ -90,3 +90,15 @@ CASES = {
         slow=True, store_full_logits=False, store_query_embedding=False, oracle_tol=1e-4,
     ),
 }
+
+
+# Training-step fixture (tests/golden/train_step.safetensors, tools/make_golden_train.py): decoder-only model with the LAM neck
+# (96 -> 64), D = 64, class encoder on, masks + points + boxes, 2-way 2-shot, two episodes, non-square original sizes.
+TRAIN_CASE = dict(
+    cfg=LamConfig(encoder=None, use_vit=False, image_size=128, image_embed_dim=96, embed_dim=64, spatial_convs=3,
+                  class_encoder={"name": "RandomMatrixEncoder", "bank_size": 10, "embed_dim": 64}, custom_preprocess=True),
+    weight_seed=21,
+    episode=dict(batch=2, n_ways=2, k_shots=2, image_size=128, seed=121, prompts=("mask", "point", "box"),
+                 embeddings_channels=96, grid=8, dims=[[100, 128]] * 5),
+    lr=1e-3, weight_decay=1e-2, steps=3, warmup=2,
+)

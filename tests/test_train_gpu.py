@@ -1,0 +1,189 @@
+"""GPU: the training step (forward -> focal objective -> backward -> AdamW) of the HIP path against torch autograd of the CPU
+oracle (oracle/lam_oracle.py + oracle/loss_oracle.py, both pinned on the reference) and against the reference's own parameter
+update (tests/golden/train_step_*.safetensors, tools/make_golden_train.py)."""
+import os
+
+import pytest
+import torch
+
+from labelanything_amd.episodes import make_episode
+from labelanything_amd.models import Lam
+from labelanything_amd.train import LamTrainer
+from labelanything_amd.weights import init_state_dict
+from oracle import lam_oracle as O
+from oracle import loss_oracle as LO
+from tests.cases import CASES, geometry_for
+from tests.helpers import GOLDEN, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make_gt(batch, n_classes, seed=0):
+    """A ground-truth map per episode at the padded output size: random blocky labels, some ignored pixels."""
+    g = torch.Generator().manual_seed(seed)
+    dims = batch["dims"]
+    b = dims.shape[0]
+    hmax, wmax = int(dims[..., 0].max()), int(dims[..., 1].max())
+    gt = torch.randint(0, n_classes, (b, (hmax + 15) // 16, (wmax + 15) // 16), generator=g)
+    gt = gt.repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :hmax, :wmax].contiguous()
+    for i in range(b):
+        h, w = int(dims[i, 0, 0]), int(dims[i, 0, 1])
+        gt[i, h:, :] = -100
+        gt[i, :, w:] = -100
+    gt[torch.rand(gt.shape, generator=g) < 0.02] = -100
+    return gt
+
+
+def oracle_grads(case, batch, gt, rows):
+    cfg = case["cfg"]
+    w = {k: v.clone().requires_grad_(v.is_floating_point() and "image_encoder" not in k and "gaussian" not in k)
+         for k, v in init_state_dict(cfg, case["weight_seed"]).items()}
+    out = O.lam_forward(w, geometry_for(cfg), batch, selected_rows=rows)
+    loss, _ = LO.focal_objective(out["logits"], gt)
+    loss.backward()
+    return float(loss.detach()), out["logits"].detach(), {k: v.grad for k, v in w.items() if v.requires_grad and v.grad is not None}
+
+
+@pytest.mark.parametrize("name", ["novit_d256_2w3s", "novit_d512_neck_1w2s", "sam_tiny_2w2s_all_prompts", "hf_tiny_1w1s_masks"])
+def test_gradients_match_oracle_autograd(name):
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    c = batch["flag_examples"].shape[2]
+    gt = make_gt(batch, c, seed=3)
+    rows = gold.get("selected_rows")
+    ref_loss, ref_logits, ref_g = oracle_grads(case, batch, gt, rows)
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    lam.selected_rows = rows
+    tr = LamTrainer(lam)
+    tr.opt.zero_grad()
+    res = tr.forward_backward(batch, gt)
+    torch.cuda.synchronize()
+    # forward of the training graph == inference engine == oracle (the encoder, when present, runs with 16-bit operands)
+    tol_fwd = 1e-3 if case["cfg"].encoder_spec is not None else 2e-5
+    assert rel_err(res["logits"], ref_logits) <= tol_fwd
+    assert abs(float(res["loss"]) - ref_loss) <= tol_fwd * max(1.0, abs(ref_loss))
+    # per-tensor max error relative to the tensor's own gradient scale, floored at 1e-2 of the largest gradient of the model:
+    # several parameters have an analytically ZERO gradient (a key-projection bias shifts all scores of a softmax row alike, the
+    # last class_mlp bias shifts all class logits of a pixel alike) and the reference's value for them is rounding noise
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    worst = {}
+    for k, gv in zip(tr.names, tr.opt.grad_views):
+        ref = ref_g.get(k)
+        if ref is None:                 # never reached by the forward (dead final attention of the prompt encoder's transformer)
+            assert float(gv.abs().max()) == 0.0, k
+            continue
+        assert torch.isfinite(gv).all(), k
+        worst[k] = float((gv.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * gmax)
+    # Decoder-only models: the gradient must match to accumulation accuracy.  With an image encoder in front, the embeddings carry
+    # the 16-bit operand error of the HIP encoder (3-6e-4) and the gradient of a random-weight decoder amplifies that by up to two
+    # orders of magnitude (measured 2-6e-2 on hf_tiny; with the ORACLE's embeddings fed in instead the same graph is at 2.4e-4:
+    # test_decoder_graph_is_exact_behind_an_encoder below) - the image path is therefore only held to 1e-1 here.
+    tol = 1e-1 if case["cfg"].encoder_spec is not None else 3e-4
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    assert set(k for k in ref_g) <= set(tr.names)
+
+
+def test_decoder_graph_is_exact_behind_an_encoder():
+    """hf_tiny with the oracle's (fp32) encoder output fed in as precomputed pre-neck embeddings: LAM neck + decoder gradients
+    match the oracle's autograd to accumulation accuracy, i.e. the looser bound of the image path above is the encoder's
+    16-bit operands, not the training graph."""
+    case = CASES["hf_tiny_1w1s_masks"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    ref_loss, _, ref_g = oracle_grads(case, batch, gt, None)
+    w = init_state_dict(case["cfg"], case["weight_seed"])
+    with torch.no_grad():
+        im = batch["images"]
+        b, n = im.shape[:2]
+        e = O.encode_images(w, geometry_for(case["cfg"]), im.flatten(0, 1))
+    b2 = {k: v for k, v in batch.items() if k != "images"}
+    b2["embeddings"] = e.view(b, n, *e.shape[1:])
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    tr = LamTrainer(lam)
+    tr.opt.zero_grad()
+    res = tr.forward_backward(b2, gt)
+    assert abs(float(res["loss"]) - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss))
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    for k, gv in zip(tr.names, tr.opt.grad_views):
+        if k in ref_g:
+            assert float((gv.cpu() - ref_g[k]).abs().max()) / max(float(ref_g[k].abs().max()), 1e-2 * gmax) <= 4e-4, k
+
+
+def test_three_steps_match_the_reference_fixture():
+    """tests/golden/train_step.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up schedule
+    (tools/make_golden_train.py): losses of three steps, the first gradient and the total parameter change of every tensor."""
+    import json
+    from safetensors.torch import load_file
+    from tests.cases import TRAIN_CASE as case
+    gold = load_file(os.path.join(GOLDEN, "train_step.safetensors"))
+    with open(os.path.join(GOLDEN, "train_step.json")) as fh:
+        keys = json.load(fh)["keys"]
+    batch = make_episode(**case["episode"])
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    lam.selected_rows = gold["selected_rows"]
+    start = {k: p.detach().clone() for k, p in lam.named_parameters()}
+    tr = LamTrainer(lam, lr=case["lr"], weight_decay=case["weight_decay"], num_warmup_steps=case["warmup"])
+    assert sorted(tr.names) == keys
+    losses = []
+    for step in range(case["steps"]):
+        tr.opt.zero_grad()
+        res = tr.forward_backward(batch, gold["gt"])
+        losses.append(float(res["loss"]))
+        if step == 0:
+            assert rel_err(res["logits"], gold["logits0"]) <= 2e-5
+            g0 = {k: gv.clone() for k, gv in zip(tr.names, tr.opt.grad_views)}
+        tr.apply_update()
+        lam.invalidate()
+    assert torch.allclose(torch.tensor(losses), gold["loss"], rtol=2e-5, atol=0), (losses, gold["loss"])
+    gn = torch.stack([g0[k].norm() for k in keys]).cpu()
+    dn = torch.stack([(dict(lam.named_parameters())[k].detach() - start[k]).norm() for k in keys]).cpu()
+    floor_g = 1e-3 * float(gold["grad_norm"].max())
+    assert float(((gn - gold["grad_norm"]).abs() / gold["grad_norm"].clamp_min(floor_g)).max()) <= 1e-3
+    # AdamW's step is lr * m / (sqrt(v) + eps): a tensor whose gradient is rounding noise (analytically zero: key-projection biases,
+    # the last class_mlp bias) moves by ~lr per entry in a noise-given direction, in the reference as here - its total change is
+    # only bounded; every tensor with a real gradient must move exactly like the reference's, and the tensors the forward never
+    # reaches must not move at all (torch skips .grad = None tensors, weight decay included)
+    real = ((gn - gold["grad_norm"]).abs() <= 1e-3 * gold["grad_norm"]) & (gold["grad_norm"] > 0)   # gradient is signal, not noise
+    assert int(real.sum()) >= 0.8 * len(keys)
+    dead = gold["delta_norm"] == 0           # .grad was None in the reference: AdamW skipped the tensor, weight decay included
+    zero_g = (gold["grad_norm"] == 0) & ~dead  # a ZERO gradient tensor is decayed, here as there (point_embeddings.3: no real 2nd corner)
+    assert float(((dn - gold["delta_norm"]).abs() / gold["delta_norm"].clamp_min(1e-12))[zero_g].max()) <= 1e-4 if bool(zero_g.any()) else True
+    # (single ENTRIES of a real tensor can still be noise - units that are almost dead - so the norms agree tightly for most tensors
+    # and loosely for all; the entry-wise check below is the sharp one)
+    rel_d = ((dn - gold["delta_norm"]).abs() / gold["delta_norm"].clamp_min(1e-12))[real]
+    assert float(rel_d.quantile(0.9)) <= 2e-3 and float(rel_d.max()) <= 0.5, (float(rel_d.quantile(0.9)), float(rel_d.max()))
+    assert float(dn[dead].abs().max()) == 0.0 and int(dead.sum()) >= 10
+    params = dict(lam.named_parameters())
+    gmax = max(float(v.abs().max()) for k, v in gold.items() if k.startswith("grad."))
+    for k, v in gold.items():
+        if k.startswith("grad."):
+            assert float((g0[k[5:]].cpu() - v).abs().max()) <= 3e-4 * max(float(v.abs().max()), 1e-2 * gmax), k
+        if k.startswith("final."):
+            name = k[6:]
+            mine, ref0 = params[name].detach().cpu(), start[name].cpu()
+            sig = gold["grad." + name].abs() > 1e-2 * gold["grad." + name].abs().max()             # entries with a real gradient
+            step_ref, step_mine = (v - ref0)[sig], (mine - ref0)[sig]
+            assert float((step_mine - step_ref).abs().max()) <= 2e-2 * float(step_ref.abs().max()), name
+
+
+def test_step_updates_weights_and_invalidates_the_engine():
+    """FlatAdamW writes through raw pointers; the inference engine must re-pack afterwards."""
+    case = CASES["novit_d512_neck_1w2s"]
+    gold, _ = load_golden("novit_d512_neck_1w2s")
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=4)
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    lam.selected_rows = gold.get("selected_rows")
+    before = lam(batch)["logits"].clone()
+    tr = LamTrainer(lam, lr=1e-3)
+    l0 = float(tr.step(batch, gt)["loss"])
+    after = lam(batch)["logits"]
+    assert not torch.allclose(before, after)                      # the forward sees the updated weights ...
+    fresh = Lam(case["cfg"], seed=123).cuda()
+    fresh.load_state_dict(lam.state_dict())
+    fresh.selected_rows = lam.selected_rows
+    assert rel_err(after, fresh(batch)["logits"]) < 1e-6          # ... exactly as a freshly built model with the same weights does
+    losses = [l0] + [float(tr.step(batch, gt)["loss"]) for _ in range(5)]
+    assert losses[-1] < losses[0]                                 # and the objective goes down on the batch it is trained on
