@@ -51,6 +51,18 @@ WORKLOADS = {
                  model=dict(encoder=None, use_vit=False, image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3,
                             custom_preprocess=False),
                  episode=dict(n_ways=2, k_shots=5, image_size=1024, embeddings_channels=256, grid=64), default_episodes=8),
+    "cfg5": dict(desc="BASELINE cfg5 geometry, forward: ViT-MAE-L 480px (parameters/trainval/coco/mael.yaml), 10-way 5-shot episodes "
+                      "(51 images, 550 prompt pairs each), 16-bit MFMA attention (the fp8 attention of BASELINE cfg5 is not built)",
+                 model=dict(encoder="vit_l_mae", image_size=480, image_embed_dim=1024, embed_dim=256, spatial_convs=3,
+                            class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
+                 episode=dict(n_ways=10, k_shots=5, image_size=480), default_episodes=1),
+    # BASELINE cfg3 as it is trained (mae_noembs.yaml): one optimizer step per episode batch = frozen-encoder forward, decoder forward,
+    # focal objective, backward, flat-gradient SUM all-reduce over the ranks (RCCL), AdamW.  value = episodes/s of full training steps.
+    "cfg3_train": dict(desc="BASELINE cfg3 TRAINING step: ViT-MAE-B 480px (frozen), 5-way 5-shot episodes, focal objective, backward through "
+                            "neck + prompt encoder + mask decoder (10.14 M parameters), gradient all-reduce, AdamW",
+                       model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
+                                  class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
+                       episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=1, train=True),
 }
 
 
@@ -82,7 +94,8 @@ class KernelTimer:
         self.saved = {}
         names = ["gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
                  "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
-                 "conv3x3_f32", "nhwc_to_nchw", "dense_pe"]
+                 "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
+                 "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -107,13 +120,15 @@ class KernelTimer:
                                                               + 4 * (kw.get("res") is not None and kw.get("res_mod", 0) == 0))
                     if kw.get("vt") is not None:
                         nbytes += esz * m * (n - kw.get("vt_col0", 0))
+                elif _n == "gemm_tn":
+                    flops = issued = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
                     flops = 4.0 * b * heads * t * t * 64
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
-                self.records.append((tag, flops, s, e, nbytes, issued if _n == "gemm" else flops))
+                self.records.append((tag, flops, s, e, nbytes, issued if _n in ("gemm", "gemm_tn") else flops))
             setattr(L, n, wrapped)
         return self
 
@@ -134,33 +149,65 @@ class KernelTimer:
         return agg
 
 
-def pmc_traffic():
-    """HBM-side bytes per la_gemm launch of THIS workload from the committed PMC passes (profiles/*_traffic.json, written by
-    tools/collect_profiles.sh with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); None when no such file is present."""
+def pmc_traffic(workload: str, precise):
+    """HBM-side bytes per la_gemm launch from the committed PMC passes (profiles/r*_traffic.json, written by tools/collect_profiles.sh
+    with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE).  A file only applies to the workload AND the numerics configuration it was
+    collected on (it records both); anything else reports null instead of a stale number."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        return json.load(f).get("bytes_per_launch")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload", "cfg2") == workload and d.get("encoder_split_precision") == list(precise):
+            return d.get("bytes_per_launch")
+    return None
 
 
-def cpu_baseline(cfg, episodes_sample: int = 1):
-    """Time the CPU oracle on one episode of the same workload (host cores of this box)."""
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this box from /proc/cpuinfo."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("processor"):
+                    logical += 1
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(cfg, timed: int = 3):
+    """Time the CPU oracle (kind "port": the checked restatement of the reference's torch path) on this box's host cores: one warm-up
+    episode + the median of ``timed`` episodes of the bench workload, torch intra-op threads = physical cores."""
     from labelanything_amd.episodes import make_episode
     from labelanything_amd.weights import init_state_dict
     from oracle import lam_oracle as O
     from tests.cases import geometry_for
     sd = init_state_dict(cfg, 2)
-    batch = make_episode(batch=episodes_sample, n_ways=1, k_shots=1, image_size=1024, seed=1234, prompts=("mask",))
     geo = geometry_for(cfg)
-    cores = torch.get_num_threads()
+    model, phys, logical = host_cpu()
+    torch.set_num_threads(max(1, phys))
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        O.lam_forward(sd, geo, batch)
-        dt = time.perf_counter() - t0
-    return {"value": round(episodes_sample / dt, 5), "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": f"{episodes_sample} episode (2 images 1024x1024) of the bench workload, fp32 torch CPU oracle, {dt:.1f} s, no warm-up"}
+        for i in range(timed + 1):
+            batch = make_episode(batch=1, n_ways=1, k_shots=1, image_size=1024, seed=1234 + i, prompts=("mask",))
+            t0 = time.perf_counter()
+            O.lam_forward(sd, geo, batch)
+            if i:
+                times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(1.0 / med, 5), "unit": "episodes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": model, "physical_cores": phys, "logical_cpus": logical,
+            "sample": f"1 warm-up + median of {timed} episodes (2 images 1024x1024 each) of the bench workload, fp32 torch CPU oracle, "
+                      f"{med:.1f} s per episode (all: {', '.join(f'{t:.1f}' for t in times)})"}
 
 
 def main():
@@ -205,8 +252,17 @@ def main():
     precise = None if a.precise == "default" else (() if a.precise == "none" else tuple(a.precise.split(",")))
     lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None, a.workload, precise)
     lam = lam.to(dev)
-    lam.use_graphs = not a.no_graphs
+    train = bool(WORKLOADS[a.workload].get("train"))
+    lam.use_graphs = not a.no_graphs and not train
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
+    if train:
+        from labelanything_amd.train import LamTrainer
+        trainer = LamTrainer(lam, lr=5e-5, num_warmup_steps=1000)           # mae_noembs.yaml:30-37
+        c = batch["flag_examples"].shape[2]
+        gt = torch.randint(0, c, (a.episodes, WORKLOADS[a.workload]["episode"]["image_size"], WORKLOADS[a.workload]["episode"]["image_size"]),
+                           generator=torch.Generator().manual_seed(99 + rank)).to(dev)
+        lam_fwd = lam
+        lam = lambda bt: trainer.step(bt, gt)                               # noqa: E731  one full optimizer step
 
     def barrier():
         torch.cuda.synchronize()
@@ -226,13 +282,14 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(out["logits"]).all()
+    assert torch.isfinite(out["logits"][out["logits"] > float("-inf")]).all()
 
     # instrumented step: per-kernel HIP-event timing (outside the timed region)
     roof = None
     kernels = None
     if rank == 0:
-        lam.use_graphs = False          # per-kernel events need eager launches
+        if not train:
+            lam.use_graphs = False      # per-kernel events need eager launches
         with KernelTimer() as kt:
             lam(batch)
         agg = kt.summary()
@@ -249,7 +306,7 @@ def main():
             ach = g[2] / g[1] / 1e12
             roof = {"kernel": "la_gemm (gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(a.workload, (lam_fwd if train else lam).precise),
                     "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
                     "share_of_kernel_time": round(g[1] / tot, 3),
                     # split-precision weights ([W_hi | W_lo]) issue two MFMA passes for one algorithmic product
@@ -258,14 +315,16 @@ def main():
     if rank == 0:
         eps = a.episodes * world * a.steps / elapsed
         line = {
-            "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot" if a.workload == "cfg2" else f"episodes/sec (forward) {a.workload}",
+            "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot" if a.workload == "cfg2" else
+                      (f"episodes/sec (training steps) {a.workload}" if train else f"episodes/sec (forward) {a.workload}"),
             "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list(lam.precise), "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),
-                       "parallelism": f"episode-sharded x{world}, no collective",
+                       "parallelism": (f"data-parallel x{world}, one flat-gradient SUM all-reduce (RCCL) per step" if train else
+                                       f"episode-sharded x{world}, no collective"),
                        "launch": "eager" if a.no_graphs else "hipGraph replay"},
             "roofline": roof, "kernels_ms_per_step": kernels,
         }

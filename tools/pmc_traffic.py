@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py into per-launch HBM-side traffic of the GEMM kernels.
 
-    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [workload] [precise groups, comma list]
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
 (MI355X_MICROARCH.md, "HBM"), so reads are doubled; WRITE_SIZE is taken as reported (it matches the algorithmic output
@@ -9,8 +9,11 @@ bytes of the GEMMs exactly, see profiles/r01_pmc_summary.txt).
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -33,7 +36,11 @@ def main():
     launches = sum(fcnt[n] for n in names)
     fkib = sum(fetch[n] for n in names)
     wkib = sum(write.get(n, 0.0) for n in names)
+    from labelanything_amd.engine import PRECISE_DEFAULT
+    workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    precise = list(PRECISE_DEFAULT) if len(sys.argv) <= 5 or sys.argv[5] == "default" else [g for g in sys.argv[5].split(",") if g and g != "none"]
     out = {
+        "workload": workload, "encoder_split_precision": precise,      # bench.py only attaches this file to a matching run
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-graphs --no-cpu-baseline`",
         "kernels": names,
         "launches_counted": launches,
