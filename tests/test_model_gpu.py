@@ -279,3 +279,72 @@ def test_cfg5_episode_shape_10way_5shot_matches_oracle():
     assert out["class_examples_embeddings"].shape == (1, 50, 11, 64)
     assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
     assert rel_err(out["logits"], ref["logits"]) < 4e-3
+
+
+# ---- every BASELINE config at its own size ----------------------------------------------------------------------------------------
+def _bench_model(workload, episodes=1, seed=7, **kw):
+    import bench
+    from labelanything_amd.config import LamConfig
+    w = bench.WORKLOADS[workload]
+    lam = Lam(LamConfig(**w["model"]), seed=3, **kw).cuda()
+    batch = make_episode(batch=episodes, seed=seed, prompts=("mask",), **w["episode"])
+    return lam, batch
+
+
+def test_cfg4_full_size_matches_the_oracle():
+    """BASELINE cfg4 at its own size: precomputed 256 x 64 x 64 embeddings, 2-way 5-shot (30 prompt pairs, hw = 4096), whole
+    decoder + post-processing against the CPU oracle (44.6 GMAC: a few seconds of host time)."""
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    lam, batch = _bench_model("cfg4")
+    out = lam.forward_argmax(batch)
+    with torch.no_grad():
+        ref = O.lam_forward(init_state_dict(lam.cfg, 3), geometry_for(lam.cfg), batch)
+    assert out["logits"].shape == (1, 3, 1024, 1024)
+    assert rel_err(out["logits"], ref["logits"]) <= 2e-5
+    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) <= 2e-5
+    n_diff, n_real = argmax_disagreement(out["logits"], ref["logits"].argmax(1), ref["logits"], margin_rel=1e-4)
+    assert n_real == 0 and n_diff <= 1e-3 * out["logits"][:, 0].numel()       # near-ties (margin < 1e-4 of the logit range) may swap
+
+
+@pytest.mark.parametrize("workload", ["cfg3", "cfg5"])
+def test_full_geometry_episode_properties(workload):
+    """BASELINE cfg3 (MAE-B 480, 5-way 5-shot: 26 images, 150 pairs) and cfg5 (MAE-L 480, 10-way 5-shot: 51 images, 550 pairs) at
+    full geometry.  The oracle needs minutes per episode here, so: shapes, finiteness, HIP-graph replay == eager launches bit for bit,
+    and episode-shard invariance (two episodes in one batch == the same episodes one at a time: what N-GPU sharding relies on)."""
+    lam, batch = _bench_model(workload, episodes=2)
+    lam.selected_rows = torch.arange(batch["flag_examples"].shape[2])
+    both = lam(batch)["logits"]
+    c = batch["flag_examples"].shape[2]
+    assert both.shape == (2, c, 480, 480) and bool(torch.isfinite(both).all())
+    singles = [lam({k: v[i:i + 1] for k, v in batch.items()})["logits"] for i in range(2)]
+    assert rel_err(both, torch.cat(singles)) <= 1e-5          # batched GEMM tiles see other row neighbours: accumulation-level only
+    lam.use_graphs = True
+    g1 = lam(batch)["logits"].clone()
+    g2 = lam(batch)["logits"]
+    assert torch.equal(g1, g2) and torch.equal(g1, both)
+
+
+def test_cfg3_decoder_at_full_size_matches_the_oracle_on_device_embeddings():
+    """cfg3 at full size, decoder side against the oracle: the HIP encoder's post-neck embeddings are handed to the CPU oracle's
+    prompt encoder + mask decoder + post-processing (150 pairs x 900 positions: seconds), which must reproduce the HIP logits."""
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    lam, batch = _bench_model("cfg3")
+    rows = torch.arange(batch["flag_examples"].shape[2])
+    lam.selected_rows = rows
+    out = lam(batch)
+    e32, b, n, g = lam._embeddings_nhwc(batch, True)
+    d = lam.cfg.embed_dim
+    emb = e32.view(b, n, g * g, d).permute(0, 1, 3, 2).reshape(b, n, d, g, g).cpu()
+    w = init_state_dict(lam.cfg, 3)
+    geo = geometry_for(lam.cfg)
+    with torch.no_grad():
+        pts, bxs, msk = O.select_prompts(batch)
+        pe = O.prompt_encoder(w, geo, emb[:, 1:], pts, bxs, msk, batch["flag_examples"], rows)
+        low = O.mask_decoder(w, geo, emb[:, 0], pe["class_embeddings"])
+        ref = O.postprocess(geo, low, batch["dims"], batch.get("flag_gts"))
+    assert rel_err(out["class_examples_embeddings"], pe["class_examples_embeddings"]) <= 2e-5
+    assert rel_err(out["logits"], ref) <= 5e-5
