@@ -68,10 +68,9 @@ WORKLOADS = {
 
 def build_model(dtype, decoder_dtype=torch.float32, workload="cfg2", precise=None):
     from labelanything_amd.config import LamConfig
-    from labelanything_amd.engine import PRECISE_DEFAULT
     from labelanything_amd.models import Lam
     cfg = LamConfig(**WORKLOADS[workload]["model"])
-    return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype, precise=PRECISE_DEFAULT if precise is None else precise), cfg
+    return Lam(cfg, seed=2, compute_dtype=dtype, decoder_dtype=decoder_dtype, precise="auto" if precise is None else precise), cfg
 
 
 def make_inputs(episodes: int, seed: int, device, workload="cfg2"):
@@ -222,7 +221,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--decoder", default="f32", choices=["f32", "same"], help="operand type of the decoder-side GEMMs")
     ap.add_argument("--precise", default="default", help="encoder GEMM groups in split precision: 'default' (the parity-tested "
-                    "configuration, engine.PRECISE_DEFAULT), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
+                    "configuration, engine.resolve_precise), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
                     "or a comma list of groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")

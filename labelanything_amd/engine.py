@@ -53,13 +53,30 @@ class Arena:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
-# Encoder GEMM groups that run in split precision by default (tools/error_budget.py): the 16-bit rounding of
-# the WEIGHTS is the same perturbation for every token, so its effect survives attention and pooling instead of averaging
-# out like the activation roundings, and the necks / patch embedding have no residual stream to dilute their error.
+# Encoder GEMM groups that run in split precision (tools/error_budget.py): the 16-bit rounding of the WEIGHTS is
+# the same perturbation for every token, so its effect survives attention and pooling instead of averaging out like the
+# activation roundings, and the necks / patch embedding have no residual stream to dilute their error.
 #   "qkv", "proj", "lin1", "lin2": weights as two 16-bit planes [W_hi | W_lo] (la_gemm a_kmod), activations 16-bit;
 #   "patch", "neck": exact-fp32 MFMA (1 % of the FLOPs).
-PRECISE_DEFAULT = ("patch", "qkv", "proj", "lin2", "neck")
+# Which planes are worth their MFMA passes was measured on the six golden cases (profiles/r02_parity_groups.log, max error of
+# any stage, tolerance 1e-3): full set 3.7-6.0e-4; without lin2 6.2-8.3e-4; without lin2 and proj 7.4-9.1e-4.  The 768+-wide
+# encoders of the BASELINE configs keep patch / qkv / proj / neck (cfg2 7.0e-4, cfg1 6.2e-4: lin2's second plane would cost
+# 8 % of the step for the last 1.5e-4); encoders narrower than 512 keep lin2 as well (it is cheap there and its share of the
+# error is larger: sam_tiny 8.3e-4 -> 6.0e-4).
+PRECISE_FULL = ("patch", "qkv", "proj", "lin2", "neck")
+PRECISE_WIDE = ("patch", "qkv", "proj", "neck")
+PRECISE_DEFAULT = "auto"
 PRECISE_GROUPS = ("patch", "qkv", "proj", "lin1", "lin2", "neck")
+
+
+def resolve_precise(cfg: LamConfig, precise) -> tuple:
+    """'auto' -> the measured default for this encoder width; None / () -> no split precision; else the given groups."""
+    if isinstance(precise, str):
+        if precise != "auto":
+            raise ValueError("precise must be 'auto', None or a sequence of group names")
+        spec = cfg.encoder_spec
+        return PRECISE_WIDE if (spec is not None and spec.dim >= 512) else PRECISE_FULL
+    return tuple(precise or ())
 
 
 class LamEngine:
@@ -71,7 +88,7 @@ class LamEngine:
         that run in split precision (see PRECISE_DEFAULT); () = every encoder GEMM with plain 16-bit operands."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
-        self.precise = frozenset(precise or ())
+        self.precise = frozenset(resolve_precise(cfg, precise))
         if not self.precise <= set(PRECISE_GROUPS):
             raise ValueError(f"unknown precise groups {sorted(self.precise - set(PRECISE_GROUPS))}; known: {PRECISE_GROUPS}")
         self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)

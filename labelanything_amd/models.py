@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .config import LamConfig, ENCODER_SPECS, config_from_kwargs
-from .engine import LamEngine, PRECISE_DEFAULT
+from .engine import LamEngine, PRECISE_DEFAULT, resolve_precise
 from .weights import model_shapes, init_state_dict
 from . import _lib as L
 
@@ -86,7 +86,7 @@ class Lam(nn.Module):
         self.custom_preprocess = cfg.custom_preprocess
         self.compute_dtype = compute_dtype
         self.decoder_dtype = decoder_dtype
-        self.precise = tuple(precise or ())      # encoder GEMM groups in split precision (engine.PRECISE_DEFAULT)
+        self.precise = resolve_precise(cfg, precise)      # encoder GEMM groups in split precision ('auto': engine.PRECISE_*)
         self.class_embeddings = None
         sd = init_state_dict(cfg, 0 if seed is None else seed)
         for k, v in sd.items():

@@ -6,7 +6,7 @@ import torch
 from labelanything_amd.models import Lam
 from labelanything_amd.episodes import make_episode
 from tests.cases import CASES
-from labelanything_amd.engine import PRECISE_DEFAULT
+from labelanything_amd.engine import PRECISE_DEFAULT, PRECISE_FULL, PRECISE_WIDE
 from tests.helpers import load_golden, rel_err, reference_logits, argmax_disagreement
 
 
@@ -17,6 +17,8 @@ def main():
                 (torch.float16, None, PRECISE_DEFAULT), (torch.bfloat16, torch.float32, PRECISE_DEFAULT)]
     if "--quick" in sys.argv:
         variants = variants[:2]
+    if "--groups" in sys.argv:      # the default against leaner group sets (which planes are worth their MFMA passes)
+        variants = [(torch.float16, torch.float32, g) for g in (PRECISE_FULL, PRECISE_WIDE, ("patch", "qkv", "neck"), ("patch", "qkv", "lin2", "neck"))]
     for dt, ddt, precise in variants:
         for name, case in CASES.items():
             if only and name not in only:
@@ -60,9 +62,8 @@ def main():
             errs["logits_vs_ref"] = rel_err(out["logits"], ref_logits)
             n_diff, n_real = argmax_disagreement(out["logits"], ref_am, ref_logits, margin_rel=2e-3)
             errs["argmax_diff_outside_2e-3_margin"] = n_real
-            ptag = "default" if tuple(precise) == tuple(PRECISE_DEFAULT) else ("none" if not precise else "+".join(precise))
+            ptag = "auto=" + "+".join(lam.precise) if precise == "auto" else ("none" if not precise else "+".join(precise))
             print(f"[{name} enc={str(dt)[6:]} dec={str(ddt)[6:] if ddt else 'same'} precise={ptag}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
-            del lam
             torch.cuda.empty_cache()
 
 

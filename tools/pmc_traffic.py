@@ -36,9 +36,9 @@ def main():
     launches = sum(fcnt[n] for n in names)
     fkib = sum(fetch[n] for n in names)
     wkib = sum(write.get(n, 0.0) for n in names)
-    from labelanything_amd.engine import PRECISE_DEFAULT
+    from labelanything_amd.engine import PRECISE_WIDE
     workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
-    precise = list(PRECISE_DEFAULT) if len(sys.argv) <= 5 or sys.argv[5] == "default" else [g for g in sys.argv[5].split(",") if g and g != "none"]
+    precise = list(PRECISE_WIDE) if len(sys.argv) <= 5 or sys.argv[5] == "default" else [g for g in sys.argv[5].split(",") if g and g != "none"]
     out = {
         "workload": workload, "encoder_split_precision": precise,      # bench.py only attaches this file to a matching run
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-graphs --no-cpu-baseline`",
