@@ -219,7 +219,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the BASELINE metric (default); the others are "
                     "extra data points with the geometry of the other BASELINE configs")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
-    ap.add_argument("--decoder", default="f32", choices=["f32", "same"], help="operand type of the decoder-side GEMMs")
+    ap.add_argument("--decoder", default="f32", choices=["f32", "f16x2", "same"], help="operand type of the decoder-side GEMMs: exact-fp32 "
+                    "MFMA, fp16 plane pairs on the image side (3 fast-MFMA products, fp32-level accuracy), or the encoder's 16-bit type")
     ap.add_argument("--precise", default="default", help="encoder GEMM groups in split precision: 'default' (the parity-tested "
                     "configuration, engine.resolve_precise), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
                     "or a comma list of groups")
@@ -249,7 +250,7 @@ def main():
             dist.init_process_group(backend)
     dtype = torch.float16 if a.dtype == "f16" else torch.bfloat16
     precise = None if a.precise == "default" else (() if a.precise == "none" else tuple(a.precise.split(",")))
-    lam, cfg = build_model(dtype, torch.float32 if a.decoder == "f32" else None, a.workload, precise)
+    lam, cfg = build_model(dtype, {"f32": torch.float32, "f16x2": "f16x2", "same": None}[a.decoder], a.workload, precise)
     lam = lam.to(dev)
     train = bool(WORKLOADS[a.workload].get("train"))
     lam.use_graphs = not a.no_graphs and not train
@@ -318,7 +319,7 @@ def main():
                       (f"episodes/sec (training steps) {a.workload}" if train else f"episodes/sec (forward) {a.workload}"),
             "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": "f32" if a.decoder == "f32" else a.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),

@@ -23,7 +23,11 @@ extern "C" {
 
 /* LA_F32: operands stay fp32 and la_gemm runs on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the 16-bit rate);
  * used for the small decoder stages where 16-bit operand rounding would dominate the logit error. */
-enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2 };
+/* LA_F16X2 (la_layernorm, la_add_cast, la_attn_small, la_mask_embed outputs only): the "16-bit" buffers hold TWO fp16 planes per row,
+ * [hi (E) | lo (E)] with hi = rn(v), lo = rn(v - hi) (row stride 2 E).  Fed to la_gemm as A with a_kmod = 2 K against weights packed as
+ * [W_hi | W_hi | W_lo] (K' = 3 K) the product carries ~21 mantissa bits through the fast MFMA: the decoder-side (P, hw, D) stream at
+ * fp32-level accuracy for 3 fp16 passes instead of the 16 passes an exact-fp32 MFMA costs. */
+enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2, LA_F16X2 = 3 };
 enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2 };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
 enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3, LA_MAP_WINDOW_PART = 4 };

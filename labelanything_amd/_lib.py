@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libla_hip.so")
 
-LA_F16, LA_BF16, LA_F32 = 0, 1, 2
+LA_F16, LA_BF16, LA_F32, LA_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 MAP_NONE, MAP_GROUP, MAP_WINDOW_MERGE, MAP_CONVT2X2, MAP_WINDOW_PART = 0, 1, 2, 3, 4
 ATTN_PLAIN, ATTN_RELPOS, ATTN_RELPOS_WIN16 = 0, 1, 2
@@ -181,9 +181,15 @@ def mask_embed(masks, flags, p: int, c: int, hm: int, g: int, d: int, wlist, sup
 
 
 def attn_small(q, k, v, b: int, nq: int, nk: int, heads: int, hd: int, *, out16=None, out32=None, dt: int = LA_F16) -> None:
-    """q/k/v: fp32 2-D views [rows, ld] (row stride = ld, head h at column h*hd)."""
+    """q/k/v: fp32 2-D views [rows, ld] (row stride = ld, head h at column h*hd).  dt = LA_F16X2: out16 is [rows, 2 * heads * hd]
+    ([hi | lo] planes)."""
     _dev(q)
     o = out16 if out16 is not None else out32
+    if dt == LA_F16X2:
+        _check(lib().la_attn_small(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), _ptr(v), C.c_int(v.stride(0)),
+                                   C.c_int(b), C.c_int(nq), C.c_int(nk), C.c_int(heads), C.c_int(hd), _ptr(out16), None,
+                                   C.c_int(heads * hd), C.c_int(dt), _stream()), "la_attn_small")
+        return
     _check(lib().la_attn_small(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), _ptr(v), C.c_int(v.stride(0)),
                                C.c_int(b), C.c_int(nq), C.c_int(nk), C.c_int(heads), C.c_int(hd), _ptr(out16), _ptr(out32),
                                C.c_int(o.stride(0)), C.c_int(dt), _stream()), "la_attn_small")

@@ -67,6 +67,7 @@ struct MaskEmbedArgs {
   float* src32;
   void* src16;
   void* srcpe16;
+  int split;            // LA_F16X2: [hi | lo] plane pairs
 };
 
 constexpr int ME_PIX = 32;
@@ -197,8 +198,14 @@ __global__ __launch_bounds__(256) void mask_embed_kernel(MaskEmbedArgs a) {
     if (a.class_enc) v += a.class_enc[c * a.D + d];
     const size_t o = ((size_t)p * hw + pix) * a.D + d;
     a.src32[o] = v;
-    if (s16) s16[o] = (T)v;
-    if (spe16) spe16[o] = (T)(v + a.pe[(size_t)pix * a.D + d]);
+    if (a.split) {
+      const size_t r2 = ((size_t)p * hw + pix) * 2 * a.D;
+      if (s16) store_split<T>(s16 + r2, a.D, d, v);
+      if (spe16) store_split<T>(spe16 + r2, a.D, d, v + a.pe[(size_t)pix * a.D + d]);
+    } else {
+      if (s16) s16[o] = (T)v;
+      if (spe16) spe16[o] = (T)(v + a.pe[(size_t)pix * a.D + d]);
+    }
   }
 }
 
@@ -213,6 +220,7 @@ struct SmallAttnArgs {
   float scale;
   void* out16;
   float* out32;
+  int split;            // LA_F16X2: out16 rows are [hi | lo] plane pairs of ldo halves each (row stride 2 ldo)
 };
 
 // few keys, many queries: one thread per (b, q, head), two passes over the keys (max, then exp-sum).
@@ -257,7 +265,11 @@ __global__ __launch_bounds__(256) void attn_fewkeys_kernel(SmallAttnArgs a) {
 #pragma unroll
       for (int d = 0; d < HDIM; ++d) a.out32[bq * a.ldo + h * HDIM + d] = acc[d] * inv;
     }
-    if (a.out16) {
+    if (a.out16 && a.split) {
+      T* op = reinterpret_cast<T*>(a.out16) + bq * 2 * a.ldo;
+#pragma unroll
+      for (int d = 0; d < HDIM; ++d) store_split<T>(op, a.ldo, h * HDIM + d, acc[d] * inv);
+    } else if (a.out16) {
       T* op = reinterpret_cast<T*>(a.out16) + bq * a.ldo + h * HDIM;
 #pragma unroll
       for (int d = 0; d < HDIM; d += 2) store2<T>(op + d, acc[d] * inv, acc[d + 1] * inv);
@@ -331,7 +343,8 @@ __global__ __launch_bounds__(256) void attn_manykeys_kernel(SmallAttnArgs a) {
     }
     const float o = at / lt;
     if (a.out32) a.out32[(size_t)bq * a.ldo + h * HDIM + tid] = o;
-    if (a.out16) reinterpret_cast<T*>(a.out16)[(size_t)bq * a.ldo + h * HDIM + tid] = (T)o;
+    if (a.out16 && a.split) store_split<T>(reinterpret_cast<T*>(a.out16) + (size_t)bq * 2 * a.ldo, a.ldo, h * HDIM + tid, o);
+    else if (a.out16) reinterpret_cast<T*>(a.out16)[(size_t)bq * a.ldo + h * HDIM + tid] = (T)o;
   }
 }
 
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(256) void classify_kernel(const float* __restrict__
 // out = x (+ y[row % ymod]) as fp32 and/or 16 bit; contiguous [rows, D]
 template <typename T>
 __global__ void add_cast_kernel(const float* __restrict__ x, const float* __restrict__ y, int ymod, long rows, int D, float* __restrict__ out32,
-                                T* __restrict__ out16) {
+                                T* __restrict__ out16, int split) {
   const long total = rows * D;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float v = x[i];
@@ -428,7 +441,8 @@ __global__ void add_cast_kernel(const float* __restrict__ x, const float* __rest
       v += y[(ymod ? r % ymod : r) * D + (i % D)];
     }
     if (out32) out32[i] = v;
-    if (out16) out16[i] = (T)v;
+    if (out16 && split) store_split<T>(out16 + (i / D) * 2 * D, D, (int)(i % D), v);
+    else if (out16) out16[i] = (T)v;
   }
 }
 
@@ -504,9 +518,10 @@ extern "C" int la_mask_embed(const float* masks, const int* flags, int P, int C,
   a.w0 = w[0]; a.b0 = w[1]; a.g1 = w[2]; a.be1 = w[3]; a.w3 = w[4]; a.b3 = w[5]; a.g4 = w[6]; a.be4 = w[7]; a.w6 = w[8]; a.b6 = w[9];
   a.not_a_mask = w[10]; a.no_mask = w[11];
   a.support = support; a.class_enc = class_enc; a.pe = pe; a.src32 = src32; a.src16 = src16; a.srcpe16 = srcpe16;
+  a.split = dt == LA_F16X2 ? 1 : 0;
   const int hw = g * g;
   dim3 grid((hw + ME_PIX - 1) / ME_PIX, P);
-  if (dt == LA_F16) hipLaunchKernelGGL(mask_embed_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (dt == LA_F16 || dt == LA_F16X2) hipLaunchKernelGGL(mask_embed_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (dt == LA_BF16) hipLaunchKernelGGL(mask_embed_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else if (dt == LA_F32) hipLaunchKernelGGL(mask_embed_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else LA_CHECK_ARG(false, "la_mask_embed: bad dtype %d", dt);
@@ -542,7 +557,7 @@ extern "C" int la_attn_small(const float* q, int ldq, const float* k, int ldk, c
   LA_CHECK_ARG(q && k && v && (out16 || out32), "la_attn_small: null pointer");
   LA_CHECK_ARG(B > 0 && Nq > 0 && Nk > 0 && heads > 0, "la_attn_small: bad shape");
   LA_CHECK_ARG((ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 2) == 0, "la_attn_small: leading dims must be multiples of 4");
-  SmallAttnArgs a{q, k, v, ldq, ldk, ldv, ldo, B, Nq, Nk, heads, 1.0f / sqrtf((float)hd), out16, out32};
+  SmallAttnArgs a{q, k, v, ldq, ldk, ldv, ldo, B, Nq, Nk, heads, 1.0f / sqrtf((float)hd), out16, out32, dt == LA_F16X2 ? 1 : 0};
   int rc = (dt == LA_BF16) ? dispatch_small<bf16_t>(a, hd, (hipStream_t)stream)
            : (dt == LA_F32) ? dispatch_small<float>(a, hd, (hipStream_t)stream) : dispatch_small<f16_t>(a, hd, (hipStream_t)stream);
   LA_CHECK_ARG(rc == 0, "la_attn_small: unsupported head dim %d (4, 8, 16, 32, 64)", hd);
@@ -584,9 +599,9 @@ extern "C" int la_classify(const float* feat, const float* protos, int B, int Np
 extern "C" int la_add_cast(const float* x, const float* y, int ymod, long rows, int D, float* out32, void* out16, int dt, void* stream) {
   LA_CHECK_ARG(x && (out32 || out16) && rows > 0 && D > 0, "la_add_cast: bad arguments");
   const int grid = grid_for(rows * D);
-  if (dt == LA_BF16) hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (bf16_t*)out16);
-  else if (dt == LA_F32) hipLaunchKernelGGL(add_cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (float*)out16);
-  else hipLaunchKernelGGL(add_cast_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (f16_t*)out16);
+  if (dt == LA_BF16) hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (bf16_t*)out16, 0);
+  else if (dt == LA_F32) hipLaunchKernelGGL(add_cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (float*)out16, 0);
+  else hipLaunchKernelGGL(add_cast_kernel<f16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, ymod, rows, D, out32, (f16_t*)out16, dt == LA_F16X2 ? 1 : 0);
   LA_CHECK_LAUNCH("la_add_cast");
   return 0;
 }

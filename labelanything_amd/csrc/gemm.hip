@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256_kernel(const T* __restrict__
 #pragma unroll
     for (int o = 0; o < 1 + NPL; ++o)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dma16s((o ? Wt : A) + kt * BK_, soff[o][i], base + o * OPB + i * 8192);
+      for (int i = 0; i < 2; ++i) dma16s(o ? Wt + kt * BK_ : A + a_koff(e, kt * BK_), soff[o][i], base + o * OPB + i * 8192);
   };
 
   f32x16 acc[4][2];
@@ -1574,8 +1574,8 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   LA_CHECK_ARG((K % kq) == 0 && (lda % kq) == 0 && (ldw % kq) == 0, "la_gemm: K, lda, ldw must be multiples of %d (K=%d lda=%d ldw=%d)", kq, K,
                lda, ldw);
   LA_CHECK_ARG(epi->out32 || epi->out16 || epi->vt, "la_gemm: no output");
-  LA_CHECK_ARG(epi->a_kmod == 0 || (dt != LA_F32 && epi->a_kmod > 0 && (epi->a_kmod % 64) == 0 && (K % epi->a_kmod) == 0 && M > 32),
-               "la_gemm: a_kmod=%d must be a multiple of 64 that divides K=%d (16-bit operands, M > 32)", epi->a_kmod, K);
+  LA_CHECK_ARG(epi->a_kmod == 0 || (dt != LA_F32 && epi->a_kmod > 0 && (epi->a_kmod % 64) == 0 && epi->a_kmod <= K && lda >= epi->a_kmod && M > 32),
+               "la_gemm: a_kmod=%d must be a multiple of 64, <= K=%d and <= lda=%d (16-bit operands, M > 32)", epi->a_kmod, K, lda);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_gemm: bad dtype %d", dt);
   LA_CHECK_ARG(epi->amap == LA_MAP_NONE || (epi->amap == LA_MAP_WINDOW_PART && epi->map == LA_MAP_NONE && dt != LA_F32),
                "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
@@ -1616,8 +1616,8 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     const bool planes2 = epi->a_kmod > 0 && K == 2 * epi->a_kmod;
     // ... and, measured on MI355X (tools/gemm_planes_bench.py), its single-plane form beats the 256 x 128, the 128 x 128 and the older
     // ping-pong kernel on every shape with >= 2 full rounds of 256 x 256 tiles (K = 768: +10-15 %, K = 3072: equal)
-    bool t256 = ((planes2 && tiles_pp >= 128) || (epi->a_kmod == 0 && tiles_pp >= 512)) && (!epi->vt || (epi->vt_col0 % 256) == 0);
-    if (force) t256 = (force[0] == '7') && (planes2 || epi->a_kmod == 0) && (!epi->vt || (epi->vt_col0 % 256) == 0);
+    bool t256 = ((planes2 && tiles_pp >= 128) || (!planes2 && tiles_pp >= 512)) && (!epi->vt || (epi->vt_col0 % 256) == 0);
+    if (force) t256 = (force[0] == '7') && (!epi->vt || (epi->vt_col0 % 256) == 0);
     if (t256) {
       if (planes2) {
         if (dt == LA_F16) la::launch_t256<la::f16_t, 2>(A, lda, W, ldw, M, N, K / 2, *epi, st);

@@ -56,6 +56,20 @@ template <> __device__ __forceinline__ void store4v<float>(float* p, float a, fl
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
+// ---- LA_F16X2 operand rows: two 16-bit planes [hi (E) | lo (E)] per row, hi = rn(v), lo = rn(v - hi) --------------------------------
+// A GEMM that multiplies [A_hi | A_lo | A_hi] by [W_hi | W_hi | W_lo] (la_gemm a_kmod = 2 K over 3 K columns) then carries ~21
+// mantissa bits through the fast MFMA: fp32-level accuracy at 3 of its 16 passes per fp32-MFMA pass.
+template <typename T> __device__ __forceinline__ void store_split(T* row2e, int E, int col, float v) {
+  const T h = (T)v;
+  row2e[col] = h;
+  row2e[E + col] = (T)(v - (float)h);
+}
+template <typename T> __device__ __forceinline__ void store4_split(T* row2e, int E, int col, float a, float b, float c, float d) {
+  const T ha = (T)a, hb = (T)b, hc = (T)c, hd = (T)d;
+  store4v<T>(row2e + col, a, b, c, d);
+  store4v<T>(row2e + E + col, a - (float)ha, b - (float)hb, c - (float)hc, d - (float)hd);
+}
+
 // ---- activations ----------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -23,6 +23,7 @@ struct LnArgs {
   const float* pe;
   int pe_mod;
   int window, H, W;
+  int split;          // LA_F16X2: the 16-bit outputs are [hi | lo] plane pairs (row stride 2 E)
 };
 
 template <typename T>
@@ -96,10 +97,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           o.x = gelu_erf(o.x); o.y = gelu_erf(o.y); o.z = gelu_erf(o.z); o.w = gelu_erf(o.w);
         }
         if (a.out32) reinterpret_cast<float4*>(a.out32 + (size_t)row * a.E)[c] = o;
-        if (o16) store4<T>(o16 + (size_t)drow * a.E + c * 4, o.x, o.y, o.z, o.w);
+        if (o16) {
+          if (a.split) store4_split<T>(o16 + (size_t)drow * 2 * a.E, a.E, c * 4, o.x, o.y, o.z, o.w);
+          else store4<T>(o16 + (size_t)drow * a.E + c * 4, o.x, o.y, o.z, o.w);
+        }
         if (o16pe) {
           const float4 p = pp[c];
-          store4<T>(o16pe + (size_t)drow * a.E + c * 4, o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+          if (a.split) store4_split<T>(o16pe + (size_t)drow * 2 * a.E, a.E, c * 4, o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
+          else store4<T>(o16pe + (size_t)drow * a.E + c * 4, o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
         }
       }
     }
@@ -151,10 +156,10 @@ extern "C" int la_layernorm(const float* x, const float* x2, int ldx, int rows, 
   LA_CHECK_ARG(out32 || out16 || out16_pe, "la_layernorm: no output");
   LA_CHECK_ARG(!out16_pe || pe, "la_layernorm: out16_pe needs pe");
   LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "la_layernorm: bad window geometry");
-  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_layernorm: bad dtype %d", dt);
-  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W};
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32 || dt == LA_F16X2, "la_layernorm: bad dtype %d", dt);
+  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt == LA_F16X2 ? 1 : 0};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dt == LA_F16) la::launch_ln<la::f16_t>(a, st);
+  if (dt == LA_F16 || dt == LA_F16X2) la::launch_ln<la::f16_t>(a, st);
   else if (dt == LA_BF16) la::launch_ln<la::bf16_t>(a, st);
   else la::launch_ln<float>(a, st);
   LA_CHECK_LAUNCH("la_layernorm");

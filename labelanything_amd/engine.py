@@ -89,6 +89,17 @@ class LamEngine:
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
         self.precise = frozenset(resolve_precise(cfg, precise))
+        # decoder_dtype "f16x2": the IMAGE-side GEMM operands of the prompt encoder / mask decoder (the (P, hw, D) stream) are pairs
+        # of fp16 planes [hi | lo] and their weights [W_hi | W_hi | W_lo] (LA_F16X2, la_hip.h): 3 fast-MFMA products instead of the
+        # exact-fp32 MFMA, same accuracy class; the few-row token side stays exact fp32.
+        self.isplit = isinstance(decoder_dtype, str) and decoder_dtype == "f16x2"
+        if isinstance(decoder_dtype, str):
+            if not self.isplit:
+                raise ValueError("decoder_dtype must be a torch dtype, None or 'f16x2'")
+            decoder_dtype = torch.float32
+            # the narrowest image-side GEMM (output_upscaling.3, K = D / 4) needs 2 K % 64 == 0 for the plane-pair operand:
+            # narrower decoders (test geometries) run the exact-fp32 MFMA throughout
+            self.isplit = cfg.embed_dim % 128 == 0
         if not self.precise <= set(PRECISE_GROUPS):
             raise ValueError(f"unknown precise groups {sorted(self.precise - set(PRECISE_GROUPS))}; known: {PRECISE_GROUPS}")
         self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)
@@ -114,6 +125,31 @@ class LamEngine:
 
     def _hd(self, t: Tensor) -> Tensor:
         return t.to(self.ddt).contiguous()
+
+    @staticmethod
+    def _split3(t: Tensor) -> Tensor:
+        """[N, K] fp32 -> [N, 3K] fp16 = [W_hi | W_hi | W_lo] (pairs with A = [A_hi | A_lo], a_kmod = 2K)."""
+        hi = t.to(torch.float16)
+        lo = (t - hi.float()).to(torch.float16)
+        return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+    def ibuf(self, name: str, rows: int, e: int) -> Tensor:
+        """Image-side GEMM operand buffer: [rows, 2e] fp16 plane pairs in split mode, else a decoder-dtype [rows, e] buffer."""
+        if self.isplit:
+            return self.arena.get(name, (rows, 2 * e), torch.float16, False)
+        return self.dbuf(name, (rows, e))
+
+    @property
+    def idti(self) -> int:
+        return L.LA_F16X2 if self.isplit else self.ddti
+
+    def igemm(self, a: Tensor, wkey: str, **kw) -> None:
+        """GEMM with an image-side A operand against decoder weight ``wkey`` (split-plane aware)."""
+        if self.isplit:
+            w = self.p[wkey + "s"]
+            L.gemm(a, w, a_kmod=2 * (w.shape[1] // 3), **kw)
+        else:
+            L.gemm(a, self.p[wkey], **kw)
 
     def _hw(self, key: str, t: Tensor, group: str) -> None:
         """Pack an encoder GEMM weight [N, K]: one 16-bit plane, or [W_hi | W_lo] when its group is precise."""
@@ -170,6 +206,8 @@ class LamEngine:
             p[pre + ".qk.b"] = torch.cat([w[pre + ".q_proj.bias"], w[pre + ".k_proj.bias"]]).contiguous()
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
             p[f"{pre}.{n}.w"] = self._hd(w[f"{pre}.{n}.weight"])
+            if self.isplit:
+                p[f"{pre}.{n}.ws"] = self._split3(w[f"{pre}.{n}.weight"])
 
     def _pack_mlp(self, pre: str) -> None:
         self.p[pre + ".lin1.w"] = self._hd(self.w32[pre + ".lin1.weight"])
@@ -252,6 +290,9 @@ class LamEngine:
         # ConvTranspose2d weight (Cin, Cout, 2, 2) -> GEMM weight [(ky, kx, cout), cin]
         p[md + ".up0.w"] = self._hd(w[md + ".output_upscaling.0.weight"].permute(2, 3, 1, 0).flatten(0, 2))
         p[md + ".up3.w"] = self._hd(w[md + ".output_upscaling.3.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+        if self.isplit:
+            p[md + ".up0.ws"] = self._split3(w[md + ".output_upscaling.0.weight"].permute(2, 3, 1, 0).flatten(0, 2))
+            p[md + ".up3.ws"] = self._split3(w[md + ".output_upscaling.3.weight"].permute(2, 3, 1, 0).flatten(0, 2))
         if cfg.spatial_convs:
             for i in range(cfg.spatial_convs):
                 p[f"{md}.sc{i}.w"] = self._hd(w[f"{md}.spatial_convs.{3 * i}.weight"].permute(0, 2, 3, 1).flatten(1))
@@ -495,8 +536,13 @@ class LamEngine:
     # ------------------------------------------------------------------------------------------------
     # decoder attention building blocks
     # ------------------------------------------------------------------------------------------------
-    def _attn_core(self, q32, k32, v32, groups, nq, nk, internal, tag) -> Tensor:
+    def _attn_core(self, q32, k32, v32, groups, nq, nk, internal, tag, image_side: bool = False) -> Tensor:
+        """image_side: the output feeds an image-side GEMM (rows = groups * hw): plane-pair operand in split mode."""
         heads = self.cfg.dec_heads
+        if image_side:
+            o16 = self.ibuf(tag + ".o16", groups * nq, internal)
+            L.attn_small(q32, k32, v32, groups, nq, nk, heads, internal // heads, out16=o16, dt=self.idti)
+            return o16
         o16 = self.dbuf(tag + ".o16", (groups * nq, internal))
         L.attn_small(q32, k32, v32, groups, nq, nk, heads, internal // heads, out16=o16, dt=self.ddti)
         return o16
@@ -559,8 +605,8 @@ class LamEngine:
             L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
             k = self.f32(tag + ".ik", (ri, di))
             v = self.f32(tag + ".iv", (ri, di))
-            L.gemm(imgpe16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=k)
-            L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
+            self.igemm(imgpe16, ca + ".k_proj.w", bias=w[ca + ".k_proj.bias"], out32=k)
+            self.igemm(img16, ca + ".v_proj.w", bias=w[ca + ".v_proj.bias"], out32=v)
             o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
             L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
             self.dln(tnew, lp + ".norm2", 1e-5, out32=t32, out16=t16)
@@ -572,14 +618,15 @@ class LamEngine:
             # image -> tokens
             ca = lp + ".cross_attn_image_to_token"
             qi = self.f32(tag + ".iq", (ri, di))
-            L.gemm(imgpe16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=qi)
+            self.igemm(imgpe16, ca + ".q_proj.w", bias=w[ca + ".q_proj.bias"], out32=qi)
             kt = self.f32(tag + ".tk", (r, di))
             vtok = self.f32(tag + ".tv", (r, di))
             L.gemm(tq16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=kt)
             L.gemm(t16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=vtok)
-            oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t")
-            L.gemm(oi16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
-            self.dln(img32, lp + ".norm4", 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32, pe_mod=hw)
+            oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t", image_side=True)
+            self.igemm(oi16, ca + ".out_proj.w", bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
+            L.layernorm(img32, w[lp + ".norm4.weight"], w[lp + ".norm4.bias"], 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32,
+                        pe_mod=hw, dt=self.idti)
         if not want_tokens:
             return None, None
         ca = pre + ".final_attn_token_to_image"
@@ -587,8 +634,8 @@ class LamEngine:
         L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
         k = self.f32(tag + ".ik", (ri, di))
         v = self.f32(tag + ".iv", (ri, di))
-        L.gemm(imgpe16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=k)
-        L.gemm(img16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=v)
+        self.igemm(imgpe16, ca + ".k_proj.w", bias=w[ca + ".k_proj.bias"], out32=k)
+        self.igemm(img16, ca + ".v_proj.w", bias=w[ca + ".v_proj.bias"], out32=v)
         o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
         L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
         self.dln(tnew, pre + ".norm_final_attn", 1e-5, out32=t32, out16=t16)
@@ -666,8 +713,8 @@ class LamEngine:
         # dense stream
         pe32 = self.dense_pe(g)
         src32 = self.f32("pe.src32", (pcount * hw, d))
-        src16 = self.dbuf("pe.src16", (pcount * hw, d))
-        srcpe16 = self.dbuf("pe.srcpe16", (pcount * hw, d))
+        src16 = self.ibuf("pe.src16", pcount * hw, d)
+        srcpe16 = self.ibuf("pe.srcpe16", pcount * hw, d)
         if masks is not None:
             mk, mf = masks
             mk = self.h2d(mk, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
@@ -675,10 +722,10 @@ class LamEngine:
                 raise ValueError("prompt masks must be square")
             mf = self.h2d(mf.reshape(pcount), torch.int32).contiguous()
             L.mask_embed(mk, mf, pcount, c, mk.shape[-1], g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16,
-                         srcpe16, self.ddti)
+                         srcpe16, self.idti)
         else:
             L.mask_embed(None, None, pcount, c, 0, g, d, p[pe_ + ".mask_w"], support32, class_enc, pe32, src32, src16, srcpe16,
-                         self.ddti)
+                         self.idti)
         self.two_way(pe_ + ".transformer", sp, pcount, ns, src32, src16, srcpe16, hw, pe32, "pe.tw", want_tokens=False)
         emb = self.f32("pe.emb", (pcount, d))
         L.colmean(src32, pcount, hw, d, emb, self.f32("pe.colmean.part", (pcount, L.COLMEAN_SPLIT, d)))
@@ -708,10 +755,10 @@ class LamEngine:
         c = class_emb.shape[1]
         pe32 = self.dense_pe(g)
         img32 = self.f32("md.img32", (b * hw, d))
-        img16 = self.dbuf("md.img16", (b * hw, d))
-        imgpe16 = self.dbuf("md.imgpe16", (b * hw, d))
-        L.add_cast(query32, out32=img32, out16=img16, dt=self.ddti)
-        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.ddti)
+        img16 = self.ibuf("md.img16", b * hw, d)
+        imgpe16 = self.ibuf("md.imgpe16", b * hw, d)
+        L.add_cast(query32, out32=img32, out16=img16, dt=self.idti)
+        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.idti)
         tok = self.h2d(class_emb, torch.float32).reshape(b * c, d).contiguous()
         t32, t16 = self.two_way(md + ".transformer", tok, b, c, img32, img16, imgpe16, hw, pe32, "md.tw", want_tokens=True)
         # class_mlp (3 x Linear, ReLU between) -> prototypes
@@ -725,17 +772,19 @@ class LamEngine:
         # output_upscaling: ConvT(k2,s2) -> LN2d -> GELU -> ConvT(k2,s2), both as pixel-shuffle GEMMs
         c1 = d // 4
         up1 = self.f32("md.up1", (b * 4 * hw, c1))
-        L.gemm(img16, p[md + ".up0.w"], bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
-        up1h = self.dbuf("md.up1h", (b * 4 * hw, c1))
-        self.dln(up1, md + ".output_upscaling.1", 1e-6, gelu=True, out16=up1h)
+        self.igemm(img16, md + ".up0.w", bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
+        up1h = self.ibuf("md.up1h", b * 4 * hw, c1)
+        L.layernorm(up1, w[md + ".output_upscaling.1.weight"], w[md + ".output_upscaling.1.bias"], 1e-6, gelu=True, out16=up1h, dt=self.idti)
         npix = 16 * hw
         feat32 = self.f32("md.feat32", (b * npix, cf))
-        feat16 = self.dbuf("md.feat16", (b * npix, cf))
-        L.gemm(up1h, p[md + ".up3.w"], bias=w[md + ".output_upscaling.3.bias"], out32=feat32, out16=feat16, map=L.MAP_CONVT2X2,
-               p=(2 * g, 2 * g, cf, 0, 0))
+        feat16 = self.f32("md.feat16f", (b * npix, cf)) if self.isplit else self.dbuf("md.feat16", (b * npix, cf))
+        self.igemm(up1h, md + ".up3.w", bias=w[md + ".output_upscaling.3.bias"], out32=feat32, out16=None if self.isplit else feat16,
+                   map=L.MAP_CONVT2X2, p=(2 * g, 2 * g, cf, 0, 0))
         if cfg.spatial_convs:
             implicit = self.ddt == torch.float32 and cf % 32 == 0
             col = None if implicit else self.dbuf("md.col", (b * npix, 9 * cf))
+            if self.isplit:       # the up3 GEMM cannot emit a second fp32 copy in split mode: the first conv reads its fp32 output
+                L.add_cast(feat32, out32=feat16, dt=L.LA_F32)
             for i in range(cfg.spatial_convs):
                 if implicit:      # fp32 implicit GEMM: no im2col buffer (feat16 IS fp32 here)
                     nxt = self.f32("md.feat32b" if i % 2 == 0 else "md.feat32", (b * npix, cf))

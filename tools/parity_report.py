@@ -17,6 +17,8 @@ def main():
                 (torch.float16, None, PRECISE_DEFAULT), (torch.bfloat16, torch.float32, PRECISE_DEFAULT)]
     if "--quick" in sys.argv:
         variants = variants[:2]
+    if "--decoder" in sys.argv:     # exact-fp32 MFMA decoder against the fp16 plane-pair (3-product) image side
+        variants = [(torch.float16, torch.float32, "auto"), (torch.float16, "f16x2", "auto")]
     if "--groups" in sys.argv:      # the default against leaner group sets (which planes are worth their MFMA passes)
         variants = [(torch.float16, torch.float32, g) for g in (PRECISE_FULL, PRECISE_WIDE, ("patch", "qkv", "neck"), ("patch", "qkv", "lin2", "neck"))]
     for dt, ddt, precise in variants:
@@ -63,7 +65,7 @@ def main():
             n_diff, n_real = argmax_disagreement(out["logits"], ref_am, ref_logits, margin_rel=2e-3)
             errs["argmax_diff_outside_2e-3_margin"] = n_real
             ptag = "auto=" + "+".join(lam.precise) if precise == "auto" else ("none" if not precise else "+".join(precise))
-            print(f"[{name} enc={str(dt)[6:]} dec={str(ddt)[6:] if ddt else 'same'} precise={ptag}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
+            print(f"[{name} enc={str(dt)[6:]} dec={(ddt if isinstance(ddt, str) else str(ddt)[6:]) if ddt else 'same'} precise={ptag}] {t1:.2f}s  " + "  ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in errs.items()), flush=True)
             torch.cuda.empty_cache()
 
 
