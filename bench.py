@@ -91,7 +91,7 @@ class KernelTimer:
         from labelanything_amd import _lib as L
         self.L = L
         self.saved = {}
-        names = ["gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
+        names = ["twoway_t2i", "twoway_i2t", "gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
                  "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
                  "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step"]

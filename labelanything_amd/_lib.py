@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t",
 ]
 
 
@@ -371,3 +371,24 @@ def row_broadcast(src, groups: int, rep: int, d: int, scale: float, out) -> None
     _f32c(src, out)
     _check(lib().la_row_broadcast(_ptr(src), C.c_long(groups), C.c_int(rep), C.c_int(d), C.c_float(scale), _ptr(out), _stream()),
            "la_row_broadcast")
+
+
+# ---- fused image-side kernels of the two-way transformer (csrc/twoway.hip) -----------------------------------------------------
+def twoway_t2i(img, wk, wv, pek, bv, q, groups: int, hw: int, nt: int, heads: int, part, out) -> None:
+    """wk / wv: (hi, lo) fp16 plane pairs [128, D]; pek = pe @ Wk.T + bk [hw, 128]."""
+    _f32c(img, pek, bv, q, part, out)
+    d = img.shape[1]
+    need = groups * ((hw + 127) // 128) * 4 * nt * 8 * 18
+    if part.numel() < need:
+        raise ValueError(f"twoway_t2i: scratch too small ({part.numel()} < {need})")
+    _check(lib().la_twoway_t2i(_ptr(img), _ptr(wk[0]), _ptr(wk[1]), _ptr(wv[0]), _ptr(wv[1]), _ptr(pek), _ptr(bv), _ptr(q),
+                               C.c_int(groups), C.c_int(hw), C.c_int(nt), C.c_int(d), C.c_int(heads), _ptr(part), _ptr(out), _stream()),
+           "la_twoway_t2i")
+
+
+def twoway_i2t(img, wq, peq, k, v, wo, bo, gamma, beta, eps: float, groups: int, hw: int, nt: int, heads: int) -> None:
+    """peq = pe @ Wq.T + bq [hw, 128]; img is updated in place."""
+    _f32c(img, peq, k, v, bo, gamma, beta)
+    _check(lib().la_twoway_i2t(_ptr(img), _ptr(wq[0]), _ptr(wq[1]), _ptr(peq), _ptr(k), _ptr(v), _ptr(wo[0]), _ptr(wo[1]), _ptr(bo),
+                               _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(groups), C.c_int(hw), C.c_int(nt), C.c_int(img.shape[1]),
+                               C.c_int(heads), _stream()), "la_twoway_i2t")

@@ -96,6 +96,28 @@ __device__ __forceinline__ float wave_max(float v, int width = 64) {
   return v;
 }
 
+// ---- DPP reductions -------------------------------------------------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS-crossbar round trip, ~200 cycles when the next step depends on it).  A wave that
+// runs alone on its SIMD with a serial chain of them (the fused two-way kernels: 1 workgroup per CU) is latency-bound on exactly
+// that; the DPP forms below are plain VALU moves.  row16_sum: every lane ends up with the sum of its 16-lane row (xor 1, xor 2 as
+// quad permutes, then rotations by 4 and 8 inside the row).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);      // row_ror:4
+  v += dpp_mov<0x128>(v);      // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = row16_sum(v);
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
 // ---- LDS tile swizzle -----------------------------------------------------------------------
 // Tiles are [rows][64 halfs] = 128 B per row = 8 chunks of 16 B.  ds_read_b128 is serviced in 16-lane
 // groups over a 256-B bank row (MI355X_MICROARCH LDS table); XOR-ing the chunk with (row>>1)&7 makes

@@ -69,13 +69,15 @@ PRECISE_DEFAULT = "auto"
 PRECISE_GROUPS = ("patch", "qkv", "proj", "lin1", "lin2", "neck")
 
 
-def resolve_precise(cfg: LamConfig, precise) -> tuple:
-    """'auto' -> the measured default for this encoder width; None / () -> no split precision; else the given groups."""
+def resolve_precise(cfg: LamConfig, precise, dtype: torch.dtype = torch.float16) -> tuple:
+    """'auto' -> the measured default for this encoder width and operand type; None / () -> no split precision; else the given
+    groups.  bf16 operands (8 mantissa bits) always take the full set: its activations alone cost more than fp16's weights."""
     if isinstance(precise, str):
         if precise != "auto":
             raise ValueError("precise must be 'auto', None or a sequence of group names")
         spec = cfg.encoder_spec
-        return PRECISE_WIDE if (spec is not None and spec.dim >= 512) else PRECISE_FULL
+        wide = spec is not None and spec.dim >= 512 and dtype == torch.float16
+        return PRECISE_WIDE if wide else PRECISE_FULL
     return tuple(precise or ())
 
 
@@ -88,7 +90,7 @@ class LamEngine:
         that run in split precision (see PRECISE_DEFAULT); () = every encoder GEMM with plain 16-bit operands."""
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
-        self.precise = frozenset(resolve_precise(cfg, precise))
+        self.precise = frozenset(resolve_precise(cfg, precise, dtype))
         # decoder_dtype "f16x2": the IMAGE-side GEMM operands of the prompt encoder / mask decoder (the (P, hw, D) stream) are pairs
         # of fp16 planes [hi | lo] and their weights [W_hi | W_hi | W_lo] (LA_F16X2, la_hip.h): 3 fast-MFMA products instead of the
         # exact-fp32 MFMA, same accuracy class; the few-row token side stays exact fp32.
@@ -103,6 +105,11 @@ class LamEngine:
         if not self.precise <= set(PRECISE_GROUPS):
             raise ValueError(f"unknown precise groups {sorted(self.precise - set(PRECISE_GROUPS))}; known: {PRECISE_GROUPS}")
         self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)
+        # the image side of the two-way transformers runs in the fused kernels (one read / one read + write of the stream per
+        # attention, csrc/twoway.hip) for the published decoder geometry; LA_FUSE_TWOWAY=0 keeps the GEMM + attention + norm chain
+        import os as _os
+        self.fuse_twoway = (cfg.embed_dim == 256 and cfg.dec_heads == 8 and decoder_dtype == torch.float32
+                            and _os.environ.get("LA_FUSE_TWOWAY", "1") != "0")
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
         L.lib()  # fail loudly if the HIP extension is missing
@@ -114,6 +121,7 @@ class LamEngine:
         self.w32: Dict[str, Tensor] = {k: v.detach().to(device=device, dtype=torch.float32).contiguous() for k, v in weights.items()}
         self.p: Dict[str, Tensor] = {}
         self._pe_cache: Dict[int, Tensor] = {}
+        self._pe_tables: Dict[tuple, Tensor] = {}
         self._hfpos_cache: Dict[int, Tensor] = {}
         self._pack()
 
@@ -208,6 +216,9 @@ class LamEngine:
             p[f"{pre}.{n}.w"] = self._hd(w[f"{pre}.{n}.weight"])
             if self.isplit:
                 p[f"{pre}.{n}.ws"] = self._split3(w[f"{pre}.{n}.weight"])
+            if self.fuse_twoway and (".cross_attn_" in pre or pre.endswith("final_attn_token_to_image")):
+                hi = w[f"{pre}.{n}.weight"].to(torch.float16).contiguous()       # fp16 plane pair of the fused kernels (csrc/twoway.hip)
+                p[f"{pre}.{n}.planes"] = (hi, (w[f"{pre}.{n}.weight"] - hi.float()).to(torch.float16).contiguous())
 
     def _pack_mlp(self, pre: str) -> None:
         self.p[pre + ".lin1.w"] = self._hd(self.w32[pre + ".lin1.weight"])
@@ -568,15 +579,48 @@ class LamEngine:
         self.dln(z, pre + ".norm", 1e-5, out32=z)
         return z
 
-    def two_way(self, pre: str, tok32: Tensor, groups: int, nt: int, img32: Tensor, img16: Tensor, imgpe16: Tensor, hw: int,
+    def fused_ok(self, nt: int) -> bool:
+        return self.fuse_twoway and nt <= 32
+
+    def pe_table(self, proj: str, pe32: Tensor) -> Tensor:
+        """pe W^T + b of one image-side projection, [hw, internal] fp32: the positional encoding's share of (x + pe) W^T + b is a constant
+        of (weights, grid), computed once per engine and grid (exact-fp32 MFMA) and added inside the fused two-way kernels."""
+        key = (proj, pe32.shape[0])
+        t = self._pe_tables.get(key)
+        if t is None:
+            t = torch.empty(pe32.shape[0], self.w32[proj + ".weight"].shape[0], device=self.dev)
+            L.gemm(pe32, self.w32[proj + ".weight"], bias=self.w32[proj + ".bias"], out32=t)
+            self._pe_tables[key] = t
+        return t
+
+    def _t2i(self, ca: str, q: Tensor, img32: Tensor, pe32: Tensor, img16, imgpe16, groups: int, nt: int, hw: int, tag: str) -> Tensor:
+        """Attention output (before out_proj) of the tokens over the image side; fused: K / V are never materialised."""
+        w, p = self.w32, self.p
+        di = self.cfg.embed_dim // 2
+        if self.fused_ok(nt):
+            o = self.f32(tag + ".t2i.o", (groups * nt, di))
+            part = self.f32(tag + ".t2i.part", (groups * ((hw + 127) // 128) * 4 * nt * 8 * 18,))
+            L.twoway_t2i(img32, p[ca + ".k_proj.planes"], p[ca + ".v_proj.planes"], self.pe_table(ca + ".k_proj", pe32), w[ca + ".v_proj.bias"], q,
+                         groups, hw, nt, self.cfg.dec_heads, part, o)
+            return o
+        ri = groups * hw
+        k = self.f32(tag + ".ik", (ri, di))
+        v = self.f32(tag + ".iv", (ri, di))
+        self.igemm(imgpe16, ca + ".k_proj.w", bias=w[ca + ".k_proj.bias"], out32=k)
+        self.igemm(img16, ca + ".v_proj.w", bias=w[ca + ".v_proj.bias"], out32=v)
+        return self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
+
+    def two_way(self, pre: str, tok32: Tensor, groups: int, nt: int, img32: Tensor, img16, imgpe16, hw: int,
                 pe32: Tensor, tag: str, want_tokens: bool):
         """TwoWayTransformer (transformer.py:206-329).  tok32 [groups*nt, D] fp32 (also the token PE); image side
-        [groups*hw, D] as fp32 stream + 16-bit copies (x and x+pe), updated in place.  Returns (tokens32, tokens16)."""
+        [groups*hw, D] as fp32 stream, updated in place (+ its GEMM-operand copies x and x+pe when the unfused chain runs:
+        ``fused_ok(nt)`` false).  Returns (tokens32, tokens16)."""
         w, p, cfg = self.w32, self.p, self.cfg
         d = cfg.embed_dim
         di = d // 2
         r = groups * nt
         ri = groups * hw
+        fused = self.fused_ok(nt)
         tpe = tok32
         t32 = self.f32(tag + ".t32", (r, d))
         t16 = self.dbuf(tag + ".t16", (r, d))
@@ -603,11 +647,7 @@ class LamEngine:
             ca = lp + ".cross_attn_token_to_image"
             q = self.f32(tag + ".tq", (r, di))
             L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
-            k = self.f32(tag + ".ik", (ri, di))
-            v = self.f32(tag + ".iv", (ri, di))
-            self.igemm(imgpe16, ca + ".k_proj.w", bias=w[ca + ".k_proj.bias"], out32=k)
-            self.igemm(img16, ca + ".v_proj.w", bias=w[ca + ".v_proj.bias"], out32=v)
-            o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
+            o16 = self._t2i(ca, q, img32, pe32, img16, imgpe16, groups, nt, hw, tag)
             L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
             self.dln(tnew, lp + ".norm2", 1e-5, out32=t32, out16=t16)
             # MLP (ReLU)
@@ -617,26 +657,26 @@ class LamEngine:
             self.dln(tnew, lp + ".norm3", 1e-5, out32=t32, out16=t16, out16_pe=tq16, pe=tpe, pe_mod=0)
             # image -> tokens
             ca = lp + ".cross_attn_image_to_token"
-            qi = self.f32(tag + ".iq", (ri, di))
-            self.igemm(imgpe16, ca + ".q_proj.w", bias=w[ca + ".q_proj.bias"], out32=qi)
             kt = self.f32(tag + ".tk", (r, di))
             vtok = self.f32(tag + ".tv", (r, di))
             L.gemm(tq16, p[ca + ".k_proj.w"], bias=w[ca + ".k_proj.bias"], out32=kt)
             L.gemm(t16, p[ca + ".v_proj.w"], bias=w[ca + ".v_proj.bias"], out32=vtok)
-            oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t", image_side=True)
-            self.igemm(oi16, ca + ".out_proj.w", bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
-            L.layernorm(img32, w[lp + ".norm4.weight"], w[lp + ".norm4.bias"], 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32,
-                        pe_mod=hw, dt=self.idti)
+            if fused:       # q_proj + attention + out_proj + residual + norm4: one read and one write of the stream
+                L.twoway_i2t(img32, p[ca + ".q_proj.planes"], self.pe_table(ca + ".q_proj", pe32), kt, vtok, p[ca + ".out_proj.planes"],
+                             w[ca + ".out_proj.bias"], w[lp + ".norm4.weight"], w[lp + ".norm4.bias"], 1e-5, groups, hw, nt, cfg.dec_heads)
+            else:
+                qi = self.f32(tag + ".iq", (ri, di))
+                self.igemm(imgpe16, ca + ".q_proj.w", bias=w[ca + ".q_proj.bias"], out32=qi)
+                oi16 = self._attn_core(qi, kt, vtok, groups, hw, nt, di, tag + ".i2t", image_side=True)
+                self.igemm(oi16, ca + ".out_proj.w", bias=w[ca + ".out_proj.bias"], res=img32, out32=img32)
+                L.layernorm(img32, w[lp + ".norm4.weight"], w[lp + ".norm4.bias"], 1e-5, out32=img32, out16=img16, out16_pe=imgpe16, pe=pe32,
+                            pe_mod=hw, dt=self.idti)
         if not want_tokens:
             return None, None
         ca = pre + ".final_attn_token_to_image"
         q = self.f32(tag + ".tq", (r, di))
         L.gemm(tq16, p[ca + ".q_proj.w"], bias=w[ca + ".q_proj.bias"], out32=q)
-        k = self.f32(tag + ".ik", (ri, di))
-        v = self.f32(tag + ".iv", (ri, di))
-        self.igemm(imgpe16, ca + ".k_proj.w", bias=w[ca + ".k_proj.bias"], out32=k)
-        self.igemm(img16, ca + ".v_proj.w", bias=w[ca + ".v_proj.bias"], out32=v)
-        o16 = self._attn_core(q, k, v, groups, nt, hw, di, tag + ".t2i")
+        o16 = self._t2i(ca, q, img32, pe32, img16, imgpe16, groups, nt, hw, tag)
         L.gemm(o16, p[ca + ".out_proj.w"], bias=w[ca + ".out_proj.bias"], res=t32, out32=tnew)
         self.dln(tnew, pre + ".norm_final_attn", 1e-5, out32=t32, out16=t16)
         return t32, t16
@@ -713,8 +753,9 @@ class LamEngine:
         # dense stream
         pe32 = self.dense_pe(g)
         src32 = self.f32("pe.src32", (pcount * hw, d))
-        src16 = self.ibuf("pe.src16", pcount * hw, d)
-        srcpe16 = self.ibuf("pe.srcpe16", pcount * hw, d)
+        fused = self.fused_ok(ns)           # fused two-way kernels read the fp32 stream itself: no GEMM-operand copies
+        src16 = None if fused else self.ibuf("pe.src16", pcount * hw, d)
+        srcpe16 = None if fused else self.ibuf("pe.srcpe16", pcount * hw, d)
         if masks is not None:
             mk, mf = masks
             mk = self.h2d(mk, torch.float32).reshape(pcount, mk.shape[-2], mk.shape[-1]).contiguous()
@@ -755,10 +796,15 @@ class LamEngine:
         c = class_emb.shape[1]
         pe32 = self.dense_pe(g)
         img32 = self.f32("md.img32", (b * hw, d))
-        img16 = self.ibuf("md.img16", b * hw, d)
-        imgpe16 = self.ibuf("md.imgpe16", b * hw, d)
-        L.add_cast(query32, out32=img32, out16=img16, dt=self.idti)
-        L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.idti)
+        fused = self.fused_ok(c)
+        img16 = imgpe16 = None
+        if fused:
+            L.add_cast(query32, out32=img32, dt=L.LA_F32)
+        else:
+            img16 = self.ibuf("md.img16", b * hw, d)
+            imgpe16 = self.ibuf("md.imgpe16", b * hw, d)
+            L.add_cast(query32, out32=img32, out16=img16, dt=self.idti)
+            L.add_cast(query32, pe32, hw, out16=imgpe16, dt=self.idti)
         tok = self.h2d(class_emb, torch.float32).reshape(b * c, d).contiguous()
         t32, t16 = self.two_way(md + ".transformer", tok, b, c, img32, img16, imgpe16, hw, pe32, "md.tw", want_tokens=True)
         # class_mlp (3 x Linear, ReLU between) -> prototypes
@@ -772,7 +818,10 @@ class LamEngine:
         # output_upscaling: ConvT(k2,s2) -> LN2d -> GELU -> ConvT(k2,s2), both as pixel-shuffle GEMMs
         c1 = d // 4
         up1 = self.f32("md.up1", (b * 4 * hw, c1))
-        self.igemm(img16, md + ".up0.w", bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
+        if fused:       # the stream itself is the (fp32) operand: there is no separate copy to read
+            L.gemm(img32, p[md + ".up0.w"], bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
+        else:
+            self.igemm(img16, md + ".up0.w", bias=w[md + ".output_upscaling.0.bias"], out32=up1, map=L.MAP_CONVT2X2, p=(g, g, c1, 0, 0))
         up1h = self.ibuf("md.up1h", b * 4 * hw, c1)
         L.layernorm(up1, w[md + ".output_upscaling.1.weight"], w[md + ".output_upscaling.1.bias"], 1e-6, gelu=True, out16=up1h, dt=self.idti)
         npix = 16 * hw

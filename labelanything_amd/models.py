@@ -86,7 +86,7 @@ class Lam(nn.Module):
         self.custom_preprocess = cfg.custom_preprocess
         self.compute_dtype = compute_dtype
         self.decoder_dtype = decoder_dtype
-        self.precise = resolve_precise(cfg, precise)      # encoder GEMM groups in split precision ('auto': engine.PRECISE_*)
+        self.precise = resolve_precise(cfg, precise, compute_dtype)      # encoder GEMM groups in split precision ('auto': engine.PRECISE_*)
         self.class_embeddings = None
         sd = init_state_dict(cfg, 0 if seed is None else seed)
         for k, v in sd.items():

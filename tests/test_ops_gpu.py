@@ -520,3 +520,46 @@ def test_gemm_split_precision_weights(L, dt, mnk):
     assert e1 > 4 * e2                                    # and the single plane really is the coarser one
     with pytest.raises(RuntimeError, match="a_kmod"):
         L.gemm(a, w2, out32=o32, a_kmod=k + 8)
+
+
+def _planes(w):
+    hi = w.to(torch.float16)
+    return hi.contiguous(), (w - hi.float()).to(torch.float16).contiguous()
+
+
+@pytest.mark.parametrize("g,hw,nt", [(3, 900, 5), (2, 4096, 1), (1, 128, 11), (5, 200, 32)])
+def test_fused_twoway_image_side_kernels(L, g, hw, nt):
+    """la_twoway_t2i / la_twoway_i2t (D = 256, 8 heads) against the same mathematics in torch fp32: k / v / q projections from the
+    (groups, hw, D) stream, softmax attention against / over a handful of tokens, out_proj + residual + LayerNorm."""
+    d, di, heads, hd = 256, 128, 8, 16
+    x = rnd(g * hw, d, seed=31)
+    pe = rnd(hw, d, seed=32)
+    wk, wv, wq = (rnd(di, d, seed=33 + i) / 16 for i in range(3))
+    wo = rnd(d, di, seed=36) / 11
+    bk, bv, bq, bo = rnd(di, seed=37), rnd(di, seed=38), rnd(di, seed=39), rnd(d, seed=40)
+    gamma, beta = 1 + 0.1 * rnd(d, seed=41), 0.1 * rnd(d, seed=42)
+    qt, kt, vt = rnd(g * nt, di, seed=43), rnd(g * nt, di, seed=44), rnd(g * nt, di, seed=45)
+    xp = (x.view(g, hw, d) + pe).reshape(g * hw, d)
+
+    def heads_of(t, n):
+        return t.view(g, n, heads, hd).transpose(1, 2)
+    # tokens -> image
+    kk, vv = xp @ wk.t() + bk, x @ wv.t() + bv
+    att = torch.softmax(heads_of(qt, nt) @ heads_of(kk, hw).transpose(-1, -2) / 4.0, dim=-1) @ heads_of(vv, hw)
+    ref_t2i = att.transpose(1, 2).reshape(g * nt, di)
+    part = torch.empty(g * ((hw + 127) // 128) * 4 * nt * 8 * 18, device="cuda")
+    out = torch.empty(g * nt, di, device="cuda")
+    L.twoway_t2i(x, _planes(wk), _planes(wv), (pe @ wk.t() + bk).contiguous(), bv, qt, g, hw, nt, heads, part, out)
+    # image -> tokens, in place
+    qq = xp @ wq.t() + bq
+    o = torch.softmax(heads_of(qq, hw) @ heads_of(kt, nt).transpose(-1, -2) / 4.0, dim=-1) @ heads_of(vt, nt)
+    y = o.transpose(1, 2).reshape(g * hw, di) @ wo.t() + bo + x
+    ref_i2t = F.layer_norm(y, (d,), gamma, beta, 1e-5)
+    img = x.clone()
+    peq = (pe @ wq.t() + bq).contiguous()
+    L.twoway_i2t(img, _planes(wq), peq, kt, vt, _planes(wo), bo, gamma, beta, 1e-5, g, hw, nt, heads)
+    torch.cuda.synchronize()
+    assert rel_err(out, ref_t2i) < 2e-5
+    assert rel_err(img, ref_i2t) < 2e-5
+    with pytest.raises(RuntimeError, match="nt="):
+        L.twoway_i2t(img, _planes(wq), peq, rnd(g * 40, di), rnd(g * 40, di), _planes(wo), bo, gamma, beta, 1e-5, g, hw, 40, heads)
