@@ -127,6 +127,8 @@ class KernelTimer:
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
+                if _n == "attn_fwd" and self.by_shape:
+                    tag = f"attn_fwd[{a[5]}x{a[6]}x{a[7]}]"
                 self.records.append((tag, flops, s, e, nbytes, issued if _n in ("gemm", "gemm_tn") else flops))
             setattr(L, n, wrapped)
         return self
@@ -297,14 +299,14 @@ def main():
             with KernelTimer(by_shape=True) as kt2:
                 lam(batch)
             for n, v in sorted(kt2.summary().items(), key=lambda kv: -kv[1][1]):
-                if n.startswith("gemm"):
+                if n.startswith("gemm") or n.startswith("attn_fwd"):
                     print(f"{n:44s} x{v[0]:3d}  {v[1]*1e3:8.3f} ms  {v[2]/max(v[1],1e-12)/1e12:7.1f} TF/s", file=sys.stderr)
         g = agg.get("gemm")
         tot = sum(v[1] for v in agg.values())
         kernels = {n: {"launches": v[0], "ms": round(v[1] * 1e3, 3)} for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         if g:
             ach = g[2] / g[1] / 1e12
-            roof = {"kernel": "la_gemm (gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel)", "bound": "mfma",
+            roof = {"kernel": "la_gemm (gemm_t256_kernel / gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(a.workload, (lam_fwd if train else lam).precise),
                     "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),

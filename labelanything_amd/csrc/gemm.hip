@@ -1244,6 +1244,346 @@ __global__ __launch_bounds__(512, 2) void gemm_t256_kernel(const T* __restrict__
   epilogue_t256<T, EPI>(smem, acc, grp, wi * 64, m0, n0, M, N, e, tid);
 }
 
+// =================================================================================================================
+// v8 "t256p": the same 256 x 256 x 32 main loop as gemm_t256_kernel, PERSISTENT: one workgroup per CU walks its tiles and
+// the k-step stream never stops at a tile seam -
+//   * the last NST - 1 L intervals of a tile issue the first NST - 1 k-steps of the NEXT tile, so the next main loop
+//     starts on resident stages (no prologue bubble, no relaunch, and the finished tile's stores drain behind it instead
+//     of holding the CU until the workgroup may retire);
+//   * the epilogue never touches the ring and has no workgroup barrier: every wave transposes its own 128 x 64 block
+//     through a PRIVATE 2 KiB slab behind the ring (16 rows x 64 columns of 16-bit output, or 8 rows of fp32) and stores
+//     whole 128-B / 256-B row segments.  It sits at the head of the wave's next L interval, i.e. while the SIMD's other
+//     wave runs its MFMA interval (the two groups stay one barrier out of phase across the seam).
+// vmcnt bookkeeping across a seam: the epilogue's S stores sit between the DMA pieces of next-tile k-steps NST - 2 and
+// NST - 1 in issue order (the counter retires in order and counts stores), so the first NST - 2 waits of the new tile
+// allow S more outstanding operations (only for tiles whose store count is exact: interior rows, not a V^T tile).
+// EPI: 1 bias -> 16-bit (+ V^T columns), 2 bias -> GELU -> 16-bit, 3 bias + fp32 residual -> fp32 [+ 16-bit].
+// =================================================================================================================
+// rare path of the V^T store (a quad that straddles a window row or the end of M): token by token
+template <typename T>
+__device__ __noinline__ void vt_store_slow(T* vt, size_t colbase, size_t bstride, int vt_T, int ws, int row, int M, float v0, float v1, float v2,
+                                           float v3) {
+  const float vv[4] = {v0, v1, v2, v3};
+  for (int j = 0; j < 4; ++j) {
+    const int rj = row + j;
+    if (rj >= M) break;
+    const int bj = rj / vt_T, tj = rj % vt_T;
+    vt[(size_t)bj * bstride + colbase + vt_slot(tj, ws)] = (T)vv[j];
+  }
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_wave(char* slab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M, const LaGemmEpilogue& e,
+                                              int lane) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const float bias0 = e.bias ? e.bias[col0 + fr] : 0.f, bias1 = e.bias ? e.bias[col0 + 32 + fr] : 0.f;
+  if (EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0) {
+    // V^T columns: a lane owns one column, registers 4 g .. 4 g + 3 are 4 consecutive tokens -> one 8-byte store into
+    // vt[(b, head, d)][slot] when the quad stays inside a window row.  (b, t) of the quad's first token is carried along
+    // incrementally (rows advance by 8 per quad): no division in the unrolled body.
+    T* vt = reinterpret_cast<T*>(e.vt);
+    const bool quad_ok = (e.vt_T & 3) == 0;
+    const int ws = e.vt_ws;
+    const int cv0 = col0 + fr - e.vt_col0, cv1 = cv0 + 32;
+    const size_t cb0 = (size_t)((cv0 / e.vt_hd) * e.vt_hd + cv0 % e.vt_hd) * e.vt_Tpad;      // (vhead * hd + vd) * Tpad
+    const size_t cb1 = (size_t)((cv1 / e.vt_hd) * e.vt_hd + cv1 % e.vt_hd) * e.vt_Tpad;
+    const size_t bstride = (size_t)e.vt_heads * e.vt_hd * e.vt_Tpad;
+    int row = row0 + 4 * fh;
+    int b = row / e.vt_T, t = row % e.vt_T;
+    int tq = ws > 0 ? t / ws : 0, tw = ws > 0 ? t % ws : t;                                    // t = tq * ws + tw
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (row < M) {
+          const int slot = ws > 0 ? tq * 16 + tw : t;
+          const bool fast = quad_ok && row + 3 < M && (ws == 0 || (ws & 3) == 0 || tw <= ws - 4);
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) {
+            const float bias = tj ? bias1 : bias0;
+            const float v0 = acc[i][tj][g4 * 4] + bias, v1 = acc[i][tj][g4 * 4 + 1] + bias, v2 = acc[i][tj][g4 * 4 + 2] + bias,
+                        v3 = acc[i][tj][g4 * 4 + 3] + bias;
+            T* rowp = vt + (size_t)b * bstride + (tj ? cb1 : cb0);
+            if (fast) store4v<T>(rowp + slot, v0, v1, v2, v3);
+            else vt_store_slow<T>(vt, (tj ? cb1 : cb0), bstride, e.vt_T, ws, row, M, v0, v1, v2, v3);
+          }
+        }
+        row += 8;
+        t += 8;
+        tw += 8;
+        if (ws > 0) {
+          while (tw >= ws) {
+            tw -= ws;
+            ++tq;
+          }
+        }
+        if (t >= e.vt_T) {                       // next image / window (vt_T >= 8 on this path: host side)
+          t -= e.vt_T;
+          ++b;
+          tq = ws > 0 ? t / ws : 0;
+          tw = ws > 0 ? t % ws : t;
+        }
+      }
+    return;
+  }
+  if (EPI == 1 || EPI == 2) {
+    // 16-bit output.  Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ (r & 7).  Lane pairs (fr, fr ^ 1) trade one
+    // value per register pair over DPP: the even lane ends up with columns (c, c + 1) of row k, the odd lane with the same columns
+    // of row k + 1 - one 32-bit LDS store each.
+    T* out = reinterpret_cast<T*>(e.out16);
+    const bool odd = fr & 1;
+    const int rrow = lane >> 3, rch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const float bias = tj ? bias1 : bias0;
+          const int c = tj * 32 + (fr & ~1);
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+              float a = acc[i][tj][h * 8 + q * 4 + 2 * kp] + bias, b = acc[i][tj][h * 8 + q * 4 + 2 * kp + 1] + bias;
+              if (EPI == 2) {
+                a = gelu_erf_fast(a);
+                b = gelu_erf_fast(b);
+              }
+              const float y = dpp_mov<0xB1>(odd ? a : b);
+              const uint32_t w = odd ? pack2<T>(y, b) : pack2<T>(a, y);
+              const int srow = 2 * kp + (odd ? 1 : 0) + 8 * q + 4 * fh;
+              *reinterpret_cast<uint32_t*>(slab + srow * 128 + (((c >> 3) ^ (srow & 7)) << 4) + (c & 7) * 2) = w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int sr = rrow + 8 * j;
+          const uint4 v = *reinterpret_cast<const uint4*>(slab + sr * 128 + ((rch ^ (sr & 7)) << 4));
+          const int row = row0 + i * 32 + h * 16 + sr;
+          if (row < M) *reinterpret_cast<uint4*>(out + (size_t)row * e.ld16 + col0 + rch * 8) = v;
+        }
+      }
+    return;
+  }
+  // EPI 3: fp32 slab = [8 rows][256 B] (one register quad of both column tiles), 16-B chunk c of row r at slot c ^ (r & 7); the
+  // residual (often the output buffer itself) is fetched HALF a wave tile ahead - 16 float4 per lane in the registers the operand
+  // fragments occupied - so that its latency is paid twice per tile, not once per slab.
+  {
+    T* out16 = reinterpret_cast<T*>(e.out16);
+    const int rr4 = lane >> 4, rch = lane & 15;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 rv[2][4][2];
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = min(row0 + (half * 2 + ii) * 32 + 8 * g4 + rr4 + 4 * j, M - 1);
+            rv[ii][g4][j] = *reinterpret_cast<const float4*>(e.res + (size_t)row * e.ldr + col0 + rch * 4);
+          }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int i = half * 2 + ii;
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) {
+            const float bias = tj ? bias1 : bias0;
+            const int c = tj * 32 + fr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int srow = k + 4 * fh;
+              *reinterpret_cast<float*>(slab + srow * 256 + (((c >> 2) ^ (srow & 7)) << 4) + (c & 3) * 4) = acc[i][tj][g4 * 4 + k] + bias;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int sr = rr4 + 4 * j;
+            float4 v = *reinterpret_cast<const float4*>(slab + sr * 256 + ((rch ^ (sr & 7)) << 4));
+            const float4 r = rv[ii][g4][j];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            const int row = row0 + i * 32 + 8 * g4 + sr;
+            if (row < M) {
+              *reinterpret_cast<float4*>(e.out32 + (size_t)row * e.ld32 + col0 + rch * 4) = v;
+              if (out16) store4v<T>(out16 + (size_t)row * e.ld16 + col0 + rch * 4, v.x, v.y, v.z, v.w);
+            }
+          }
+        }
+    }
+  }
+}
+
+template <typename T, int NPL, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                             int M, int N, int K, LaGemmEpilogue e, int gm) {
+  constexpr int BK_ = 32;
+  constexpr int OPB = 256 * BK_ * 2;                 // 16 KiB per operand tile
+  constexpr int STAGE = OPB * (1 + NPL);
+  constexpr int NST = (NPL == 2) ? 3 : 4;
+  constexpr int NP = 2 * (1 + NPL);                  // DMA pieces per wave per k-step
+  constexpr int SDECL = (EPI == 3) ? 32 : 16;        // stores per wave of an interior, non-V^T tile (never more than are issued)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wi = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ntn = N / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
+  char* slab = smem + NST * STAGE + wave * 2048;
+
+  // DMA plan of a tile: operand o (0 = A, 1 = W_hi, 2 = W_lo), piece i of this wave = tile rows [(wave + 8 i) 16, +16)
+  auto plan = [&](int tile, unsigned (&so)[1 + NPL][2], int& m0, int& n0) {
+    int tm_, tn_;
+    tile_coords(xcd_remap(tile, ntiles), ntm, ntn, gm, tm_, tn_);
+    m0 = tm_ * 256;
+    n0 = tn_ * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wave + 8 * i) * 16 + (lane >> 2);
+      const int ch = ((lane & 3) ^ ((r >> 2) & 3)) << 3;
+      so[0][i] = (unsigned)(((size_t)a_row(e, min(m0 + r, M - 1)) * lda + ch) * sizeof(T));
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) so[1 + pl][i] = (unsigned)(((size_t)(n0 + r) * ldw + pl * K + ch) * sizeof(T));
+    }
+  };
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma = [&](const unsigned (&so)[1 + NPL][2], int kt, int stage) {
+    const unsigned base = lds0 + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int o = 0; o < 1 + NPL; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16s(o ? Wt + kt * BK_ : A + a_koff(e, kt * BK_), so[o][i], base + o * OPB + i * 8192);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK_;                            // >= NST (host side)
+  uint4 af[2][4], wf[2][NPL][2];
+  auto load_frags = [&](int stage) {
+    const char* sa = smem + stage * STAGE;
+    const char* sw = sa + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[ks][i] = *reinterpret_cast<const uint4*>(sa + swz64_off(grp * 128 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          wf[ks][pl][j] = *reinterpret_cast<const uint4*>(sw + pl * OPB + swz64_off(wi * 64 + j * 32 + fr, ks * 2 + fh));
+    }
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  unsigned soff[1 + NPL][2], soffn[1 + NPL][2];
+  int m0, n0, m0n = 0, n0n = 0;
+  int tile = blockIdx.x;
+  plan(tile, soff, m0, n0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) dma(soff, s, s);
+  dma_wait<(NST - 2) * NP>();                        // k-step 0 resident ...
+  bar();                                             // ... for everybody
+  if (grp == 1) bar();                               // group 1 runs one interval behind
+  int stage = 0;
+  bool seam_slack = false;                           // the finished tile's SDECL stores are still in front of this tile's late pieces
+  for (;;) {
+    const int next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    if (more) plan(next, soffn, m0n, n0n);
+    for (int kt = 0; kt < nk; ++kt) {
+      // ---- L(kt) ------------------------------------------------------------------------------------------------------
+      {
+        int ps = stage + NST - 1;
+        if (ps >= NST) ps -= NST;
+        const int pf = kt + NST - 1;
+        if (pf < nk) dma(soff, pf, ps);
+        else if (more) dma(soffn, pf - nk, ps);
+      }
+      // retire this wave's pieces of the NEXT k-step of the stream (kt + 1, or the next tile's k-step 0)
+      auto retire_next = [&]() {
+        const int younger = more ? NST - 2 : min(NST - 2, nk - 2 - kt);
+        if (seam_slack && kt < NST - 2) {            // (implies more-or-not irrelevant: kt + 1 <= NST - 2 < nk)
+          if (NST == 4) dma_wait<2 * NP + SDECL>();
+          else dma_wait<NP + SDECL>();
+        } else if (younger >= 2 && NST == 4) dma_wait<2 * NP>();
+        else if (younger >= 1) dma_wait<NP>();
+        else dma_wait<0>();
+      };
+      load_frags(stage);
+      if (grp == 1) retire_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      // ---- M(kt) ------------------------------------------------------------------------------------------------------
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = Half16<T>::mfma32(af[ks][i], wf[ks][pl][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) retire_next();
+      if (kt + 1 < nk || grp == 0) bar();             // group 1 keeps its last M interval open: both groups' epilogues share it
+      stage = (stage == NST - 1) ? 0 : stage + 1;
+    }
+    // ---- tile done: this wave's block leaves through its private slab; the ring already holds the next tile's first k-steps.
+    // Interval plan at a seam (| = barrier):   group 0   M(nk-1) | E      | L'(0) | M'(0) | ...
+    //                                          group 1   L(nk-1) | M(nk-1) E | -  | L'(0) | ...
+    // i.e. both epilogues run side by side (they are latency-, not issue-bound) and the one-interval stagger is restored after it. ----
+    epilogue_wave<T, EPI>(slab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane);
+    seam_slack = (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0);
+    bar();
+    if (!more) break;
+    if (grp == 1) bar();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < 1 + NPL; ++o)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) soff[o][i] = soffn[o][i];
+    m0 = m0n;
+    n0 = n0n;
+    tile = next;
+  }
+}
+
+template <typename T, int NPL, int EPI>
+static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768) + 8 * 2048;      // ring + one 2 KiB slab per wave (144 / 160 KiB)
+  static bool attr_set = false;
+  static int ncu = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) ncu = 256;
+    attr_set = true;
+  }
+  const int ntiles = ((M + 255) / 256) * (N / 256);
+  const int grid = ntiles < ncu ? ntiles : ncu;
+  hipLaunchKernelGGL((gemm_t256p_kernel<T, NPL, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
+}
+
 template <typename T, int NPL, int EPI>
 static void launch_t256_epi(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = (NPL == 2) ? 3 * 49152 : 136 * 1024;     // ring 144 / 128 KiB; epilogue: two staging buffers of 65 KiB
@@ -1261,6 +1601,12 @@ static void launch_t256_epi(const void* A, int lda, const void* W, int ldw, int 
 template <typename T, int NPL>
 static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   const bool plain = e.map == LA_MAP_NONE && e.res_mod == 0;
+  static const char* nop = getenv("LA_GEMM_NO_PERSISTENT");
+  const bool al = (N % 256) == 0 && K / 32 >= 8 && !nop && (e.ld16 % 8) == 0;
+  if (al && plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
+  if (al && plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) return launch_t256p<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
+  if (al && plain && e.act == LA_ACT_NONE && e.res && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (e.ldr % 4) == 0)
+    return launch_t256p<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);
   if (plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) launch_t256_epi<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   else if (plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) launch_t256_epi<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
   else if (plain && e.act == LA_ACT_NONE && e.res && e.out32 && !e.vt) launch_t256_epi<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);

@@ -522,6 +522,81 @@ def test_gemm_split_precision_weights(L, dt, mnk):
         L.gemm(a, w2, out32=o32, a_kmod=k + 8)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("planes", [1, 2])
+def test_gemm_persistent_256x256_epilogues(L, dt, planes):
+    """gemm_t256p_kernel (persistent workgroups, k-step stream running across tile seams, wave-private epilogue slabs) on its three
+    epilogues: bias -> GELU -> 16 bit; bias + in-place fp32 residual (+ 16-bit copy) behind a window-gather A map; bias -> 16 bit with
+    the V columns leaving transposed in 16-slot window order.  M is not a multiple of 256 (row-edge tiles) and there are more tiles
+    than CUs (every workgroup crosses seams)."""
+    k = 768
+
+    def weights(n, seed):
+        w32 = rnd(n, k, seed=seed) / math.sqrt(k)
+        hi = w32.to(dt)
+        if planes == 1:
+            return hi.contiguous(), hi.float(), {}
+        lo = (w32 - hi.float()).to(dt)
+        return torch.cat([hi, lo], dim=1).contiguous(), hi.float() + lo.float(), {"a_kmod": k}
+
+    tol = TOL16[dt]
+    # --- GELU (lin1 shape class) ---------------------------------------------------------------------------------------------
+    m, n = 256 * (43 if planes == 1 else 11) + 100, 3072
+    a = rnd(m, k, seed=61).to(dt)
+    w, wref, kw = weights(n, 62)
+    bias = rnd(n, seed=63)
+    out = torch.zeros(m, n, device="cuda", dtype=dt)
+    L.gemm(a, w, bias=bias, out16=out, act=L.ACT_GELU, **kw)
+    torch.cuda.synchronize()
+    assert rel_err(out, F.gelu(a.float() @ wref.t() + bias)) < tol
+    # --- residual in place, A rows gathered in window order (proj of a window block) ------------------------------------------------
+    b, h, ws = 3, 64, 14
+    nwy = -(-h // ws)
+    rows, arows = b * h * h, b * nwy * nwy * ws * ws
+    n = 768 if planes == 2 else 3072                 # >= 128 (two planes) / >= 512 (one plane) tiles of 256 x 256
+    ao = rnd(arows, k, seed=64).to(dt)
+    w, wref, kw = weights(n, 65)
+    bias = rnd(n, seed=66)
+    res = rnd(rows, n, seed=67)
+    ref_res = res.clone()
+    o16 = torch.zeros(rows, n, device="cuda", dtype=dt)
+    L.gemm(ao, w, bias=bias, res=res, out32=res, out16=o16, M=rows, amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, h, h), **kw)
+    torch.cuda.synchronize()
+    merged = ao.float().view(b, nwy, nwy, ws, ws, k).permute(0, 1, 3, 2, 4, 5).reshape(b, nwy * ws, nwy * ws, k)[:, :h, :h].reshape(rows, k)
+    ref = merged @ wref.t() + bias + ref_res
+    assert rel_err(res, ref) < 1e-5
+    assert rel_err(o16, ref) < tol
+    # --- qkv of window blocks: V^T in 16-slot order -----------------------------------------------------------------------------------
+    e, heads, t = 768, 12, ws * ws
+    nb = 75 if planes == 1 else 40
+    tpad = (16 * ws + 63) // 64 * 64
+    x = rnd(nb * t, k, seed=68).to(dt)
+    w, wref, kw = weights(3 * e, 69)
+    bias = rnd(3 * e, seed=70) * 0.1
+    fill = 7.0
+    qkv = torch.full((nb * t, 3 * e), fill, device="cuda", dtype=dt)
+    vt = torch.full((nb * heads, 64, tpad), fill, device="cuda", dtype=dt)
+    L.gemm(x, w, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=ws, **kw)
+    torch.cuda.synchronize()
+    ref = x.float() @ wref.t() + bias
+    assert rel_err(qkv[:, : 2 * e], ref[:, : 2 * e]) < tol
+    assert bool((qkv[:, 2 * e:] == fill).all())
+    v = ref[:, 2 * e:].view(nb, ws, ws, heads, 64).permute(0, 3, 4, 1, 2)
+    slots = vt.view(nb, heads, 64, tpad)[..., : 16 * ws].reshape(nb, heads, 64, ws, 16)
+    assert rel_err(slots[..., :ws], v) < tol
+    assert bool((slots[..., ws:] == fill).all()) and bool((vt.view(nb, heads, 64, tpad)[..., 16 * ws:] == fill).all())
+    # --- and the global-attention form (identity slots) -------------------------------------------------------------------------------
+    t, nb = 4096, 4 if planes == 1 else 2
+    x = rnd(nb * t, k, seed=71).to(dt)
+    qkv = torch.zeros(nb * t, 3 * e, device="cuda", dtype=dt)
+    vt = torch.zeros(nb * heads, 64, t, device="cuda", dtype=dt)
+    L.gemm(x, w, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=t, vt_hd=64, vt_heads=heads, **kw)
+    torch.cuda.synchronize()
+    ref = x.float() @ wref.t() + bias
+    assert rel_err(qkv[:, : 2 * e], ref[:, : 2 * e]) < tol
+    assert rel_err(vt, ref[:, 2 * e:].view(nb, t, heads, 64).permute(0, 2, 3, 1).reshape(nb * heads, 64, t)) < tol
+
+
 def _planes(w):
     hi = w.to(torch.float16)
     return hi.contiguous(), (w - hi.float()).to(torch.float16).contiguous()
