@@ -133,10 +133,14 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, *, x2=None, gelu=False, 
     _check(rc, "la_layernorm")
 
 
-def im2col_patch(img: torch.Tensor, patch: int, out16: torch.Tensor) -> None:
+def im2col_patch(img: torch.Tensor, patch: int, out16: torch.Tensor, split: bool = False) -> None:
+    """split: out16 is fp16 [rows, 2 K] = [hi | lo] plane pairs (LA_F16X2)."""
     _dev(img)
     bn, _, s, _ = img.shape
-    _check(lib().la_im2col_patch(_ptr(img), C.c_int(bn), C.c_int(s), C.c_int(patch), _ptr(out16), C.c_int(dt_of(out16)),
+    dt = LA_F16X2 if split else dt_of(out16)
+    if split and out16.dtype != torch.float16:
+        raise RuntimeError("im2col_patch(split=True) writes fp16 plane pairs")
+    _check(lib().la_im2col_patch(_ptr(img), C.c_int(bn), C.c_int(s), C.c_int(patch), _ptr(out16), C.c_int(dt),
                                  _stream()), "la_im2col_patch")
 
 

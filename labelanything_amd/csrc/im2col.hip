@@ -6,7 +6,8 @@
 namespace la {
 
 // image fp32 NCHW [Bn,3,S,S] -> [Bn*g*g, 3*p*p]; column k = c*p*p + ky*p + kx (Conv2d weight flattening order).
-template <typename T>
+// SPLIT: rows are [hi (K) | lo (K)] fp16 plane pairs (LA_F16X2: the patch-embed GEMM then runs on three fp16 products).
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, int Bn, int S, int p, T* __restrict__ out) {
   const int g = S / p;
   const int K = 3 * p * p;
@@ -24,6 +25,9 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
     if constexpr (sizeof(T) == 4) {        // fp32 patches for the exact-fp32 patch-embed GEMM (split-precision group "patch")
       reinterpret_cast<float4*>(out + row * K + k)[0] = v0;
       reinterpret_cast<float4*>(out + row * K + k)[1] = v1;
+    } else if constexpr (SPLIT) {
+      store4_split<T>(out + row * 2 * K, K, k, v0.x, v0.y, v0.z, v0.w);
+      store4_split<T>(out + row * 2 * K, K, k + 4, v1.x, v1.y, v1.z, v1.w);
     } else {
       uint4 o;
       o.x = pack2<T>(v0.x, v0.y);
@@ -63,6 +67,8 @@ extern "C" int la_im2col_patch(const float* img, int Bn, int S, int patch, void*
   if (dt == LA_F16) hipLaunchKernelGGL(la::im2col_patch_kernel<la::f16_t>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (la::f16_t*)out16);
   else if (dt == LA_BF16) hipLaunchKernelGGL(la::im2col_patch_kernel<la::bf16_t>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (la::bf16_t*)out16);
   else if (dt == LA_F32) hipLaunchKernelGGL(la::im2col_patch_kernel<float>, dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (float*)out16);
+  else if (dt == LA_F16X2)
+    hipLaunchKernelGGL((la::im2col_patch_kernel<la::f16_t, true>), dim3(blocks), dim3(256), 0, st, img, Bn, S, patch, (la::f16_t*)out16);
   else LA_CHECK_ARG(false, "la_im2col_patch: bad dtype %d", dt);
   LA_CHECK_LAUNCH("la_im2col_patch");
   return 0;

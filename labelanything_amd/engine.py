@@ -91,6 +91,7 @@ class LamEngine:
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
         self.precise = frozenset(resolve_precise(cfg, precise, dtype))
+        self.patch_split = False                 # set by _patch_weight
         # decoder_dtype "f16x2": the IMAGE-side GEMM operands of the prompt encoder / mask decoder (the (P, hw, D) stream) are pairs
         # of fp16 planes [hi | lo] and their weights [W_hi | W_hi | W_lo] (LA_F16X2, la_hip.h): 3 fast-MFMA products instead of the
         # exact-fp32 MFMA, same accuracy class; the few-row token side stays exact fp32.
@@ -171,6 +172,30 @@ class LamEngine:
             self.p[key] = t.to(self.dt)
             self.kmod.pop(key, None)
 
+    def _patch_weight(self, pw: Tensor) -> Tensor:
+        """Patch-embed weight [dim, 3 p p]: plain 16-bit; or, in the split-precision group "patch", fp16 plane triples
+        [W_hi | W_hi | W_lo] against [A_hi | A_lo] patches (three fp16 MFMA products, ~21 mantissa bits; 2.8x the rate of
+        the exact-fp32 MFMA it replaces) - fp32 for bf16 operands, whose planes would carry 16 bits only."""
+        if "patch" not in self.precise:
+            return self._h(pw)
+        self.patch_split = self.dt == torch.float16 and pw.shape[1] % 64 == 0
+        return self._split3(pw) if self.patch_split else pw.contiguous()
+
+    def patches(self, name: str, images: Tensor, rows: int, patch: int):
+        """im2col of the patch embedding in the operand form _patch_weight chose; returns (A, extra la_gemm keywords)."""
+        k = 3 * patch * patch
+        if "patch" not in self.precise:
+            a = self.buf(name, (rows, k))
+            L.im2col_patch(images, patch, a)
+            return a, {}
+        if self.patch_split:
+            a = self.buf(name, (rows, 2 * k), torch.float16)
+            L.im2col_patch(images, patch, a, split=True)
+            return a, {"a_kmod": 2 * k}
+        a = self.buf(name, (rows, k), torch.float32)
+        L.im2col_patch(images, patch, a)
+        return a, {}
+
     def gemm_w(self, a: Tensor, key: str, **kw) -> None:
         """la_gemm against the packed encoder weight ``key`` (split-precision aware)."""
         L.gemm(a, self.p[key], a_kmod=self.kmod.get(key, 0), **kw)
@@ -245,7 +270,7 @@ class LamEngine:
         if spec is not None and spec.kind == "sam":
             pre = "image_encoder"
             pw = w[pre + ".patch_embed.proj.weight"].flatten(1)
-            p[pre + ".patch.w"] = pw.contiguous() if "patch" in self.precise else self._h(pw)
+            p[pre + ".patch.w"] = self._patch_weight(pw)
             p[pre + ".pos"] = w[pre + ".pos_embed"].reshape(-1, spec.dim).contiguous()
             g = spec.img_size // spec.patch
             hd, hdp = spec.head_dim, self.head_pad
@@ -266,7 +291,7 @@ class LamEngine:
         elif spec is not None and spec.kind == "hf":
             pre = "image_encoder"
             pw = w[pre + ".embeddings.patch_embeddings.projection.weight"].flatten(1)
-            p[pre + ".patch.w"] = pw.contiguous() if "patch" in self.precise else self._h(pw)
+            p[pre + ".patch.w"] = self._patch_weight(pw)
             hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 lp = f"{pre}.encoder.layer.{i}"
@@ -398,10 +423,9 @@ class LamEngine:
         ea = heads * hdp                # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
         w, p = self.w32, self.p
         images = images.contiguous()
-        a = self.buf("enc.patchA", (rows, 3 * spec.patch * spec.patch), torch.float32 if "patch" in self.precise else None)
-        L.im2col_patch(images, spec.patch, a)
+        a, akw = self.patches("enc.patchA", images, rows, spec.patch)
         res = self.f32("enc.res", (rows, e))
-        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res)
+        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
         nwy = (g + ws - 1) // ws
         x16 = self.buf("enc.x16", (rows, e))
         last16 = None
@@ -490,12 +514,11 @@ class LamEngine:
         pos = self._hf_pos(g)
         cls_row = self._hfpos_cache[-g]
         images = images.contiguous()
-        a = self.buf("hf.patchA", (bn * hw, 3 * spec.patch * spec.patch), torch.float32 if "patch" in self.precise else None)
-        L.im2col_patch(images, spec.patch, a)
+        a, akw = self.patches("hf.patchA", images, bn * hw, spec.patch)
         res = self.f32("hf.res", (rows, e))
         res.view(bn, t, e)[:, 0].copy_(cls_row)      # CLS row = cls_token + pos[0] (weights only; plain copy)
         L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".embeddings.patch_embeddings.projection.bias"], res=pos, res_mod=t,
-               out32=res, map=L.MAP_GROUP, p=(hw, t, 1, 0, 0))
+               out32=res, map=L.MAP_GROUP, p=(hw, t, 1, 0, 0), **akw)
         tpad = _ceil(t, 64)
         x16 = self.buf("hf.x16", (rows, e))
         hdp = self.head_pad
