@@ -109,7 +109,8 @@ int la_layernorm(const float* x, const float* x2, int ldx, int rows, int E, cons
 int la_im2col_patch(const float* img, int Bn, int S, int patch, void* out16, int dt, void* stream);
 
 /* 3x3 / pad 1 im2col on an NHWC 16-bit map [B,H,W,C] -> [B*H*W, 9*C], k = (ky*3+kx)*C + c  (C % 8 == 0)
- * (neck conv image_encoder.py:100-106, spatial convs mask_decoder.py:236-255). */
+ * (neck conv image_encoder.py:100-106, spatial convs mask_decoder.py:236-255).  dt = LA_F16X2: pixel rows are fp16 plane pairs
+ * [hi (C) | lo (C)] and the output rows [9 taps of hi | 9 taps of lo] (18 C columns). */
 int la_im2col_3x3(const void* in16, int B, int H, int W, int C, void* out16, int dt, void* stream);
 
 /* Decomposed relative-position terms (image_encoder.py:340-376) from the UNSCALED q of a fused qkv buffer:

@@ -144,10 +144,11 @@ def im2col_patch(img: torch.Tensor, patch: int, out16: torch.Tensor, split: bool
                                  _stream()), "la_im2col_patch")
 
 
-def im2col_3x3(x16: torch.Tensor, b: int, h: int, w: int, c: int, out16: torch.Tensor) -> None:
+def im2col_3x3(x16: torch.Tensor, b: int, h: int, w: int, c: int, out16: torch.Tensor, split: bool = False) -> None:
+    """split: x16 rows are fp16 plane pairs [hi (c) | lo (c)], out16 rows [9 taps of hi | 9 taps of lo] (LA_F16X2)."""
     _dev(x16)
-    _check(lib().la_im2col_3x3(_ptr(x16), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(c), _ptr(out16), C.c_int(dt_of(x16)),
-                               _stream()), "la_im2col_3x3")
+    _check(lib().la_im2col_3x3(_ptr(x16), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(c), _ptr(out16),
+                               C.c_int(LA_F16X2 if split else dt_of(x16)), _stream()), "la_im2col_3x3")
 
 
 def relpos_terms(qkv: torch.Tensor, b: int, heads: int, g: int, e: int, tabh, tabw, relh, relw) -> None:

@@ -39,18 +39,22 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
   }
 }
 
-// NHWC 16-bit [B,H,W,C] -> [B*H*W, 9*C]; column k = (ky*3+kx)*C + c, zero padding 1.
-__global__ __launch_bounds__(256) void im2col_3x3_kernel(const uint4* __restrict__ in, int B, int H, int W, int C8, uint4* __restrict__ out) {
-  const long total = (long)B * H * W * 9 * C8;
+// NHWC 16-bit [B,H,W,C] -> [B*H*W, 9*C]; column k = (ky*3+kx)*C + c, zero padding 1.  planes = 2 (LA_F16X2): the pixel rows are
+// [hi (C) | lo (C)] plane pairs and the output rows [9 taps of hi | 9 taps of lo], i.e. again a plane pair of the whole patch.
+__global__ __launch_bounds__(256) void im2col_3x3_kernel(const uint4* __restrict__ in, int B, int H, int W, int C8, int planes,
+                                                         uint4* __restrict__ out) {
+  const long total = (long)B * H * W * planes * 9 * C8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C8);
     long r = i / C8;
     const int tap = (int)(r % 9);
     r /= 9;
+    const int pl = (int)(r % planes);
+    r /= planes;
     const int x = (int)(r % W), y = (int)((r / W) % H), b = (int)(r / ((long)W * H));
     const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[(((long)b * H + yy) * W + xx) * C8 + c];
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((((long)b * H + yy) * W + xx) * planes + pl) * C8 + c];
     out[i] = v;
   }
 }
@@ -77,11 +81,12 @@ extern "C" int la_im2col_patch(const float* img, int Bn, int S, int patch, void*
 extern "C" int la_im2col_3x3(const void* in16, int B, int H, int W, int C, void* out16, int dt, void* stream) {
   LA_CHECK_ARG(in16 && out16, "la_im2col_3x3: null pointer");
   const int per16 = (dt == LA_F32) ? 4 : 8;   // elements per 16-byte chunk
+  const int planes = (dt == LA_F16X2) ? 2 : 1;
   LA_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && (C % per16) == 0, "la_im2col_3x3: bad geometry (C=%d must be a multiple of %d)", C, per16);
-  const long total = (long)B * H * W * 9 * (C / per16);
+  const long total = (long)B * H * W * planes * 9 * (C / per16);
   int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(la::im2col_3x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const uint4*>(in16), B, H, W, C / per16, reinterpret_cast<uint4*>(out16));
+                     reinterpret_cast<const uint4*>(in16), B, H, W, C / per16, planes, reinterpret_cast<uint4*>(out16));
   LA_CHECK_LAUNCH("la_im2col_3x3");
   return 0;
 }
