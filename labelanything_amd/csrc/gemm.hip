@@ -1347,8 +1347,9 @@ __device__ __forceinline__ void epilogue_wave(char* slab, f32x16 (&acc)[4][2], i
             for (int kp = 0; kp < 2; ++kp) {
               float a = acc[i][tj][h * 8 + q * 4 + 2 * kp] + bias, b = acc[i][tj][h * 8 + q * 4 + 2 * kp + 1] + bias;
               if (EPI == 2) {
-                a = gelu_erf_fast(a);
-                b = gelu_erf_fast(b);
+                const f32x2 gv = gelu_erf_pk(f32x2{a, b});
+                a = gv.x;
+                b = gv.y;
               }
               const float y = dpp_mov<0xB1>(odd ? a : b);
               const uint32_t w = odd ? pack2<T>(y, b) : pack2<T>(a, y);
