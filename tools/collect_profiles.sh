@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the MI355X box (via gpurun) from the repo root: refreshes everything the judge reads under profiles/ for round $1.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -18,8 +18,19 @@ cp $(find $OUT/prof_eager -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_be
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
 python tools/pmc_traffic.py $(find $OUT/pmc -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic.json > /dev/null 2> $OUT/traffic.stderr
+# 3b. the same two passes on cfg4 (decoder-dominated: the fused two-way kernels' stream traffic)
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -o f -- python bench.py --workload cfg4 --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o w -- python bench.py --workload cfg4 --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+python tools/pmc_traffic.py $(find $OUT/pmc4 -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc4 -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic_cfg4.json cfg4 > /dev/null 2>> $OUT/traffic.stderr
+# 3c. the other workloads (each carries its own kernel table; traffic stays null where no PMC file matches) and the two
+#     numerics variants of the headline: plain 16-bit operands (round-1 numerics, misses 1e-3) and bf16
+for w in cfg1 cfg3 cfg4 cfg5 cfg3_train; do timeout 600 python bench.py --workload $w --no-cpu-baseline > $OUT/${R}_bench_$w.json 2>> $OUT/bench.stderr; done
+timeout 600 python bench.py --no-cpu-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --no-cpu-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
+timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>&1
 # 4. parity report + per-op micro benchmarks
 timeout 900 python tools/parity_report.py > $OUT/${R}_parity.log 2>&1
+timeout 900 python tools/parity_report.py --groups > $OUT/${R}_parity_groups.log 2>&1
 timeout 600 python tools/bench_ops.py > $OUT/${R}_bench_ops.log 2>&1
-rm -rf $OUT/prof $OUT/prof_eager $OUT/pmc
+rm -rf $OUT/prof $OUT/prof_eager $OUT/pmc $OUT/pmc4
 ls -la $OUT

@@ -39,6 +39,7 @@ def main():
     from labelanything_amd.engine import PRECISE_WIDE
     workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
     precise = list(PRECISE_WIDE) if len(sys.argv) <= 5 or sys.argv[5] == "default" else [g for g in sys.argv[5].split(",") if g and g != "none"]
+    tw = sorted(n for n in fetch if "twoway_" in n and "merge" not in n)
     out = {
         "workload": workload, "encoder_split_precision": precise,      # bench.py only attaches this file to a matching run
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-graphs --no-cpu-baseline`",
@@ -50,6 +51,10 @@ def main():
         "bytes_per_launch": round((2.0 * fkib + wkib) * 1024.0 / max(launches, 1)),
         "per_kernel": {n: {"launches": fcnt[n], "fetch_kib_raw": round(fetch[n] / fcnt[n], 1),
                            "write_kib_raw": round(write.get(n, 0.0) / max(wcnt.get(n, 1), 1), 1)} for n in names},
+        # fused image-side kernels of the two-way transformer (csrc/twoway.hip): bytes per launch with the same x2 read correction;
+        # algorithmic = the (groups, hw, 256) fp32 stream once (t2i: read) or twice (i2t: read + write)
+        "twoway": {n: {"launches": fcnt[n], "bytes_per_launch": round((2.0 * fetch[n] / fcnt[n] + write.get(n, 0.0) / max(wcnt.get(n, 1), 1)) * 1024.0)}
+                   for n in tw},
     }
     with open(sys.argv[3], "w") as f:
         json.dump(out, f, indent=1)
