@@ -57,16 +57,19 @@ class Arena:
 # the same perturbation for every token, so its effect survives attention and pooling instead of averaging out like the
 # activation roundings, and the necks / patch embedding have no residual stream to dilute their error.
 #   "qkv", "proj", "lin1", "lin2": weights as two 16-bit planes [W_hi | W_lo] (la_gemm a_kmod), activations 16-bit;
-#   "patch", "neck": exact-fp32 MFMA (1 % of the FLOPs).
-# Which planes are worth their MFMA passes was measured on the six golden cases (profiles/r02_parity_groups.log, max error of
-# any stage, tolerance 1e-3): full set 3.7-6.0e-4; without lin2 6.2-8.3e-4; without lin2 and proj 7.4-9.1e-4.  The 768+-wide
-# encoders of the BASELINE configs keep patch / qkv / proj / neck (cfg2 7.0e-4, cfg1 6.2e-4: lin2's second plane would cost
-# 8 % of the step for the last 1.5e-4); encoders narrower than 512 keep lin2 as well (it is cheap there and its share of the
-# error is larger: sam_tiny 8.3e-4 -> 6.0e-4).
+#   "v": only the V rows of the qkv weight carry the second plane (the qkv GEMM becomes a one-plane q/k launch and a two-plane V
+#        launch).  tools/error_budget.py: rounding Wq / Wk perturbs the attention SCORES incoherently and washes out (cfg1 low-res
+#        logits 9.5e-4 with only Wq, Wk split = the same as with no plane at all), the V projection is linear all the way to the
+#        block output (7.0e-4 with only Wv split, 6.7e-4 with all three);
+#   "patch", "neck": fp32-class products (fp16 plane pairs on both operands where the shape allows, exact-fp32 MFMA otherwise).
+# Which planes are worth their MFMA passes was measured on the golden cases (profiles/r02_parity_groups.log, max error of any
+# stage, tolerance 1e-3).  The 768+-wide encoders of the BASELINE configs keep patch / v / neck (cfg2 7.5e-4, cfg1 7.0e-4;
+# proj's second plane would buy 0.6e-4 for 3 % of the step, lin2's 1.5e-4 for 8 %); encoders narrower than 512 keep the full qkv,
+# proj and lin2 planes (cheap there, and their share of the error is larger: sam_tiny 8.3e-4 -> 6.0e-4).
 PRECISE_FULL = ("patch", "qkv", "proj", "lin2", "neck")
-PRECISE_WIDE = ("patch", "qkv", "proj", "neck")
+PRECISE_WIDE = ("patch", "v", "neck")
 PRECISE_DEFAULT = "auto"
-PRECISE_GROUPS = ("patch", "qkv", "proj", "lin1", "lin2", "neck")
+PRECISE_GROUPS = ("patch", "qkv", "v", "proj", "lin1", "lin2", "neck")
 
 
 def resolve_precise(cfg: LamConfig, precise, dtype: torch.dtype = torch.float16) -> tuple:
@@ -171,6 +174,27 @@ class LamEngine:
         else:
             self.p[key] = t.to(self.dt)
             self.kmod.pop(key, None)
+
+    def _hw_qkv(self, key: str, t: Tensor, bias: Tensor, ea: int) -> None:
+        """Pack a fused qkv weight [3 ea, K] + bias.  Group "qkv": planes for all rows; group "v": a one-plane [2 ea, K] q/k weight and
+        a two-plane [ea, 2 K] V weight (two launches, qkv_gemm); else one plane."""
+        self.p[key[:-2] + ".b"] = bias
+        if "qkv" not in self.precise and "v" in self.precise and t.shape[1] % 64 == 0 and (2 * ea) % 8 == 0:
+            self.p[key + ".qk"] = t[: 2 * ea].to(self.dt).contiguous()
+            self._hw(key + ".v", t[2 * ea:], "v")
+            self.p.pop(key, None)
+            return
+        self._hw(key, t, "qkv")
+
+    def qkv_gemm(self, x: Tensor, key: str, qkv: Tensor, vt: Tensor, ea: int, **vtkw) -> None:
+        """qkv[:, :2 ea] = q, k rows of x W^T + b; V goes transposed to vt (la_gemm vt epilogue) - one launch, or two when only the V
+        rows of the weight carry a second plane."""
+        b = self.p[key[:-2] + ".b"]
+        if (key + ".qk") in self.p:
+            L.gemm(x, self.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea])
+            L.gemm(x, self.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], vt=vt, vt_col0=0, a_kmod=self.kmod.get(key + ".v", 0), **vtkw)
+        else:
+            self.gemm_w(x, key, bias=b, out16=qkv, vt=vt, vt_col0=2 * ea, **vtkw)
 
     def _patch_weight(self, pw: Tensor) -> Tensor:
         """Patch-embed weight [dim, 3 p p]: plain 16-bit; or, in the split-precision group "patch", fp16 plane triples
@@ -281,8 +305,8 @@ class LamEngine:
             hd, hdp = spec.head_dim, self.head_pad
             for i in range(spec.depth):
                 bp = f"{pre}.blocks.{i}"
-                self._hw(bp + ".qkv.w", self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp), "qkv")
-                p[bp + ".qkv.b"] = self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp)
+                self._hw_qkv(bp + ".qkv.w", self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp),
+                             self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(bp + ".proj.w", self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp), "proj")
                 self._hw(bp + ".lin1.w", w[bp + ".mlp.lin1.weight"], "lin1")
                 self._hw(bp + ".lin2.w", w[bp + ".mlp.lin2.weight"], "lin2")
@@ -304,8 +328,8 @@ class LamEngine:
                                    w[lp + ".attention.attention.value.weight"]])
                 qkv_b = torch.cat([w[lp + ".attention.attention.query.bias"], w[lp + ".attention.attention.key.bias"],
                                    w[lp + ".attention.attention.value.bias"]])
-                self._hw(lp + ".qkv.w", self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp), "qkv")
-                p[lp + ".qkv.b"] = self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp)
+                self._hw_qkv(lp + ".qkv.w", self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp),
+                             self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(lp + ".o.w", self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp), "proj")
                 self._hw(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], "lin1")
                 self._hw(lp + ".fc2.w", w[lp + ".output.dense.weight"], "lin2")
@@ -461,8 +485,7 @@ class LamEngine:
             # the 16 % padded rows here too, but it breaks the V^T stores into 14-token runs and measured slower.)
             qkv = self.buf("enc.qkv." + tag, (arows, 3 * ea))
             vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
-            self.gemm_w(xin, bp + ".qkv.w", bias=p[bp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t,
-                        vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
+            self.qkv_gemm(xin, bp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
             ao = self.buf("enc.ao." + tag, (arows, ea))
             if win16:
                 L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16,
@@ -544,8 +567,7 @@ class LamEngine:
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
-            self.gemm_w(x16, lp + ".qkv.w", bias=p[lp + ".qkv.b"], out16=qkv, vt=vt, vt_col0=2 * ea, vt_T=t, vt_Tpad=tpad,
-                        vt_hd=hdp, vt_heads=heads)
+            self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
             L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
             self.gemm_w(ao, lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
             self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
