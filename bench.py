@@ -124,6 +124,8 @@ class KernelTimer:
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
                     flops = 4.0 * b * heads * t * t * 64
+                elif _n in ("twoway_t2i", "twoway_i2t"):     # the (groups, hw, D) fp32 stream: read once (t2i), read + written (i2t)
+                    nbytes = a[0].numel() * 4.0 * (2 if _n == "twoway_i2t" else 1)
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
@@ -313,6 +315,24 @@ def main():
                     "share_of_kernel_time": round(g[1] / tot, 3),
                     # split-precision weights ([W_hi | W_lo]) issue two MFMA passes for one algorithmic product
                     "mfma_issued_tflops": round(g[4] / g[1] / 1e12, 1)}
+
+        top = max(agg.items(), key=lambda kv: kv[1][1])
+        if top[0].startswith("twoway_") and (not g or top[1][1] > g[1]):
+            # decoder-only workloads (cfg4): the dominant kernel is a fused pass over the image-side stream, bounded by HBM
+            i2t = agg.get("twoway_i2t", top[1])
+            ach = i2t[3] / i2t[1] / 1e9
+            tw = None
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+                with open(path) as fh:
+                    dd = json.load(fh)
+                if dd.get("workload") == a.workload and dd.get("twoway"):
+                    tw = next((v["bytes_per_launch"] for k, v in dd["twoway"].items() if "i2t" in k), None)
+                    break
+            roof = {"kernel": "twoway_i2t_kernel (q-proj + image->token attention + out_proj + residual + LayerNorm, in place on the stream)",
+                    "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": tw,
+                    "algorithmic_bytes_per_launch": round(i2t[3] / i2t[0]), "launches_per_step": i2t[0],
+                    "avg_launch_us": round(i2t[1] / i2t[0] * 1e6, 2), "share_of_kernel_time": round(i2t[1] / tot, 3)}
 
     if rank == 0:
         eps = a.episodes * world * a.steps / elapsed
