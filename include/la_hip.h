@@ -223,7 +223,8 @@ int la_prompt_masks(const unsigned char* masks, const int* first, const int* cou
  * loss/focal.py:17-26, loss/utils.py:17-43) fused with its gradient.  logits fp32 [B, C, HW] (-inf padding allowed where the
  * target is ignore_index), target int64 [B, HW]; loss fp32 [1] = scale * mean over ALL B*HW pixels of (1 - pt)^gamma * w[t] * ce;
  * dlogits fp32 [B, C, HW] or NULL; class_weights fp32 [C] or NULL (the per-batch weights 1 / log(1.1 + share), 1 for absent
- * classes; all 1 when class_weighting == 0).  scratch: device workspace, (C + 1) * 8 + 2048 * 8 bytes. */
+ * classes; all 1 when class_weighting == 0).  scratch: device workspace, (C + 2) * 8 + 2048 * 8 bytes; after the call its 64-bit word
+ * C + 1 holds the number of targets outside [0, C) other than ignore_index (torch raises on those; they contribute nothing here). */
 int la_focal_loss(const float* logits, const long long* target, int B, int C, long HW, float gamma, int class_weighting, float scale,
                   long long ignore_index, float* loss, float* dlogits, float* class_weights, void* scratch, long scratch_bytes,
                   void* stream);

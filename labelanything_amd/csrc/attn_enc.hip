@@ -686,11 +686,9 @@ static void launch_window(const AttnArgs& a, hipStream_t st) {
 
 template <typename T, int MODE, int NH>
 static void launch_attn_nh(const AttnArgs& a, size_t lds, hipStream_t st) {
-  static size_t attr_lds = 0;   // raise the dynamic-LDS limit once (and again only if a larger request shows up)
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
-  }
+  // raise the dynamic-LDS limit to the most any request of this variant can need (160 KiB), once per device
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, NH>), 160 * 1024, attr_mask);
   const int nq = (a.T + 127) / 128;
   hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, NH>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
 }

@@ -604,11 +604,8 @@ static int tile_group_m(int dflt = 8) {
 template <typename T>
 static void launch_fast4(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = 3 * (256 + BN) * 32 * 2;     // 72 KiB >= 67.5 KiB epilogue chunk
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_dma4_kernel<T>), LDS, attr_mask);
   const int ntm = (M + 255) / 256, ntn = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_dma4_kernel<T>), dim3(ntm * ntn), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
@@ -886,11 +883,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const T* __restrict__ A
 template <typename T>
 static void launch_pp(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = 2 * PP_STAGE;      // 128 KiB (epilogue chunk 64 x 260 x 4 = 65 KiB, transposed 256 x 68 x 4 = 68 KiB)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_pp_kernel<T>), LDS, attr_mask);
   const int ntm = (M + PP_BM - 1) / PP_BM, ntn = (N + PP_BN - 1) / PP_BN;
   hipLaunchKernelGGL((gemm_pp_kernel<T>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
@@ -1569,15 +1563,14 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
 template <typename T, int NPL, int EPI>
 static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768) + 8 * 2048;      // ring + one 2 KiB slab per wave (144 / 160 KiB)
-  static bool attr_set = false;
-  static int ncu = 0;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), LDS, attr_mask);
+  static int ncu = 0;                                // (the GPUs of one host are the same part)
+  if (ncu == 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (ncu <= 0) ncu = 256;
-    attr_set = true;
   }
   const int ntiles = ((M + 255) / 256) * (N / 256);
   const int grid = ntiles < ncu ? ntiles : ncu;
@@ -1588,11 +1581,8 @@ static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, 
 template <typename T, int NPL, int EPI>
 static void launch_t256_epi(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = (NPL == 2) ? 3 * 49152 : 136 * 1024;     // ring 144 / 128 KiB; epilogue: two staging buffers of 65 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_t256_kernel<T, NPL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256_kernel<T, NPL, EPI>), LDS, attr_mask);
   const int ntm = (M + 255) / 256, ntn = (N + 255) / 256;
   hipLaunchKernelGGL((gemm_t256_kernel<T, NPL, EPI>), dim3(ntm * ntn), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2));
@@ -1617,11 +1607,8 @@ static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, i
 template <typename T, int BM_>
 static void launch_fast(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   constexpr int LDS = fast_lds_bytes<BM_>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<T, BM_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_dma_kernel<T, BM_>), LDS, attr_mask);
   const int ntm = (M + BM_ - 1) / BM_, ntn = (N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm_dma_kernel<T, BM_>), dim3(ntm * ntn), dim3(BM_ * 2), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m());
@@ -1795,11 +1782,8 @@ static void launch_f32(const void* A, int lda, const void* W, int ldw, int M, in
   constexpr int EPI = 128 * (BN_ + 4) * 4;
   constexpr int LDS = (2 * (BM + BN_) * 128) > EPI ? (2 * (BM + BN_) * 128) : EPI;
   const int vec_epi = epi_vec_ok(N, e, 4) ? 1 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_f32_kernel<BN_>), LDS, attr_mask);
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN_ - 1) / BN_;
   hipLaunchKernelGGL(gemm_f32_kernel<BN_>, dim3(ntm * ntn), dim3(256), LDS, st, reinterpret_cast<const float*>(A), lda,
                      reinterpret_cast<const float*>(W), ldw, M, N, K, e, cv, vec_epi);
@@ -1899,12 +1883,8 @@ static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M,
 template <typename T>
 static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e,
                        hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * STAGE_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_nt_kernel<T>), 2 * STAGE_BYTES, attr_mask);
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
   hipLaunchKernelGGL(gemm_nt_kernel<T>, dim3(ntm * ntn), dim3(256), 2 * STAGE_BYTES, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e);

@@ -182,6 +182,16 @@ __device__ __forceinline__ void dma16s(const void* gbase_uniform, unsigned voff,
 }
 template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: remember it per (call site, device), so that a process
+// that drives several GPUs raises the limit on each of them (mask: one static 64-bit word per call site).
+static inline void ensure_dyn_lds(const void* kernel, int bytes, unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && ((mask >> dev) & 1ull)) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev >= 0 && dev < 64) mask |= 1ull << dev;
+}
+
 // XCD-aware tile order: consecutive workgroups round-robin over the 8 XCDs, so give each XCD a
 // contiguous chunk of the tile sequence (bijective also when n % 8 != 0).
 __device__ __forceinline__ int xcd_remap(int bid, int n) {

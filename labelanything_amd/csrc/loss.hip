@@ -16,17 +16,18 @@ namespace la {
 constexpr int FL_MAXC = 64;
 
 __global__ __launch_bounds__(256) void focal_hist_kernel(const long long* __restrict__ target, long n, int C, long long ignore,
-                                                         unsigned long long* __restrict__ counts /*[C + 1]: 0 = ignore*/) {
-  __shared__ unsigned int h[FL_MAXC + 1];
-  for (int i = threadIdx.x; i <= C; i += 256) h[i] = 0;
+                                                         unsigned long long* __restrict__ counts /*[C + 2]: 0 = ignore, C + 1 = out of range*/) {
+  __shared__ unsigned int h[FL_MAXC + 2];
+  for (int i = threadIdx.x; i <= C + 1; i += 256) h[i] = 0;
   __syncthreads();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long long t = target[i];
     if (t == ignore) atomicAdd(&h[0], 1u);
     else if (t >= 0 && t < C) atomicAdd(&h[1 + (int)t], 1u);
+    else atomicAdd(&h[C + 1], 1u);               // torch's cross_entropy raises on these; here they are counted (and contribute nothing)
   }
   __syncthreads();
-  for (int i = threadIdx.x; i <= C; i += 256)
+  for (int i = threadIdx.x; i <= C + 1; i += 256)
     if (h[i]) atomicAdd(&counts[i], (unsigned long long)h[i]);
 }
 
@@ -103,12 +104,12 @@ extern "C" int la_focal_loss(const float* logits, const long long* target, int B
   LA_CHECK_ARG(B > 0 && HW > 0 && C >= 2 && C <= la::FL_MAXC, "la_focal_loss: bad shape B=%d C=%d HW=%ld (C <= %d)", B, C, HW, la::FL_MAXC);
   const long n = (long)B * HW;
   int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-  const long need = (long)(C + 1) * 8 + (long)blocks * 8;
+  const long need = (long)(C + 2) * 8 + (long)blocks * 8;
   LA_CHECK_ARG(scratch_bytes >= need, "la_focal_loss: scratch needs %ld bytes", need);
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* counts = (unsigned long long*)scratch;
-  double* partial = (double*)((char*)scratch + (long)(C + 1) * 8);
-  if (hipMemsetAsync(counts, 0, (size_t)(C + 1) * 8, st) != hipSuccess) {
+  double* partial = (double*)((char*)scratch + (long)(C + 2) * 8);
+  if (hipMemsetAsync(counts, 0, (size_t)(C + 2) * 8, st) != hipSuccess) {
     la_set_error("la_focal_loss: memset failed");
     return -2;
   }

@@ -145,12 +145,9 @@ extern "C" int la_confmat_update(const long long* pred, const long long* gt, int
   if (blocks > 512) blocks = 512;          // 2 per CU: the per-block histogram init + flush (K*K entries) must stay small next to the pixels
   if (K <= la::CM_LDS_K) {
     const size_t lds = ((size_t)K * K + 4) * sizeof(unsigned int);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la::confmat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (la::CM_LDS_K * la::CM_LDS_K + 4) * (int)sizeof(unsigned int));
-      attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::confmat_kernel<true>), (la::CM_LDS_K * la::CM_LDS_K + 4) * (int)sizeof(unsigned int),
+                       attr_mask);
     hipLaunchKernelGGL(la::confmat_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
   } else {
     hipLaunchKernelGGL(la::confmat_kernel<false>, dim3((unsigned)blocks), dim3(256), 4 * sizeof(unsigned int), st, a);

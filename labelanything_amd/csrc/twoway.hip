@@ -462,11 +462,8 @@ extern "C" int la_twoway_t2i(const float* img, const void* wk_hi, const void* wk
                   part, G, hw, nt, D, S, 1.0f / sqrtf((float)la::TW_HD)};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int LDS = 160 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la::twoway_t2i_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  la::ensure_dyn_lds(reinterpret_cast<const void*>(la::twoway_t2i_kernel), LDS, attr_mask);
   hipLaunchKernelGGL(la::twoway_t2i_kernel, dim3(S, G), dim3(256), LDS, st, a);
   hipLaunchKernelGGL(la::twoway_merge_kernel, dim3(nt, G), dim3(128), 0, st, part, S * 4, nt, out);
   LA_CHECK_LAUNCH("la_twoway_t2i");
@@ -482,11 +479,8 @@ extern "C" int la_twoway_i2t(float* img, const void* wq_hi, const void* wq_lo, c
   la::TwI2tArgs a{img, (const la::f16_t*)wq_hi, (const la::f16_t*)wq_lo, peq, k, v, (const la::f16_t*)wo_hi, (const la::f16_t*)wo_lo, bo, gamma,
                   beta, eps, 1.0f / sqrtf((float)la::TW_HD), G, hw, nt, D};
   constexpr int LDS = 160 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(la::twoway_i2t_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  static unsigned long long attr_mask = 0;
+  la::ensure_dyn_lds(reinterpret_cast<const void*>(la::twoway_i2t_kernel), LDS, attr_mask);
   hipLaunchKernelGGL(la::twoway_i2t_kernel, dim3((hw + la::TW_ROWS - 1) / la::TW_ROWS, G), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream), a);
   LA_CHECK_LAUNCH("la_twoway_i2t");
   return 0;

@@ -29,7 +29,9 @@ class FocalLossDevice:
         loss = torch.empty(1, device=dev)
         dlog = torch.empty_like(logits) if need_grad else None
         cw = torch.empty(c, device=dev)
-        scratch = torch.empty((c + 1) + 2048, device=dev, dtype=torch.int64)
+        scratch = torch.empty((c + 2) + 2048, device=dev, dtype=torch.int64)
         L.focal_loss(logits.contiguous(), target.contiguous(), self.gamma, self.class_weighting, self.scale, self.ignore_index, loss, dlog, cw,
                      scratch)
-        return {"loss": loss, "dlogits": dlog, "class_weights": cw}
+        # "bad_targets": labels outside [0, C) that are not ignore_index (torch raises on those; here they are counted on the device and
+        # contribute nothing - check it where a host sync is acceptable)
+        return {"loss": loss, "dlogits": dlog, "class_weights": cw, "bad_targets": scratch[c + 1]}

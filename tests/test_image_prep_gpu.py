@@ -78,3 +78,29 @@ def test_coords_boxes_and_flags_merge():
     assert flags_merge(fm, fp).tolist() == [[True, True, True], [True, False, False]]      # background column forced to 1
     with pytest.raises(ValueError):
         flags_merge()
+
+
+def test_annotations_to_tensor_rasterises_mask_prompts_on_the_device():
+    """collate.annotations_to_tensor(prompt_type="mask"): per image a dict {category: uint8 [k, H, W] instance masks}; the union of a
+    category's instances goes through the same device rasteriser as prompt_masks_from_instances (bit-exact with the reference's
+    PromptsProcessor.apply_masks, tested above) and lands in the (N, C, 256, 256) tensor with its flag."""
+    from labelanything_amd.collate import annotations_to_tensor
+    from labelanything_amd.prompts import prompt_masks_from_instances
+    g = torch.Generator().manual_seed(11)
+    sizes = [(120, 200), (333, 150)]
+    anns = []
+    for (h, w) in sizes:
+        anns.append({7: (torch.rand(2, h, w, generator=g) > 0.7).to(torch.uint8).numpy(), 3: (torch.rand(1, h, w, generator=g) > 0.5).to(torch.uint8).numpy()})
+    anns[1][3] = np.zeros((0, *sizes[1]), dtype=np.uint8)    # the second image has no instance of category 3
+    t, f = annotations_to_tensor(anns, sizes, "mask", device=torch.device("cuda"))
+    assert t.shape == (2, 2, 256, 256) and t.dtype == torch.float32 and f.shape == (2, 2) and f.dtype == torch.uint8
+    for i, a in enumerate(anns):
+        for j, c in enumerate(a):                            # class slots follow the dict order
+            if a[c].shape[0] == 0:
+                assert int(f[i, j]) == 0 and float(t[i, j].abs().max()) == 0.0
+                continue
+            inst = torch.from_numpy(a[c]).cuda()
+            ref, rf = prompt_masks_from_instances(inst, [list(range(inst.shape[0]))], 1024, 256, True)
+            assert int(f[i, j]) == int(rf[0]) and torch.equal(t[i, j], ref[0])
+    with pytest.raises(RuntimeError, match="device"):
+        annotations_to_tensor(anns, sizes, "mask")

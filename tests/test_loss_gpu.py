@@ -50,3 +50,20 @@ def test_focal_loss_rejects_bad_inputs():
         f(torch.zeros(1, 2, 4, 4), torch.zeros(1, 4, 4, dtype=torch.int64))
     with pytest.raises(ValueError):
         f(torch.zeros(1, 2, 4, 4).cuda(), torch.zeros(1, 4, 5, dtype=torch.int64).cuda())
+
+
+def test_out_of_range_targets_are_counted_not_silently_dropped():
+    """torch's cross_entropy raises on labels outside [0, C); the device kernel counts them (result["bad_targets"]) and lets them
+    contribute nothing - the caller checks the counter where a host sync is acceptable."""
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(2, 4, 32, 32, generator=g)
+    target = torch.randint(0, 4, (2, 32, 32), generator=g)
+    out = FocalLossDevice(2.0, 1.0, True)(logits.cuda(), target.cuda())
+    assert int(out["bad_targets"]) == 0
+    bad = target.clone()
+    bad[0, 0, :5] = 7
+    bad[1, 3, 3] = -3
+    bad[1, 4, 4] = -100                                     # the ignore label is not "bad"
+    out2 = FocalLossDevice(2.0, 1.0, True)(logits.cuda(), bad.cuda())
+    assert int(out2["bad_targets"]) == 6
+    assert torch.isfinite(out2["loss"]).all() and float(out2["dlogits"][0, :, 0, :5].abs().max()) == 0.0

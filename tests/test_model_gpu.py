@@ -82,6 +82,23 @@ def test_plain_16bit_operands_are_faster_but_coarser():
         Lam(case["cfg"], seed=1, precise=("mlp",)).cuda().engine()
 
 
+def test_decoder_on_fp16_plane_pairs_keeps_fp32_level_parity():
+    """decoder_dtype="f16x2": the image-side GEMM operands of the prompt encoder / mask decoder are fp16 plane pairs [hi | lo] against
+    [W_hi | W_hi | W_lo] weights (three fast-MFMA products instead of the exact-fp32 MFMA): the decoder-only fixture (no encoder error
+    at all) must stay at fp32 level, far below what one 16-bit plane gives."""
+    name = "novit_d256_2w3s"
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    errs = {}
+    for dd in ("f16x2", torch.float32, None):
+        lam = Lam(case["cfg"], seed=case["weight_seed"], decoder_dtype=dd).cuda()
+        lam.selected_rows = gold.get("selected_rows")
+        errs[dd] = rel_err(lam(batch)["logits"], gold["logits"])
+    assert errs["f16x2"] <= 2e-5 and errs[torch.float32] <= 2e-5
+    assert errs[None] > 20 * errs["f16x2"]                   # the single 16-bit plane is the coarse one
+
+
 def test_predict_with_cached_class_embeddings_matches_forward():
     """generate_class_embeddings + predict == forward for the same episode (lam.py:349-381)."""
     case = CASES["novit_d256_2w3s"]
