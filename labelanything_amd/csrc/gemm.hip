@@ -1267,11 +1267,58 @@ __device__ __noinline__ void vt_store_slow(T* vt, size_t colbase, size_t bstride
 }
 
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_wave(char* slab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M, const LaGemmEpilogue& e,
-                                              int lane) {
+__device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M,
+                                              const LaGemmEpilogue& e, int lane) {
   const int fr = lane & 31, fh = lane >> 5;
   const float bias0 = e.bias ? e.bias[col0 + fr] : 0.f, bias1 = e.bias ? e.bias[col0 + 32 + fr] : 0.f;
-  if (EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0) {
+  const bool vtile = EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0;
+  constexpr unsigned NOROW = 0xffffffffu;
+  if (EPI == 1 && rtab != nullptr) {
+    // output row map (LA_MAP_WINDOW_PART: image-order GEMM rows scattered into window order): the wave tabulates the destination
+    // of its 128 rows once - the row itself, or for a V^T tile the position b * (heads * hd * Tpad) + slot of the token
+    const RowMap rm{e.map, e.p0, e.p1, e.p2, e.p3, e.p4};
+    const unsigned bstride = (unsigned)(e.vt_heads * e.vt_hd * e.vt_Tpad);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int rr = lane + 64 * k, row = row0 + rr;
+      const int d = row < M ? map_row(rm, row) : -1;
+      unsigned v = NOROW;
+      if (d >= 0) v = vtile ? (unsigned)(d / e.vt_T) * bstride + (unsigned)vt_slot(d % e.vt_T, e.vt_ws) : (unsigned)d;
+      rtab[rr] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (vtile && rtab != nullptr) {
+    T* vt = reinterpret_cast<T*>(e.vt);
+    const int cv0 = col0 + fr - e.vt_col0, cv1 = cv0 + 32;
+    const size_t cb0 = (size_t)((cv0 / e.vt_hd) * e.vt_hd + cv0 % e.vt_hd) * e.vt_Tpad;
+    const size_t cb1 = (size_t)((cv1 / e.vt_hd) * e.vt_hd + cv1 % e.vt_hd) * e.vt_Tpad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int rb = i * 32 + 8 * g4 + 4 * fh;
+        const unsigned p0 = rtab[rb], p1 = rtab[rb + 1], p2 = rtab[rb + 2], p3 = rtab[rb + 3];
+        const bool fast = p0 != NOROW && p3 == p0 + 3 && (p0 & 3) == 0 && (e.vt_Tpad & 3) == 0;   // 4 tokens in consecutive, 8-byte aligned slots
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          const float bias = tj ? bias1 : bias0;
+          const float v0 = acc[i][tj][g4 * 4] + bias, v1 = acc[i][tj][g4 * 4 + 1] + bias, v2 = acc[i][tj][g4 * 4 + 2] + bias,
+                      v3 = acc[i][tj][g4 * 4 + 3] + bias;
+          T* cp = vt + (tj ? cb1 : cb0);
+          if (fast) {
+            store4v<T>(cp + p0, v0, v1, v2, v3);
+          } else {
+            if (p0 != NOROW) cp[p0] = (T)v0;
+            if (p1 != NOROW) cp[p1] = (T)v1;
+            if (p2 != NOROW) cp[p2] = (T)v2;
+            if (p3 != NOROW) cp[p3] = (T)v3;
+          }
+        }
+      }
+    return;
+  }
+  if (vtile) {
     // V^T columns: a lane owns one column, registers 4 g .. 4 g + 3 are 4 consecutive tokens -> one 8-byte store into
     // vt[(b, head, d)][slot] when the quad stays inside a window row.  (b, t) of the quad's first token is carried along
     // incrementally (rows advance by 8 per quad): no division in the unrolled body.
@@ -1356,7 +1403,12 @@ __device__ __forceinline__ void epilogue_wave(char* slab, f32x16 (&acc)[4][2], i
           const int sr = rrow + 8 * j;
           const uint4 v = *reinterpret_cast<const uint4*>(slab + sr * 128 + ((rch ^ (sr & 7)) << 4));
           const int row = row0 + i * 32 + h * 16 + sr;
-          if (row < M) *reinterpret_cast<uint4*>(out + (size_t)row * e.ld16 + col0 + rch * 8) = v;
+          if (EPI == 1 && rtab != nullptr) {
+            const unsigned d = rtab[i * 32 + h * 16 + sr];
+            if (d != NOROW) *reinterpret_cast<uint4*>(out + (size_t)d * e.ld16 + col0 + rch * 8) = v;
+          } else if (row < M) {
+            *reinterpret_cast<uint4*>(out + (size_t)row * e.ld16 + col0 + rch * 8) = v;
+          }
         }
       }
     return;
@@ -1426,6 +1478,11 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
   const int fr = lane & 31, fh = lane >> 5;
   const int ntn = N / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
   char* slab = smem + NST * STAGE + wave * 2048;
+  // destination-row table of a mapped epilogue (512 B per wave): behind the slabs when the ring leaves room (one plane), else the
+  // wave's own slab - two planes are only mapped when every tile is a V^T tile, which never touches the slab (host side)
+  unsigned* rtab = nullptr;
+  if (EPI == 1 && e.map != LA_MAP_NONE)
+    rtab = reinterpret_cast<unsigned*>(NPL == 1 ? smem + NST * STAGE + 8 * 2048 + wave * 512 : slab);
 
   // DMA plan of a tile: operand o (0 = A, 1 = W_hi, 2 = W_lo), piece i of this wave = tile rows [(wave + 8 i) 16, +16)
   auto plan = [&](int tile, unsigned (&so)[1 + NPL][2], int& m0, int& n0) {
@@ -1539,7 +1596,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
     // Interval plan at a seam (| = barrier):   group 0   M(nk-1) | E      | L'(0) | M'(0) | ...
     //                                          group 1   L(nk-1) | M(nk-1) E | -  | L'(0) | ...
     // i.e. both epilogues run side by side (they are latency-, not issue-bound) and the one-interval stagger is restored after it. ----
-    epilogue_wave<T, EPI>(slab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane);
+    epilogue_wave<T, EPI>(slab, rtab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane);
     seam_slack = (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0);
     bar();
     if (!more) break;
@@ -1562,7 +1619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
 
 template <typename T, int NPL, int EPI>
 static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-  constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768) + 8 * 2048;      // ring + one 2 KiB slab per wave (144 / 160 KiB)
+  constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768 + 8 * 512) + 8 * 2048;      // ring + 2 KiB slab per wave (+ row tables): 148 / 160 KiB
   static unsigned long long attr_mask = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), LDS, attr_mask);
   static int ncu = 0;                                // (the GPUs of one host are the same part)
@@ -1595,6 +1652,11 @@ static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, i
   static const char* nop = getenv("LA_GEMM_NO_PERSISTENT");
   const bool al = (N % 256) == 0 && K / 32 >= 8 && !nop && (e.ld16 % 8) == 0;
   if (al && plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
+  // qkv of a SAM window block from image-order tokens: rows scattered into window order by the epilogue (no padded rows multiplied)
+  const bool scatter = e.map == LA_MAP_WINDOW_PART && e.res_mod == 0 && e.amap == LA_MAP_NONE && e.act == LA_ACT_NONE && !e.res && !e.out32 &&
+                       e.out16 && (NPL == 1 || (e.vt && e.vt_col0 == 0)) &&
+                       (!e.vt || (size_t)((M + e.vt_T - 1) / e.vt_T + 4096) * e.vt_heads * e.vt_hd * e.vt_Tpad < (1ull << 32));
+  if (al && scatter) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) return launch_t256p<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_NONE && e.res && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (e.ldr % 4) == 0)
     return launch_t256p<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);

@@ -12,6 +12,8 @@ PyTorch is used for device memory, views/copies and the host-side prompt bookkee
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, Optional, Tuple
 
@@ -186,15 +188,17 @@ class LamEngine:
             return
         self._hw(key, t, "qkv")
 
-    def qkv_gemm(self, x: Tensor, key: str, qkv: Tensor, vt: Tensor, ea: int, **vtkw) -> None:
+    def qkv_gemm(self, x: Tensor, key: str, qkv: Tensor, vt: Tensor, ea: int, rowmap=None, **vtkw) -> None:
         """qkv[:, :2 ea] = q, k rows of x W^T + b; V goes transposed to vt (la_gemm vt epilogue) - one launch, or two when only the V
-        rows of the weight carry a second plane."""
+        rows of the weight carry a second plane.  rowmap = (map, p): output row map of both (image-order tokens -> window order)."""
         b = self.p[key[:-2] + ".b"]
+        mkw = {} if rowmap is None else {"map": rowmap[0], "p": rowmap[1]}
         if (key + ".qk") in self.p:
-            L.gemm(x, self.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea])
-            L.gemm(x, self.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], vt=vt, vt_col0=0, a_kmod=self.kmod.get(key + ".v", 0), **vtkw)
+            L.gemm(x, self.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea], **mkw)
+            L.gemm(x, self.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], vt=vt, vt_col0=0, a_kmod=self.kmod.get(key + ".v", 0),
+                   **vtkw, **mkw)
         else:
-            self.gemm_w(x, key, bias=b, out16=qkv, vt=vt, vt_col0=2 * ea, **vtkw)
+            self.gemm_w(x, key, bias=b, out16=qkv, vt=vt, vt_col0=2 * ea, **vtkw, **mkw)
 
     def _patch_weight(self, pw: Tensor) -> Tensor:
         """Patch-embed weight [dim, 3 p p]: plain 16-bit; or, in the split-precision group "patch", fp16 plane triples
@@ -476,16 +480,41 @@ class LamEngine:
             else:
                 nb, t, gg = bn * nwy * nwy, ws * ws, ws
                 arows = nb * t
-                xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g)
             win16 = (not is_global) and gg <= 16      # windows: V^T / K in 16-wide padded slot order (LA_ATTN_RELPOS_WIN16)
             tpad = _ceil(16 * gg, 64) if win16 else _ceil(t, 64)
             tag = "g" if is_global else "w"
-            # (Producing the window-ordered q / k / V^T straight from the image-order tokens with LA_MAP_WINDOW_PART would skip
-            # the 16 % padded rows here too, but it breaks the V^T stores into 14-token runs and measured slower.)
-            qkv = self.buf("enc.qkv." + tag, (arows, 3 * ea))
-            vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
-            self.qkv_gemm(xin, bp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
+            # Window blocks whose qkv weight is one plane (at most the V rows carry a second one): the GEMMs walk the REAL tokens in
+            # image order and their epilogue scatters q / k rows and V^T slots into window order (LA_MAP_WINDOW_PART) - the padded
+            # tokens (16 % of the rows at 64 x 64 / 14) are never multiplied.  Their q / k / v are the bias (pad-after-norm), constant
+            # per block: every window block owns its buffers, filled once when they are created.
+            scatter = win16 and "qkv" not in self.precise and arows > rows and not os.environ.get("LA_NO_WINDOW_SCATTER")
+            if is_global:
+                pass
+            elif scatter:
+                xin = x16
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin)
+            else:
+                xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g)
+            if scatter:
+                qb = p[bp + ".qkv.b"]
+
+                def fill_qk(tq, qb=qb):
+                    tq[:, : 2 * ea] = qb[: 2 * ea].to(tq.dtype)
+
+                def fill_v(tv, qb=qb):
+                    tv.zero_()
+                    tv.view(nb, heads, hdp, tpad)[..., : 16 * gg].view(nb, heads, hdp, gg, 16)[..., :gg] = \
+                        qb[2 * ea:].view(1, heads, hdp, 1, 1).to(tv.dtype)
+
+                qkv = self.arena.get(f"enc.qkv.w{i}", (arows, 3 * ea), self.dt, False, fill_qk)
+                vt = self.arena.get(f"enc.vt.w{i}", (nb * heads, hdp, tpad), self.dt, False, fill_v)
+                self.qkv_gemm(xin, bp + ".qkv.w", qkv, vt, ea, rowmap=(L.MAP_WINDOW_PART, (ws, nwy, nwy, g, g)), vt_T=t, vt_Tpad=tpad,
+                              vt_hd=hdp, vt_heads=heads, vt_ws=gg)
+            else:
+                qkv = self.buf("enc.qkv." + tag, (arows, 3 * ea))
+                vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
+                self.qkv_gemm(xin, bp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
             ao = self.buf("enc.ao." + tag, (arows, ea))
             if win16:
                 L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16,

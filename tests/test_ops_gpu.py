@@ -597,6 +597,54 @@ def test_gemm_persistent_256x256_epilogues(L, dt, planes):
     assert rel_err(vt, ref[:, 2 * e:].view(nb, t, heads, 64).permute(0, 2, 3, 1).reshape(nb * heads, 64, t)) < tol
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_persistent_window_scatter(L, dt):
+    """qkv of a SAM window block from IMAGE-order tokens (LA_MAP_WINDOW_PART as output map in gemm_t256p_kernel): the q / k rows land in
+    window order, V^T in 16-slot order, the padded positions are never written (they hold the bias, filled once by the host) - as one
+    one-plane launch over q | k | v, and as the one-plane q / k launch + two-plane V launch of the default numerics."""
+    b, h, ws, e, heads = 4, 64, 14, 768, 12
+    nwy = -(-h // ws)
+    nb, t = b * nwy * nwy, ws * ws
+    rows, arows = b * h * h, nb * t
+    tpad = (16 * ws + 63) // 64 * 64
+    x = rnd(rows, e, seed=90).to(dt)
+    w32 = rnd(3 * e, e, seed=91) / math.sqrt(e)
+    bias = rnd(3 * e, seed=92) * 0.1
+    fill = 7.0
+    hi = w32.to(dt)
+    lo = (w32 - hi.float()).to(dt)
+
+    def check(qkv, vt, wref):
+        ref = (x.float() @ wref.t() + bias).view(b, h, h, 3 * e)
+        pad = torch.full((b, nwy * ws, nwy * ws, 3 * e), fill, device="cuda")
+        pad[:, :h, :h] = ref
+        win = pad.view(b, nwy, ws, nwy, ws, 3 * e).permute(0, 1, 3, 2, 4, 5).reshape(arows, 3 * e)
+        assert rel_err(qkv[:, : 2 * e], win[:, : 2 * e]) < TOL16[dt]
+        assert bool((qkv[:, 2 * e:] == fill).all())
+        v = win[:, 2 * e:].view(nb, ws, ws, heads, 64).permute(0, 3, 4, 1, 2)
+        slots = vt.view(nb, heads, 64, tpad)[..., : 16 * ws].reshape(nb, heads, 64, ws, 16)
+        assert rel_err(slots[..., :ws], v) < TOL16[dt]
+        assert bool((slots[..., ws:] == fill).all()) and bool((vt.view(nb, heads, 64, tpad)[..., 16 * ws:] == fill).all())
+
+    kw = dict(vt_T=t, vt_Tpad=tpad, vt_hd=64, vt_heads=heads, vt_ws=ws, map=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, h, h))
+    # one plane, q | k | v in one launch
+    qkv = torch.full((arows, 3 * e), fill, device="cuda", dtype=dt)
+    vt = torch.full((nb * heads, 64, tpad), fill, device="cuda", dtype=dt)
+    L.gemm(x, hi.contiguous(), bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, **kw)
+    torch.cuda.synchronize()
+    check(qkv, vt, hi.float())
+    # q / k one plane + V two planes
+    qkv = torch.full((arows, 3 * e), fill, device="cuda", dtype=dt)
+    vt = torch.full((nb * heads, 64, tpad), fill, device="cuda", dtype=dt)
+    L.gemm(x, hi[: 2 * e].contiguous(), bias=bias[: 2 * e], out16=qkv[:, : 2 * e], map=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, h, h))
+    wv = torch.cat([hi[2 * e:], lo[2 * e:]], dim=1).contiguous()
+    L.gemm(x, wv, bias=bias[2 * e:], out16=qkv[:, 2 * e:], vt=vt, vt_col0=0, a_kmod=e, **kw)
+    torch.cuda.synchronize()
+    wref = hi.float().clone()
+    wref[2 * e:] += lo[2 * e:].float()
+    check(qkv, vt, wref)
+
+
 def _planes(w):
     hi = w.to(torch.float16)
     return hi.contiguous(), (w - hi.float()).to(torch.float16).contiguous()
