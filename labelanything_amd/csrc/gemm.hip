@@ -1879,6 +1879,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_COLS;
   if (n0 >= N) return;
+  // blockIdx.y: chunk of MR rows (a few hundred token rows - many prompt pairs - are still far too few for an MFMA tile grid:
+  // 240 x 256 x 2048 is FOUR 128 x 128 tiles; here it is 8 x 16 workgroups re-streaming a 2 MB weight from L2)
+  const int m_base = blockIdx.y * MR;
+  A += (size_t)m_base * lda;
+  M -= m_base;
   float acc[MR][SK_COLS];
 #pragma unroll
   for (int m = 0; m < MR; ++m)
@@ -1919,8 +1924,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int idx = r * 64 + lane;
-    const int m = idx / SK_COLS, col = n0 + idx % SK_COLS;
-    if (m < M && m < MR && col < N) {
+    const int ml = idx / SK_COLS, col = n0 + idx % SK_COLS;
+    if (ml < M && ml < MR && col < N) {
+      const int m = m_base + ml;
       float v = mine[r] + (e.bias ? e.bias[col] : 0.f);
       if (e.act == LA_ACT_GELU) v = gelu_erf(v);
       else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
@@ -1934,7 +1940,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 template <typename T>
 static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   const int waves = (N + SK_COLS - 1) / SK_COLS;
-  const dim3 grid((waves + 3) / 4), block(256);
+  const dim3 grid((waves + 3) / 4, M > 32 ? (M + 31) / 32 : 1), block(256);
   const T* a = reinterpret_cast<const T*>(A);
   const T* w = reinterpret_cast<const T*>(W);
   if (M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<T, 8>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
@@ -1970,7 +1976,10 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
                epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool skinny = (M <= 32) && (K % 8) == 0 && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && !epi->vt;
+  // up to 512 fp32 rows (decoder tokens of many prompt pairs) still go row-chunked through the VALU kernel: an MFMA tile grid of a
+  // handful of workgroups leaves the chip idle (240 x 256 x 2048: 155 us on four 128 x 128 tiles)
+  const bool few_rows = M <= 32 || (dt == LA_F32 && M <= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64);
+  const bool skinny = few_rows && (K % 8) == 0 && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && !epi->vt;
   if (skinny) {
     if (dt == LA_F32) la::launch_skinny<float>(A, lda, W, ldw, M, N, K, *epi, st);
     else if (dt == LA_F16) la::launch_skinny<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
