@@ -218,8 +218,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 16: throughput grows 178 -> "
-                    "301 -> 306 -> 310 episodes/s for 1 / 8 / 16 / 32: profiles/r01_gemm_ablation.md)")
+    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 16, kept for comparability with round 1; same box, round 2: "
+                    "302 / 309 / 312 / 316 episodes/s at 16 / 24 / 32 / 48)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the BASELINE metric (default); the others are "
                     "extra data points with the geometry of the other BASELINE configs")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
