@@ -6,15 +6,27 @@ import torch
 from labelanything_amd import _lib as L
 which = sys.argv[1] if len(sys.argv) > 1 else "lin2"
 dt = torch.float16
-shapes = {"lin2": (65536, 768, 3072), "lin1": (65536, 3072, 768), "qkv": (65536, 2304, 768)}      # 16-image encoder batch
+shapes = {"lin2": (131072, 768, 3072), "lin1": (131072, 3072, 768), "qk": (131072, 1536, 768), "v2": (131072, 768, 768)}   # 32-image encoder batch
 if which in shapes:
     m, n, k = shapes[which]
     a = torch.randn(m, k, device="cuda").to(dt)
-    w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(dt)
+    w32 = torch.randn(n, k, device="cuda") / math.sqrt(k)
+    w = w32.to(dt)
     bias = torch.randn(n, device="cuda")
     o16 = torch.empty(m, n, device="cuda", dtype=dt)
-    for _ in range(5):
-        L.gemm(a, w, bias=bias, out16=o16)
+    res = torch.zeros(m, n, device="cuda") if which == "lin2" else None
+    vt = torch.zeros((m // 4096) * 12, 64, 4096, device="cuda", dtype=dt) if which == "v2" else None
+    if which == "v2":
+        w = torch.cat([w, (w32 - w.float()).to(dt)], dim=1).contiguous()
+    for _ in range(5):                                   # the epilogues the model uses
+        if which == "lin1":
+            L.gemm(a, w, bias=bias, out16=o16, act=L.ACT_GELU)
+        elif which == "lin2":
+            L.gemm(a, w, bias=bias, res=res, out32=res)
+        elif which == "v2":
+            L.gemm(a, w, bias=bias, out16=o16, vt=vt, vt_col0=0, vt_T=4096, vt_Tpad=4096, vt_hd=64, vt_heads=12, a_kmod=k)
+        else:
+            L.gemm(a, w, bias=bias, out16=o16)
 else:
     b, heads, g = 8, 12, 64
     t_ = g * g; e = heads * 64

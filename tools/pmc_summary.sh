@@ -1,14 +1,14 @@
 #!/bin/bash
 # SQ / LDS counters of the three dominant kernels, one counter group per rocprofv3 pass (no other trace domains).
-#   gpurun --timeout 1500 -- 'bash tools/pmc_summary.sh r01'   ->  gpurun_out/<round>_pmc_summary.txt
+#   gpurun --timeout 1500 -- 'bash tools/pmc_summary.sh r02'   ->  gpurun_out/<round>_pmc_summary.txt
 set -u
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_$R
 mkdir -p $OUT
 SUM=gpurun_out/${R}_pmc_summary.txt
 : > $SUM
-for w in lin1 lin2 attn; do
+for w in lin1 lin2 qk v2 attn; do
   i=0
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
              "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
