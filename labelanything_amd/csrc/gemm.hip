@@ -1266,6 +1266,11 @@ __device__ __noinline__ void vt_store_slow(T* vt, size_t colbase, size_t bstride
   }
 }
 
+// chunk swizzle of the 16-bit epilogue slab: one store instruction writes rows k (even lanes) and k + 1 (odd lanes) at the SAME
+// four chunks; a 128-byte row spans all banks, so the two rows must land in different halves of it (bit 2), the row pairs in
+// different chunks of the half (bits 0-1).  (r & 7 put both rows on the same banks: 2-way conflicts, 9 % of the LDS cycles.)
+__device__ __forceinline__ int slab_swz(int r) { return ((r & 1) << 2) | ((r >> 1) & 3); }
+
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M,
                                               const LaGemmEpilogue& e, int lane) {
@@ -1368,7 +1373,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
     return;
   }
   if (EPI == 1 || EPI == 2) {
-    // 16-bit output.  Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ (r & 7).  Lane pairs (fr, fr ^ 1) trade one
+    // 16-bit output.  Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ slab_swz(r).  Lane pairs (fr, fr ^ 1) trade one
     // value per register pair over DPP: the even lane ends up with columns (c, c + 1) of row k, the odd lane with the same columns
     // of row k + 1 - one 32-bit LDS store each.
     T* out = reinterpret_cast<T*>(e.out16);
@@ -1395,13 +1400,13 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
               const float y = dpp_mov<0xB1>(odd ? a : b);
               const uint32_t w = odd ? pack2<T>(y, b) : pack2<T>(a, y);
               const int srow = 2 * kp + (odd ? 1 : 0) + 8 * q + 4 * fh;
-              *reinterpret_cast<uint32_t*>(slab + srow * 128 + (((c >> 3) ^ (srow & 7)) << 4) + (c & 7) * 2) = w;
+              *reinterpret_cast<uint32_t*>(slab + srow * 128 + (((c >> 3) ^ slab_swz(srow)) << 4) + (c & 7) * 2) = w;
             }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int sr = rrow + 8 * j;
-          const uint4 v = *reinterpret_cast<const uint4*>(slab + sr * 128 + ((rch ^ (sr & 7)) << 4));
+          const uint4 v = *reinterpret_cast<const uint4*>(slab + sr * 128 + ((rch ^ slab_swz(sr)) << 4));
           const int row = row0 + i * 32 + h * 16 + sr;
           if (EPI == 1 && rtab != nullptr) {
             const unsigned d = rtab[i * 32 + h * 16 + sr];
