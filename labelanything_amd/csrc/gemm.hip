@@ -1878,14 +1878,20 @@ template <typename T> struct Load8 {
 
 constexpr int SK_COLS = 4;
 
-template <typename T, int MR>
+template <typename T, int MR, int KW>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw, int M, int N,
                                                           int K, LaGemmEpilogue e) {
-  const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SK_COLS;
-  if (n0 >= N) return;
+  // A wave owns SK_COLS output columns x MR rows over a share of K; lanes split a 512-wide k-slab (8 values each).
+  //   KW = 1 (short K): the four waves of a workgroup take four column groups, each walks all of K;
+  //   KW = 4 (K >= 1024): the four waves share ONE column group and take the k-slabs w, w + 4, ... - with K <= 2048 a single batch of
+  //                        loads and MR * 32 FMAs per lane instead of a four-deep serial loop.
+  // Partials are folded inside 16-lane rows with DPP (no ds_bpermute chains); the 4 rows (x 4 waves) of every output meet in LDS
+  // and are summed in a fixed order.
+  __shared__ float part[4][MR * SK_COLS][5];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (KW == 4 ? blockIdx.x : blockIdx.x * 4 + wave) * SK_COLS;
   // blockIdx.y: chunk of MR rows (a few hundred token rows - many prompt pairs - are still far too few for an MFMA tile grid:
-  // 240 x 256 x 2048 is FOUR 128 x 128 tiles; here it is 8 x 16 workgroups re-streaming a 2 MB weight from L2)
+  // 240 x 256 x 2048 is FOUR 128 x 128 tiles; here it is 8 chunks x 64 workgroups re-streaming a 2 MB weight from L2)
   const int m_base = blockIdx.y * MR;
   A += (size_t)m_base * lda;
   M -= m_base;
@@ -1894,45 +1900,48 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
   for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int c = 0; c < SK_COLS; ++c) acc[m][c] = 0.f;
-  for (int k = lane * 8; k < K; k += 512) {
-    float w[SK_COLS][8];
+  if (n0 < N) {
+    for (int k = (KW == 4 ? wave * 512 : 0) + lane * 8; k < K; k += KW * 512) {
+      float w[SK_COLS][8];
 #pragma unroll
-    for (int c = 0; c < SK_COLS; ++c) Load8<T>::ld(Wt + (size_t)min(n0 + c, N - 1) * ldw + k, w[c]);
-    // no "if (m < M)" around the loads: hipcc would branch around every load and wait for each one in turn (one full memory
-    // latency per row); rows >= M re-read row M-1 and are simply not stored.
+      for (int c = 0; c < SK_COLS; ++c) Load8<T>::ld(Wt + (size_t)min(n0 + c, N - 1) * ldw + k, w[c]);
+      // no "if (m < M)" around the loads: hipcc would branch around every load and wait for each one in turn (one full memory
+      // latency per row); rows >= M re-read row M-1 and are simply not stored.
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      float x[8];
-      Load8<T>::ld(A + (size_t)min(m, M - 1) * lda + k, x);
+      for (int m = 0; m < MR; ++m) {
+        float x[8];
+        Load8<T>::ld(A + (size_t)min(m, M - 1) * lda + k, x);
 #pragma unroll
-      for (int c = 0; c < SK_COLS; ++c)
+        for (int c = 0; c < SK_COLS; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(x[j], w[c][j], acc[m][c]);
+          for (int j = 0; j < 8; ++j) acc[m][c] = fmaf(x[j], w[c][j], acc[m][c]);
+      }
     }
   }
-  // reduce every (m, column) partial over the wave and hand output #idx to lane idx % 64, so the epilogue (bias / activation /
-  // residual loads / stores) runs ONCE, lane-parallel, instead of 4*MR times on lane 0 behind dependent scalar loads.
-  constexpr int ROUNDS = (MR * SK_COLS + 63) / 64;
-  float mine[ROUNDS];
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) mine[r] = 0.f;
-#pragma unroll
-  for (int m = 0; m < MR; ++m) {
+  for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int c = 0; c < SK_COLS; ++c) {
-      const float s = wave_sum(acc[m][c]);
-      const int idx = m * SK_COLS + c;
-      if (lane == (idx & 63)) mine[idx >> 6] = s;
+      const float r = row16_sum(acc[m][c]);
+      if ((lane & 15) == 0) part[wave][m * SK_COLS + c][lane >> 4] = r;
     }
-  }
+  __syncthreads();
   T* outT = reinterpret_cast<T*>(e.out16);
+  constexpr int OUTS = MR * SK_COLS * (KW == 4 ? 1 : 4);
+  for (int o = threadIdx.x; o < OUTS; o += 256) {
+    const int idx = o % (MR * SK_COLS), ow = o / (MR * SK_COLS);               // ow: owning wave (KW = 1 only)
+    const int ml = idx / SK_COLS;
+    const int col = (KW == 4 ? blockIdx.x : blockIdx.x * 4 + ow) * SK_COLS + idx % SK_COLS;
+    if (ml < M && col < N) {
+      float v = 0.f;
+      if (KW == 4) {
 #pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const int idx = r * 64 + lane;
-    const int ml = idx / SK_COLS, col = n0 + idx % SK_COLS;
-    if (ml < M && ml < MR && col < N) {
+        for (int w = 0; w < 4; ++w) v += (part[w][idx][0] + part[w][idx][1]) + (part[w][idx][2] + part[w][idx][3]);
+      } else {
+        v = (part[ow][idx][0] + part[ow][idx][1]) + (part[ow][idx][2] + part[ow][idx][3]);
+      }
       const int m = m_base + ml;
-      float v = mine[r] + (e.bias ? e.bias[col] : 0.f);
+      v += e.bias ? e.bias[col] : 0.f;
       if (e.act == LA_ACT_GELU) v = gelu_erf(v);
       else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
       if (e.res) v += e.res[(size_t)(e.res_mod ? m % e.res_mod : m) * e.ldr + col];
@@ -1942,15 +1951,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
   }
 }
 
+template <typename T, int KW>
+static void launch_skinny_kw(const T* a, int lda, const T* w, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  const int groups = (N + SK_COLS - 1) / SK_COLS;
+  const dim3 grid(KW == 4 ? groups : (groups + 3) / 4, M > 32 ? (M + 31) / 32 : 1), block(256);
+  if (M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<T, 8, KW>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+  else if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<T, 16, KW>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<T, 32, KW>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+}
+
 template <typename T>
 static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-  const int waves = (N + SK_COLS - 1) / SK_COLS;
-  const dim3 grid((waves + 3) / 4, M > 32 ? (M + 31) / 32 : 1), block(256);
   const T* a = reinterpret_cast<const T*>(A);
   const T* w = reinterpret_cast<const T*>(W);
-  if (M <= 8) hipLaunchKernelGGL((gemm_skinny_kernel<T, 8>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
-  else if (M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<T, 16>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<T, 32>), grid, block, 0, st, a, lda, w, ldw, M, N, K, e);
+  if (K >= 1024) launch_skinny_kw<T, 4>(a, lda, w, ldw, M, N, K, e, st);
+  else launch_skinny_kw<T, 1>(a, lda, w, ldw, M, N, K, e, st);
 }
 
 template <typename T>
