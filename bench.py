@@ -94,7 +94,7 @@ class KernelTimer:
         names = ["twoway_t2i", "twoway_i2t", "gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
                  "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
-                 "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step"]
+                 "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -129,6 +129,8 @@ class KernelTimer:
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
+                if _n == "gemm_tn" and self.by_shape:
+                    tag = f"gemm_tn[{a[0].shape[0]}x{a[0].shape[1]}x{a[1].shape[1]}]"
                 if _n == "attn_fwd" and self.by_shape:
                     tag = f"attn_fwd[{a[5]}x{a[6]}x{a[7]}]"
                 self.records.append((tag, flops, s, e, nbytes, issued if _n in ("gemm", "gemm_tn") else flops))

@@ -243,6 +243,10 @@ int la_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
  * atomic accumulation: the caller zero-fills or pre-loads dW). */
 int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream);
 
+/* out[N] += column sums of dY[M,N] (fp32): the bias gradient of nn.Linear / the conv layers (autograd of the `+ bias` in
+ * models/common.py, transformer.py, mask_decoder.py). */
+int la_colsum_acc(const float* dy, int ldy, long M, int N, float* out, void* stream);
+
 /* Backward of la_layernorm (nn.LayerNorm / LayerNorm2d common.py:42-54, optionally followed by GELU): x, dy fp32 [rows, E] contiguous ->
  * dx (written), dgamma / dbeta fp32 [E] (ACCUMULATED). */
 int la_layernorm_bwd(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,

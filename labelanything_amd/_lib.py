@@ -59,7 +59,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t",
 ]
 
@@ -330,6 +330,13 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
     k = x.shape[1]
     _check(lib().la_gemm_tn(_ptr(dy), C.c_int(n), _ptr(x), C.c_int(k), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n), C.c_int(k), _stream()),
            "la_gemm_tn")
+
+
+def colsum_acc(dy: torch.Tensor, out: torch.Tensor) -> None:
+    """out[N] += dy[M,N].sum(0)."""
+    _f32c(dy, out)
+    m, n = dy.shape
+    _check(lib().la_colsum_acc(_ptr(dy), C.c_int(n), C.c_long(m), C.c_int(n), _ptr(out), _stream()), "la_colsum_acc")
 
 
 def layernorm_bwd(x, dy, gamma, beta, eps: float, gelu: bool, dx, dgamma, dbeta) -> None:

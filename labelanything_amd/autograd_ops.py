@@ -3,7 +3,7 @@
 Training side of the hot path.  torch.autograd only records the graph and moves data (views, permutes, cat,
 index_select, expand); every arithmetic node of the prompt encoder / mask decoder / necks is one of the functions below:
 
-    linear        la_gemm (exact-fp32 MFMA)            bwd: la_gemm (dX), la_gemm_tn (dW, db)
+    linear        la_gemm (exact-fp32 MFMA)            bwd: la_gemm (dX), la_gemm_tn (dW), la_colsum_acc (db)
     layer_norm    la_layernorm                         bwd: la_layernorm_bwd           (nn.LayerNorm, LayerNorm2d in NHWC, +GELU)
     act           la_act_fwd                           bwd: la_act_bwd                 (GELU erf, ReLU)
     attention     la_attn_small                        bwd: la_attn_small_lse + la_attn_small_bwd
@@ -26,20 +26,6 @@ from torch.autograd import Function
 from . import _lib as L
 
 Tensor = torch.Tensor
-
-_ONES: Dict[tuple, Tensor] = {}
-
-
-def _ones(m: int, dev) -> Tensor:
-    key = (m, dev)
-    t = _ONES.get(key)
-    if t is None:
-        if len(_ONES) > 64:
-            _ONES.clear()
-        t = torch.ones(m, 1, device=dev)
-        _ONES[key] = t
-    return t
-
 
 def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
@@ -68,7 +54,7 @@ class _Linear(Function):
             L.gemm_tn(dy, x, dw)                             # dY^T . X
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.new_zeros(dy.shape[1], 1)
-            L.gemm_tn(dy, _ones(dy.shape[0], dy.device), db)  # column sums of dY
+            L.colsum_acc(dy, db)  # column sums of dY
             db = db.view(-1)
         return dx, dw, db
 
@@ -253,7 +239,7 @@ class _Conv3x3(Function):
             dw = dwk.view(cout, 3, 3, cin).permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.new_zeros(cout, 1)
-            L.gemm_tn(dy, _ones(dy.shape[0], dy.device), db)
+            L.colsum_acc(dy, db)
             db = db.view(-1)
         return dx, dw, db, None, None, None
 

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     cn[i] = min(n, N - 1);
     ck[i] = min(k, K - 1);
   }
-  for (int m = mbeg; m < mend; m += 8) {
-    float a[4][2], b[4][2];
+  // software pipeline: the 16 loads of the next 8 rows are in flight while the 16 MFMAs of the current 8 rows issue (with one
+  // iteration in flight the loop ran at one memory latency per 8 rows)
+  auto fetch = [&](int m, float (&a)[4][2], float (&b)[4][2]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = m + 2 * u + fh;
@@ -59,12 +60,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         b[u][i] = x[rc * ldx + ck[i]] * (vr * vk[i]);
       }
     }
+  };
+  auto mma = [&](const float (&a)[4][2], const float (&b)[4][2]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  };
+  float a0[4][2], b0[4][2], a1[4][2], b1[4][2];
+  fetch(mbeg, a0, b0);
+  for (int m = mbeg; m < mend; m += 16) {
+    fetch(m + 8, a1, b1);                            // (rows >= mend contribute zeros)
+    mma(a0, b0);
+    fetch(m + 16, a0, b0);
+    mma(a1, b1);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -78,6 +89,83 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         if (n < N) atomicAdd(&dw[(size_t)n * ldw + k], acc[i][j][r]);
       }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// out[n] += sum_m dY[m][n]: the bias gradient of every linear / conv layer.  (As a product with a ones vector through the 128 x 128
+// MFMA tiles above it cost as much as the weight gradient itself: 5 ms of a 41 ms training step.)  Threads are laid out
+// (rows_par x NW) with NW = the column count rounded up to a power of two (<= 256): coalesced row reads, per-thread partial sums
+// over a strided row set, LDS fold over the row lanes, one atomic per column and workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, int ldy, long M, int N, int nw, long rows_per_block,
+                                                     float* __restrict__ out) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int c = tid % nw, ty = tid / nw, rp = 256 / nw;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int cb = 0; cb < N; cb += nw) {
+    const int col = cb + c;
+    float acc = 0.f;
+    if (col < N) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four rows in flight per thread
+      long r = r0 + ty;
+      for (; r + 3L * rp < r1; r += 4L * rp) {
+        a0 += dy[(size_t)r * ldy + col];
+        a1 += dy[(size_t)(r + rp) * ldy + col];
+        a2 += dy[(size_t)(r + 2L * rp) * ldy + col];
+        a3 += dy[(size_t)(r + 3L * rp) * ldy + col];
+      }
+      for (; r < r1; r += rp) a0 += dy[(size_t)r * ldy + col];
+      acc = (a0 + a1) + (a2 + a3);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s2 = rp >> 1; s2 > 0; s2 >>= 1) {
+      if (ty < s2) red[tid] += red[tid + s2 * nw];
+      __syncthreads();
+    }
+    if (ty == 0 && col < N) atomicAdd(&out[col], red[tid]);
+    __syncthreads();
+  }
+}
+
+// dW[n][k] += sum_m dY[m][n] X[m][k] for tiny outputs (N, K <= 8: e.g. the 4 x 4 taps of a k = s conv over millions of pixels): every
+// thread keeps the whole N x K block over a strided row set, DPP row sums, one atomic per entry and 16-lane row.
+template <int NN, int KK>
+__global__ __launch_bounds__(256) void gemm_tn_tiny_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                           float* __restrict__ dw, int ldw, long M, int N, int K) {
+  float acc[NN][KK];
+#pragma unroll
+  for (int n = 0; n < NN; ++n)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[n][k] = 0.f;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+    float a[NN], b[KK];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) a[n] = n < N ? dy[(size_t)r * ldy + n] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) b[k] = k < K ? x[(size_t)r * ldx + k] : 0.f;
+#pragma unroll
+    for (int n = 0; n < NN; ++n)
+#pragma unroll
+      for (int k = 0; k < KK; ++k) acc[n][k] = fmaf(a[n], b[k], acc[n][k]);
+  }
+  __shared__ float red[16][NN * KK];
+#pragma unroll
+  for (int n = 0; n < NN; ++n)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      const float v = row16_sum(acc[n][k]);
+      if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][n * KK + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < NN * KK) {
+    const int n = threadIdx.x / KK, k = threadIdx.x % KK;
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += red[g][threadIdx.x];
+    if (n < N && k < K) atomicAdd(&dw[(size_t)n * ldw + k], v);      // one atomic per entry and workgroup
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -436,17 +524,40 @@ static int grid_for_n(long n) {
 extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream) {
   LA_CHECK_ARG(dy && x && dw, "la_gemm_tn: null pointer");
   LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && ldw >= K, "la_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
+  hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+  if (N <= 8 && K <= 8 && M >= 4096) {               // tiny output, long reduction
+    const int blocks = (int)(((long)M + 255) / 256 < 1024 ? ((long)M + 255) / 256 : 1024);
+    if (N <= 4 && K <= 4) hipLaunchKernelGGL((la::gemm_tn_tiny_kernel<4, 4>), dim3(blocks), dim3(256), 0, st0, dy, ldy, x, ldx, dw, ldw, (long)M, N, K);
+    else hipLaunchKernelGGL((la::gemm_tn_tiny_kernel<8, 8>), dim3(blocks), dim3(256), 0, st0, dy, ldy, x, ldx, dw, ldw, (long)M, N, K);
+    LA_CHECK_LAUNCH("la_gemm_tn");
+    return 0;
+  }
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
-  // enough M-chunks for ~2048 workgroups, chunks of at least 256 rows (multiple of 8)
-  int chunks = 2048 / (tiles_n * tiles_k);
+  // M-chunks: every chunk ends in one atomic per output element: ~1024 workgroups, at least 128 rows each (multiple of 16)
+  int chunks = 1024 / (tiles_n * tiles_k);
   if (chunks < 1) chunks = 1;
   int mchunk = (M + chunks - 1) / chunks;
-  if (mchunk < 256) mchunk = 256;
-  mchunk = (mchunk + 7) / 8 * 8;
+  if (mchunk < 128) mchunk = 128;
+  mchunk = (mchunk + 15) / 16 * 16;
   chunks = (M + mchunk - 1) / mchunk;
   hipLaunchKernelGGL(la::gemm_tn_kernel, dim3(tiles_n * tiles_k, chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, ldy, x, ldx,
                      dw, ldw, M, N, K, mchunk, tiles_k);
   LA_CHECK_LAUNCH("la_gemm_tn");
+  return 0;
+}
+
+extern "C" int la_colsum_acc(const float* dy, int ldy, long M, int N, float* out, void* stream) {
+  LA_CHECK_ARG(dy && out && M > 0 && N > 0 && ldy >= N, "la_colsum_acc: bad arguments M=%ld N=%d ldy=%d", M, N, ldy);
+  int nw = 1;
+  while (nw < N && nw < 256) nw <<= 1;
+  const int rp = 256 / nw;
+  // ~1024 workgroups, at least 64 rows per row lane
+  long rows_per_block = (M + 1023) / 1024;
+  if (rows_per_block < 64L * rp) rows_per_block = 64L * rp;
+  const long blocks = (M + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL(la::colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, ldy, M, N, nw,
+                     rows_per_block, out);
+  LA_CHECK_LAUNCH("la_colsum_acc");
   return 0;
 }
 
