@@ -129,6 +129,9 @@ class KernelTimer:
                 tag = _n
                 if _n == "gemm" and self.by_shape:
                     tag = f"gemm[{m}x{a[1].shape[0]}x{a[1].shape[1]},{str(a[0].dtype)[6:]}]"
+                if _n in ("attn_small_bwd", "attn_small", "attn_small_lse", "layernorm_bwd", "colsum_acc", "add_cast", "act_bwd", "act_fwd") and self.by_shape:
+                    shp = [x for x in a if isinstance(x, int)][:4]
+                    tag = f"{_n}{[tuple(a[0].shape)] + shp}"
                 if _n == "gemm_tn" and self.by_shape:
                     tag = f"gemm_tn[{a[0].shape[0]}x{a[0].shape[1]}x{a[1].shape[1]}]"
                 if _n == "attn_fwd" and self.by_shape:
@@ -303,7 +306,7 @@ def main():
             with KernelTimer(by_shape=True) as kt2:
                 lam(batch)
             for n, v in sorted(kt2.summary().items(), key=lambda kv: -kv[1][1]):
-                if n.startswith("gemm") or n.startswith("attn_fwd"):
+                if n.startswith("gemm") or n.startswith("attn") or n.startswith("layernorm_bwd") or n.startswith("colsum") or n.startswith("add_cast") or n.startswith("act_"):
                     print(f"{n:44s} x{v[0]:3d}  {v[1]*1e3:8.3f} ms  {v[2]/max(v[1],1e-12)/1e12:7.1f} TF/s", file=sys.stderr)
         g = agg.get("gemm")
         tot = sum(v[1] for v in agg.values())

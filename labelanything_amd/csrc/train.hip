@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       dv[v] = c < E ? dy[r * E + c] : 0.f;
       s += xv[v];
     }
-    const float mu = wave_sum(s) * inv_e;
+    const float mu = wave_sum_dpp(s) * inv_e;
     float q = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const float d = c < E ? xv[v] - mu : 0.f;
       q += d * d;
     }
-    const float rstd = rsqrtf(wave_sum(q) * inv_e + eps);
+    const float rstd = rsqrtf(wave_sum_dpp(q) * inv_e + eps);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       xv[v] = xh;
       dv[v] = g;
     }
-    s1 = wave_sum(s1) * inv_e;
-    s2 = wave_sum(s2) * inv_e;
+    s1 = wave_sum_dpp(s1) * inv_e;
+    s2 = wave_sum_dpp(s2) * inv_e;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = lane + 64 * v;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void attn_lse_kernel(AttnBwdArgs a, float* __r
     m = mn;
   }
   const float mw = wave_max(m);
-  l = wave_sum(l * expf(m - mw));
+  l = wave_sum_dpp(l * expf(m - mw));
   if (lane == 0) {
     red[0][wave] = mw;
     red[1][wave] = l;
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fewkeys_kernel(AttnBwdArgs a) {
       const float sel = (hh == h) ? 1.f : 0.f;
 #pragma unroll
       for (int d = 0; d < HDIM; ++d) {
-        const float gk = wave_sum(ds * qv[d] * sel);
-        const float gv = wave_sum(p * dov[d] * sel);
+        const float gk = wave_sum_dpp(ds * qv[d] * sel);
+        const float gv = wave_sum_dpp(p * dov[d] * sel);
         if ((threadIdx.x & 63) == 0) {
           atomicAdd(&a.dk[((size_t)b * a.Nk + j) * a.ldk + hh * HDIM + d], gk);
           atomicAdd(&a.dv[((size_t)b * a.Nk + j) * a.ldv + hh * HDIM + d], gv);
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fewqueries_kernel(AttnBwdArgs a)
     for (int d = 0; d < HDIM; ++d) {
       dvv[d] += p * dop[d];
       dkv[d] += ds * qp[d];
-      const float gq = wave_sum(ds * kv[d]);
+      const float gq = wave_sum_dpp(ds * kv[d]);
       if ((threadIdx.x & 63) == 0) atomicAdd(&a.dq[qrow * a.ldq + h * HDIM + d], gq);
     }
   }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void classify_bwd_kernel(const float* __restri
 #pragma unroll
     for (int d = 0; d < CF; ++d) {
       df[d] += g * pr[c * CF + d];
-      const float gp = wave_sum(g * f[d]);
+      const float gp = wave_sum_dpp(g * f[d]);
       if ((threadIdx.x & 63) == 0) atomicAdd(&dprotos[((size_t)b * C + c) * CF + d], gp);
     }
   }
