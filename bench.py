@@ -62,7 +62,7 @@ WORKLOADS = {
                             "neck + prompt encoder + mask decoder (10.14 M parameters), gradient all-reduce, AdamW",
                        model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                                   class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
-                       episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=1, train=True),
+                       episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=2, train=True),     # the reference batches 2-16 episodes (mae_noembs.yaml:94)
 }
 
 
