@@ -178,33 +178,50 @@ __global__ __launch_bounds__(256) void mask_embed_kernel(MaskEmbedArgs a) {
     }
   }
   __syncthreads();
+  // fold the four bilinear taps once per (pixel, hidden channel): the 1x1 conv below then reads 16 LDS values per output, not 64
+  if (valid)
+    for (int i = tid; i < ME_PIX * 16; i += 256) {
+      const int pl = i >> 4, o = i & 15;
+      hb[pl][0][o] = (hb[pl][0][o] + hb[pl][1][o]) + (hb[pl][2][o] + hb[pl][3][o]);
+    }
+  __syncthreads();
   const int c = p % a.C;
   const int sup = p / a.C;
   T* s16 = reinterpret_cast<T*>(a.src16);
   T* spe16 = reinterpret_cast<T*>(a.srcpe16);
-  for (int idx = tid; idx < ME_PIX * a.D; idx += 256) {
-    const int pl = idx / a.D, d = idx % a.D;
-    const int pix = pix0 + pl;
-    if (pix >= hw) break;
-    float v;
+  // a thread owns output channel d for every pixel of the block: its row of the 1x1 conv weight lives in registers
+  for (int d = tid; d < a.D; d += 256) {
+    float w6r[16];
+    float v0;                                        // value before the per-pixel terms: conv bias, or the "no mask" embedding
     if (valid) {
-      v = a.b6[d];
+      v0 = a.b6[d];
 #pragma unroll
-      for (int o = 0; o < 16; ++o) v += a.w6[d * 16 + o] * ((hb[pl][0][o] + hb[pl][1][o]) + (hb[pl][2][o] + hb[pl][3][o]));
+      for (int o = 0; o < 16; ++o) w6r[o] = a.w6[d * 16 + o];
     } else {
-      v = have_mask ? a.not_a_mask[d] : a.no_mask[d];
+      v0 = have_mask ? a.not_a_mask[d] : a.no_mask[d];
+#pragma unroll
+      for (int o = 0; o < 16; ++o) w6r[o] = 0.f;
     }
-    if (a.support) v += a.support[((size_t)sup * hw + pix) * a.D + d];
-    if (a.class_enc) v += a.class_enc[c * a.D + d];
-    const size_t o = ((size_t)p * hw + pix) * a.D + d;
-    a.src32[o] = v;
-    if (a.split) {
-      const size_t r2 = ((size_t)p * hw + pix) * 2 * a.D;
-      if (s16) store_split<T>(s16 + r2, a.D, d, v);
-      if (spe16) store_split<T>(spe16 + r2, a.D, d, v + a.pe[(size_t)pix * a.D + d]);
-    } else {
-      if (s16) s16[o] = (T)v;
-      if (spe16) spe16[o] = (T)(v + a.pe[(size_t)pix * a.D + d]);
+    for (int pl = 0; pl < ME_PIX; ++pl) {
+      const int pix = pix0 + pl;
+      if (pix >= hw) break;
+      float v = v0;
+      if (valid) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) v += w6r[o] * hb[pl][0][o];
+      }
+      if (a.support) v += a.support[((size_t)sup * hw + pix) * a.D + d];
+      if (a.class_enc) v += a.class_enc[c * a.D + d];
+      const size_t o = ((size_t)p * hw + pix) * a.D + d;
+      a.src32[o] = v;
+      if (a.split) {
+        const size_t r2 = ((size_t)p * hw + pix) * 2 * a.D;
+        if (s16) store_split<T>(s16 + r2, a.D, d, v);
+        if (spe16) store_split<T>(spe16 + r2, a.D, d, v + a.pe[(size_t)pix * a.D + d]);
+      } else {
+        if (s16) s16[o] = (T)v;
+        if (spe16) spe16[o] = (T)(v + a.pe[(size_t)pix * a.D + d]);
+      }
     }
   }
 }
