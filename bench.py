@@ -38,7 +38,7 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16
 WORKLOADS = {
     "cfg2": dict(desc="BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes (2 images each)",
                  model=dict(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False),
-                 episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=16),
+                 episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=32),
     "cfg1": dict(desc="BASELINE cfg1 geometry on the GPU: ViT-MAE-B 480px encoder + decoder, 1-way 1-shot episodes (2 images each)",
                  model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                             example_class_attention=False, custom_preprocess=False),
@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 16, kept for comparability with round 1; same box, round 2: "
+    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 32 = 64 images, 30 GB of the 288 GB; round 1 used 16; same box, round 2: "
                     "302 / 309 / 312 / 316 episodes/s at 16 / 24 / 32 / 48)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the BASELINE metric (default); the others are "
                     "extra data points with the geometry of the other BASELINE configs")
