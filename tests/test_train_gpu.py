@@ -187,3 +187,35 @@ def test_step_updates_weights_and_invalidates_the_engine():
     assert rel_err(after, fresh(batch)["logits"]) < 1e-6          # ... exactly as a freshly built model with the same weights does
     losses = [l0] + [float(tr.step(batch, gt)["loss"]) for _ in range(5)]
     assert losses[-1] < losses[0]                                 # and the objective goes down on the batch it is trained on
+
+
+@pytest.mark.parametrize("mnk", [(135000, 128, 256), (900, 256, 128), (150, 256, 2048), (300000, 4, 4), (70000, 7, 3), (4099, 33, 65)])
+def test_weight_gradient_gemm_tn_matches_torch(mnk):
+    """la_gemm_tn: dW += dY^T X on the 32x32x2 fp32 MFMA (row chunks folded with atomics) and, for tiny outputs over very long
+    reductions, on the VALU; accumulation into a pre-loaded dW."""
+    from labelanything_amd import _lib as L
+    m, n, k = mnk
+    g = torch.Generator().manual_seed(m + n)
+    dy = torch.randn(m, n, generator=g).cuda()
+    x = torch.randn(m, k, generator=g).cuda()
+    dw0 = torch.randn(n, k, generator=g).cuda()
+    dw = dw0.clone()
+    L.gemm_tn(dy, x, dw)
+    torch.cuda.synchronize()
+    ref = dw0.double() + dy.double().t() @ x.double()
+    assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("mn", [(135000, 128), (2457600, 4), (614400, 256), (150, 2048), (6, 256), (1000, 300)])
+def test_bias_gradient_colsum_matches_torch(mn):
+    """la_colsum_acc: out[n] += sum_m dY[m][n] (the bias gradient of every linear / conv layer)."""
+    from labelanything_amd import _lib as L
+    m, n = mn
+    g = torch.Generator().manual_seed(m * 3 + n)
+    dy = torch.randn(m, n, generator=g).cuda()
+    out0 = torch.randn(n, generator=g).cuda()
+    out = out0.clone()
+    L.colsum_acc(dy, out)
+    torch.cuda.synchronize()
+    ref = out0.double() + dy.double().sum(0)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
