@@ -218,6 +218,35 @@ def cpu_baseline(cfg, timed: int = 3):
                       f"{med:.1f} s per episode (all: {', '.join(f'{t:.1f}' for t in times)})"}
 
 
+def eager_baseline(cfg, dev, episodes: int = 8, warm: int = 2, it: int = 5):
+    """north_star's comparator ("the reference single-GPU PyTorch-eager images/sec"): the reference is not on the GPU box, so the
+    checked fp32 restatement of its eager torch op sequence (the oracle, pinned on the reference to 2e-6) runs ON this MI355X with
+    stock torch / rocBLAS / MIOpen kernels, outside the timed region like cpu_baseline.  A baseline leg only - never the product."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    sd = {k: v.to(dev) for k, v in init_state_dict(cfg, 2).items()}
+    geo = geometry_for(cfg)
+    batch = {k: v.to(dev) for k, v in make_episode(batch=episodes, n_ways=1, k_shots=1, image_size=1024, seed=1234, prompts=("mask",)).items()}
+    torch.set_default_device(dev)             # the restatement builds a few helper tensors on the default device
+    try:
+        with torch.no_grad():
+            for _ in range(warm):
+                O.lam_forward(sd, geo, batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(it):
+                O.lam_forward(sd, geo, batch)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / it
+    finally:
+        torch.set_default_device("cpu")
+    return {"value": round(episodes / dt, 3), "unit": "episodes/s", "images_per_sec": round(2 * episodes / dt, 2),
+            "kind": "torch-eager fp32 restatement of the reference's op sequence on the same MI355X (stock torch kernels)",
+            "sample": f"{warm} warm-up + {it} forwards of {episodes} episodes (2 images 1024x1024 each), {dt * 1e3:.1f} ms per forward"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +263,7 @@ def main():
                     "configuration, engine.resolve_precise), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
                     "or a comma list of groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the torch-eager-on-GPU comparator that fills vs_baseline (cfg2, 1 GPU)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
     a = ap.parse_args()
@@ -348,13 +378,19 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
-                       "episodes_per_step_per_gpu": a.episodes,
+                       "episodes_per_step_per_gpu": a.episodes, "global_episodes_per_step": a.episodes * world,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),
                        "parallelism": (f"data-parallel x{world}, one flat-gradient SUM all-reduce (RCCL) per step" if train else
                                        f"episode-sharded x{world}, no collective"),
-                       "launch": "eager" if a.no_graphs else "hipGraph replay"},
+                       "launch": "eager" if (a.no_graphs or train) else "hipGraph replay"},
             "roofline": roof, "kernels_ms_per_step": kernels,
         }
+        if world == 1 and not a.no_eager_baseline and a.workload == "cfg2":
+            # BASELINE.md publishes no number; north_star's target is stated against the reference's eager path on the same GPU
+            eb = eager_baseline(cfg, dev)
+            line["vs_baseline"] = round(eps / eb["value"], 2)
+            line["baseline_kind"] = eb["kind"]
+            line["eager_baseline"] = eb
         if world == 1 and not a.no_cpu_baseline and a.workload == "cfg2":
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -629,7 +629,7 @@ extern "C" int la_layernorm_bwd(const float* x, const float* dy, long rows, int 
   LA_CHECK_ARG(x && dy && gamma && beta && dx && dgamma && dbeta, "la_layernorm_bwd: null pointer");
   LA_CHECK_ARG(rows > 0 && E > 0 && E <= 2048, "la_layernorm_bwd: E=%d out of range (1..2048)", E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (E <= 4 && rows >= 65536) {                     // four channels over millions of pixels: one thread per (16-byte) row
+  if (E <= 32 && rows >= 65536) {                    // 4 / 16 / 32 channels over very many pixels (LayerNorm2d stacks): one thread per row
     long nb = (rows + 255) / 256;
     if (nb > 4096) nb = 4096;
     const dim3 g2((unsigned)nb), b2(256);

@@ -65,7 +65,7 @@ class Arena:
 #        block output (7.0e-4 with only Wv split, 6.7e-4 with all three);
 #   "patch", "neck": fp32-class products (fp16 plane pairs on both operands where the shape allows, exact-fp32 MFMA otherwise).
 # Which planes are worth their MFMA passes was measured on the golden cases (profiles/r02_parity_groups.log) AND over other weight /
-# episode seeds (tests/parity_seeds_gpu.py, profiles/r02_parity_seeds.log: the max-norm error moves by +-15 % with the seed; worst
+# episode seeds (tests/test_parity_seeds_gpu.py, profiles/r02_parity_seeds.log: the max-norm error moves by +-15 % with the seed; worst
 # stage, tolerance 1e-3).  The 768+-wide encoders of the BASELINE configs keep patch / v / proj / neck: 6.6-8.0e-4 over the seeds
 # tried (without proj 7.0-9.4e-4 - inside the tolerance on every seed tried, but with 6 % to spare, for 3 % of the step; lin2's
 # plane would buy another ~1e-4 for 8 %); encoders narrower than 512 keep the full qkv, proj and lin2 planes (cheap there, and

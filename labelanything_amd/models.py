@@ -177,9 +177,10 @@ class Lam(nn.Module):
             return bool((t != 0).any())          # device-resident flags: one host sync, as in the reference
         return bool(t.numpy().any())
 
-    def _prepare(self, batched_input: Dict[str, Any], with_prompts: bool = True, with_post: bool = True):
-        """Host side (lam.py:138-170, 214-239, 401-404): returns (device inputs, hashable plan)."""
-        eng = self.engine()
+    def _prepare(self, batched_input: Dict[str, Any], with_prompts: bool = True, with_post: bool = True, eng=None):
+        """Host side (lam.py:138-170, 214-239, 401-404): returns (device inputs, hashable plan).  ``eng``: the engine whose
+        host helpers to use (the trainer passes its own so that a training step never re-packs the inference weights)."""
+        eng = eng if eng is not None else self.engine()
         inp: Dict[str, torch.Tensor] = {}
         if "embeddings" in batched_input:
             emb = batched_input["embeddings"]

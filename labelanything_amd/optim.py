@@ -2,7 +2,8 @@
 HF's ``constant_with_warmup`` schedule (``experiment/utils.py:53-100``, ``parameters/trainval/coco20i/mae_noembs.yaml:32-37``)
 under DDP, i.e. one gradient all-reduce per optimizer step.  Here the learnable parameters live in ONE flat fp32 buffer (the
 model's tensors become views of it), so a step is: one SUM all-reduce of the flat gradient over RCCL (``sum_over_ranks``) + one
-``la_adamw_step`` launch that also applies the 1 / world scaling.  The backward pass that would fill the gradient is not built.
+``la_adamw_step`` launch that also applies the 1 / world scaling.  The gradient is written by ``train.LamTrainer``'s backward pass
+(autograd accumulates straight into ``grad_views``).
 """
 from __future__ import annotations
 
@@ -48,6 +49,8 @@ class FlatAdamW:
         self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.num_warmup_steps = int(num_warmup_steps)
         self.steps = 0                 # optimizer steps taken
+        self.tensor_steps = [0] * len(self.params)   # torch.optim.AdamW keeps state['step'] PER parameter: it only advances on
+        #                                              steps where the tensor has a gradient, and drives that tensor's bias correction
         self.sched_steps = 0           # scheduler steps taken (the reference steps it per batch: mae_noembs.yaml:36)
 
     @property
@@ -69,20 +72,28 @@ class FlatAdamW:
             world = torch.distributed.get_world_size()
             sum_over_ranks(self.grad)
         self.steps += 1
-        spans = [(0, self.flat.numel())]
-        if active is not None:
-            spans, off, cur = [], 0, None
-            for p, a in zip(self.params, active):
-                k = p.numel()
-                if a:
-                    cur = [off, off + k] if cur is None else [cur[0], off + k]
-                elif cur is not None:
-                    spans.append(tuple(cur))
-                    cur = None
-                off += k
-            if cur is not None:
+        if active is None:
+            active = [True] * len(self.params)
+        # contiguous runs of active tensors that share a step count -> one launch each
+        spans, off, cur = [], 0, None
+        for i, (p, a) in enumerate(zip(self.params, active)):
+            k = p.numel()
+            if a:
+                self.tensor_steps[i] += 1
+                t = self.tensor_steps[i]
+                if cur is not None and cur[2] == t:
+                    cur[1] = off + k
+                else:
+                    if cur is not None:
+                        spans.append(tuple(cur))
+                    cur = [off, off + k, t]
+            elif cur is not None:
                 spans.append(tuple(cur))
-        for a, b in spans:
+                cur = None
+            off += k
+        if cur is not None:
+            spans.append(tuple(cur))
+        for a, b, t in spans:
             L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.lr, self.betas[0], self.betas[1],
-                         self.eps, self.weight_decay, self.steps, 1.0 / world)
+                         self.eps, self.weight_decay, t, 1.0 / world)
         self.sched_steps += 1

@@ -37,8 +37,28 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
-def sum_over_ranks(t: torch.Tensor) -> torch.Tensor:
-    """SUM all-reduce (e.g. of a confusion matrix accumulated per rank, utils/metrics.py:28-51 in the reference)."""
+def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and dist.get_backend() == "gloo":
+            # gloo (CPU tests, and the two-processes-on-one-GPU tests) moves host memory: stage device tensors through the host
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
     return t
+
+
+def sum_over_ranks(t: torch.Tensor) -> torch.Tensor:
+    """SUM all-reduce, in place (the flat gradient; a confusion matrix accumulated per rank, utils/metrics.py:28-51 in the reference)."""
+    return _all_reduce(t, dist.ReduceOp.SUM)
+
+
+def any_over_ranks(flags: Sequence[bool], device=None) -> List[bool]:
+    """Element-wise OR of per-rank boolean flags (MAX all-reduce of a byte vector): what DDP's ``find_unused_parameters=True``
+    does with its used-parameter bitmap (experiment/run.py:123) - a parameter counts as used if ANY rank used it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [bool(f) for f in flags]
+    t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
+    _all_reduce(t, dist.ReduceOp.MAX)
+    return [bool(v) for v in t.cpu().tolist()]

@@ -25,6 +25,7 @@ from . import autograd_ops as A
 from .loss import FocalLossDevice
 from .models import Lam
 from .optim import FlatAdamW
+from .parallel import any_over_ranks
 
 Tensor = torch.Tensor
 
@@ -88,11 +89,12 @@ class _AddPerGroup(Function):
 
 
 class DecoderGraph:
-    def __init__(self, lam: Lam):
+    def __init__(self, lam: Lam, eng=None):
         self.lam = lam
         self.cfg = lam.cfg
         self.w: Dict[str, Tensor] = dict(lam.state_dict(keep_vars=True))
         self._pe: Dict[int, Tensor] = {}
+        self.eng = eng if eng is not None else lam.engine()      # host-side helpers only (sparse-token layout)
 
     # ---- building blocks -----------------------------------------------------------------------------------------------------
     def lin(self, name: str, x: Tensor) -> Tensor:
@@ -182,7 +184,7 @@ class DecoderGraph:
         return torch.where(missing, nam, dense.reshape(p, g * g, d)).reshape(p * g * g, d)
 
     def sparse_tokens(self, b: int, m: int, c: int, points, boxes) -> Tuple[Tensor, int]:
-        eng = self.lam.engine(validate=False)
+        eng = self.eng
         (xy, kind, shift), ns = eng._sparse_tokens(b, m, c, points, boxes)
         pe_ = "prompt_encoder"
         # only the rows a prompt type actually uses enter the graph: the reference never touches point_embeddings.2/3 without boxes,
@@ -333,6 +335,8 @@ class LamTrainer:
         for _, p in named:
             p.requires_grad_(True)
         self.names = [k for k, _ in named]
+        # "received a gradient since the last zero_grad()": OR-ed over the micro-steps of a gradient accumulation (the reference
+        # accumulates over substitution steps, experiment/run.py:503-527) and, in apply_update, over the ranks
         self._touched = [False] * len(named)
         for i, (_, p) in enumerate(named):
             p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._touched.__setitem__(_i, True))
@@ -341,15 +345,14 @@ class LamTrainer:
         for (_, p), gv in zip(named, self.opt.grad_views):
             p.grad = gv                      # autograd accumulates straight into the flat gradient buffer
         self.crit = loss or FocalLossDevice()
-        self.graph = DecoderGraph(lam)
         self.engine = lam.engine()           # frozen encoder: its packed weights never change
+        self.graph = DecoderGraph(lam, self.engine)
 
     def forward_backward(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
         lam = self.lam
-        self._touched = [False] * len(self.names)
         with torch.cuda.device(lam._device()):
             with torch.no_grad():
-                inp, _ = lam._prepare(batch, with_post=False)
+                inp, _ = lam._prepare(batch, with_post=False, eng=self.engine)
                 if "flag_gts" in batch:
                     inp["flag_gts"] = batch["flag_gts"].to(lam._device())
                 eng = self.engine
@@ -369,14 +372,25 @@ class LamTrainer:
             (loss / loss_normalizer).backward()
         return {"loss": loss.detach(), "logits": out["logits"].detach(), "class_examples_embeddings": out["class_examples_embeddings"].detach()}
 
+    def zero_grad(self) -> None:
+        self.opt.zero_grad()
+        self._touched = [False] * len(self.names)
+
     def apply_update(self) -> None:
-        """SUM all-reduce of the flat gradient over the ranks + the AdamW launch over the tensors that received a gradient (every
-        rank runs the same graph on the same prompt types per step, so the flags agree across ranks)."""
-        self.opt.step(active=list(self._touched))
+        """SUM all-reduce of the flat gradient over the ranks + the AdamW launches over the tensors that received a gradient ON ANY
+        RANK since the last ``zero_grad``.  Prompt types are sampled per episode (data/dataset.py:292), so one rank can see points
+        and another none: the flags are OR-ed over the ranks first (DDP ``find_unused_parameters=True`` all-reduces its
+        used-parameter bitmap the same way, experiment/run.py:123) - otherwise replicas of ``point_embeddings.*``,
+        ``not_a_point_embed``, ``mask_downscaling.*`` ... would step on some ranks only and drift apart."""
+        active = any_over_ranks(self._touched, device=self.lam._device())
+        self.opt.step(active=active)
+        self._touched = [False] * len(self.names)
+        # packed / converted weight copies of the inference engine are stale now; the trainer's own engine only serves the frozen
+        # encoder and host-side helpers, so nothing is re-packed until the model is next used for inference
+        self.lam.invalidate()
 
     def step(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
-        self.opt.zero_grad()
+        self.zero_grad()
         res = self.forward_backward(batch, gt, loss_normalizer)
         self.apply_update()
-        self.lam.invalidate()                # packed / converted weight copies of the inference engine are stale now
         return res

@@ -60,7 +60,7 @@ def test_episode_matches_reference_fixture(name, dt):
     # and equals the reference's argmax wherever the reference's top-2 margin is outside the tolerance band
     n_diff, n_real = argmax_disagreement(out["logits"], gold["argmax"].long(), ref_logits, margin_rel=ARGMAX_MARGIN[dt])
     assert n_real == 0, f"{n_real} of {n_diff} differing pixels have a reference margin above the tolerance band"
-    assert n_diff <= 0.02 * am.numel()
+    assert n_diff <= 0.005 * am.numel(), f"{n_diff} of {am.numel()} pixels flip inside the near-tie band"
     assert out["logits"].shape == (b, gold["class_embeddings"].shape[1], *gold["argmax"].shape[-2:])
 
 
@@ -220,8 +220,9 @@ def test_many_pairs_5way_5shot_matches_oracle():
     with torch.no_grad():
         ref = O.lam_forward(init_state_dict(cfg, 8), geometry_for(cfg), batch, selected_rows=rows)
     assert out["logits"].shape == (1, 6, 240, 240)
-    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
-    assert rel_err(out["logits"], ref["logits"]) < 4e-3
+    e_cls, e_log = rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]), rel_err(out["logits"], ref["logits"])
+    print(f"many-pair episode: class_examples_embeddings {e_cls:.3e}, logits {e_log:.3e} (north_star bound 1e-3)")
+    assert e_cls <= 1e-3 and e_log <= 1e-3, (e_cls, e_log)
 
 
 def _encoder_vs_oracle(cfg, bn, seed):
@@ -236,7 +237,9 @@ def _encoder_vs_oracle(cfg, bn, seed):
     with torch.no_grad():
         ref = O.sam_encoder(sd, geo, images) if cfg.encoder_spec.kind == "sam" else O.hf_vit_encoder(sd, geo, images)
     assert got.shape == ref.shape
-    return rel_err(got, ref)
+    e = rel_err(got, ref)
+    print(f"encoder {cfg.encoder} vs oracle: {e:.3e} (north_star bound 1e-3)")
+    return e
 
 
 def test_patch8_hf_encoder_matches_oracle():
@@ -244,14 +247,14 @@ def test_patch8_hf_encoder_matches_oracle():
     from labelanything_amd.config import LamConfig
     cfg = LamConfig(encoder="hf_tiny_p8", image_size=160, vit_patch_size=8, image_embed_dim=128, embed_dim=64, spatial_convs=3,
                     custom_preprocess=False)
-    assert _encoder_vs_oracle(cfg, 3, 21) < 2e-3
+    assert _encoder_vs_oracle(cfg, 3, 21) <= 1e-3
 
 
 def test_wide_sam_encoder_matches_oracle():
     """SAM ViT-L width (1024 channels, 16 heads of 64, 14x14 windows on a 28x28 grid, padded) through the same kernels."""
     from labelanything_amd.config import LamConfig
     cfg = LamConfig(encoder="sam_wide", image_size=448, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False)
-    assert _encoder_vs_oracle(cfg, 2, 22) < 2e-3
+    assert _encoder_vs_oracle(cfg, 2, 22) <= 1e-3
 
 
 def test_sam_vit_h_style_80_wide_heads_match_oracle():
@@ -261,10 +264,10 @@ def test_sam_vit_h_style_80_wide_heads_match_oracle():
     from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
     register_encoder("sam_hd80", EncoderSpec("sam", dim=160, depth=2, heads=2, mlp=320, img_size=448, global_idx=(1,), window=14, out_chans=64))
     cfg = LamConfig(encoder="sam_hd80", image_size=448, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
-    assert _encoder_vs_oracle(cfg, 2, 23) < 2e-3
+    assert _encoder_vs_oracle(cfg, 2, 23) <= 1e-3
     register_encoder("sam_hd80_1k", EncoderSpec("sam", dim=160, depth=2, heads=2, mlp=320, img_size=1024, global_idx=(1,), window=14, out_chans=64))
     cfg = LamConfig(encoder="sam_hd80_1k", image_size=1024, image_embed_dim=64, embed_dim=64, spatial_convs=3, custom_preprocess=False)
-    assert _encoder_vs_oracle(cfg, 1, 24) < 2e-3
+    assert _encoder_vs_oracle(cfg, 1, 24) <= 1e-3
 
 
 def test_hf_encoder_with_32_wide_heads_is_padded_to_64():
@@ -272,7 +275,7 @@ def test_hf_encoder_with_32_wide_heads_is_padded_to_64():
     from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
     register_encoder("hf_hd32", EncoderSpec("hf", dim=128, depth=2, heads=4, mlp=256, img_size=224))
     cfg = LamConfig(encoder="hf_hd32", image_size=160, image_embed_dim=128, embed_dim=64, spatial_convs=3, custom_preprocess=False)
-    assert _encoder_vs_oracle(cfg, 2, 25) < 2e-3
+    assert _encoder_vs_oracle(cfg, 2, 25) <= 1e-3
 
 
 def test_cfg5_episode_shape_10way_5shot_matches_oracle():
@@ -294,8 +297,9 @@ def test_cfg5_episode_shape_10way_5shot_matches_oracle():
         ref = O.lam_forward(init_state_dict(cfg, 9), geometry_for(cfg), batch, selected_rows=rows)
     assert out["logits"].shape == (1, 11, 160, 160)
     assert out["class_examples_embeddings"].shape == (1, 50, 11, 64)
-    assert rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]) < 2e-3
-    assert rel_err(out["logits"], ref["logits"]) < 4e-3
+    e_cls, e_log = rel_err(out["class_examples_embeddings"], ref["class_examples_embeddings"]), rel_err(out["logits"], ref["logits"])
+    print(f"many-pair episode: class_examples_embeddings {e_cls:.3e}, logits {e_log:.3e} (north_star bound 1e-3)")
+    assert e_cls <= 1e-3 and e_log <= 1e-3, (e_cls, e_log)
 
 
 # ---- every BASELINE config at its own size ----------------------------------------------------------------------------------------

@@ -1,0 +1,109 @@
+"""GPU, two processes on the ONE GPU of the box (gloo rendezvous): the data-parallel trainer and the bench's multi-rank path.
+
+Reference semantics (experiment/run.py:122-131,359-361): DDP with ``find_unused_parameters=True`` averages the gradients over the
+ranks and treats a parameter as used when ANY rank used it; prompt types are sampled per episode (data/dataset.py:292), so the ranks
+of one step routinely disagree about which prompt-encoder tensors their forward touched."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from labelanything_amd.episodes import make_episode
+from tests.cases import TRAIN_CASE
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 2
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _episode(rank: int, step: int):
+    """Rank 0 sees masks + points + boxes, rank 1 masks only: point_embeddings.*, not_a_point_embed are touched on rank 0 alone,
+    no_sparse_embedding on rank 1 alone."""
+    ep = dict(TRAIN_CASE["episode"])
+    ep.update(batch=1, seed=500 + 10 * step + rank, prompts=("mask", "point", "box") if rank == 0 else ("mask",))
+    batch = make_episode(**ep)
+    c = batch["flag_examples"].shape[2]
+    g = torch.Generator().manual_seed(900 + 10 * step + rank)
+    h, w = int(batch["dims"][0, 0, 0]), int(batch["dims"][0, 0, 1])
+    gt = torch.randint(0, c, (1, h // 4, w // 4), generator=g).repeat_interleave(4, 1).repeat_interleave(4, 2)
+    return batch, gt
+
+
+def _trainer():
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    lam = Lam(TRAIN_CASE["cfg"], seed=TRAIN_CASE["weight_seed"]).cuda()
+    lam.selected_rows = torch.tensor([1, 4, 7])
+    return lam, LamTrainer(lam, lr=1e-3, weight_decay=1e-2, num_warmup_steps=2)
+
+
+def _worker(rank: int, world: int, port: int, out_dir: str):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    lam, tr = _trainer()
+    for step in range(STEPS):
+        batch, gt = _episode(rank, step)
+        tr.step(batch, gt)
+    torch.cuda.synchronize()
+    torch.save({"flat": tr.opt.flat.cpu(), "steps": list(tr.opt.tensor_steps), "names": tr.names}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_keeps_replicas_identical_with_rank_local_prompt_types(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"r{r}.pt") for r in range(world))
+    # (a) replicas bit-identical, including the tensors only one of the ranks touched
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert r0["steps"] == r1["steps"]
+    names = r0["names"]
+    by = dict(zip(names, r0["steps"]))
+    assert by["prompt_encoder.point_embeddings.0.weight"] == STEPS and by["prompt_encoder.no_sparse_embedding.weight"] == STEPS
+    assert by["prompt_encoder.transformer.norm_final_attn.weight"] == 0          # dead on every rank: never stepped, never decayed
+    # (b) == one process that runs the two ranks' episodes as two accumulated micro-steps (mean of the per-rank gradients, flags
+    # OR-ed over the micro-steps) and then updates once.  NOT the concatenated 2-episode batch: that is a different function in
+    # the reference as well (the padded "not a point" tokens of the episode without points, the per-batch class weighting of the
+    # objective) - DDP is the average of per-rank objectives
+    lam, tr = _trainer()
+    for step in range(STEPS):
+        tr.zero_grad()
+        for rank in range(world):
+            batch, gt = _episode(rank, step)
+            tr.forward_backward(batch, gt, loss_normalizer=float(world))
+        tr.apply_update()
+    torch.cuda.synchronize()
+    single = tr.opt.flat.cpu()
+    assert tr.opt.tensor_steps == r0["steps"]
+    scale = float(single.abs().max())
+    assert float((single - r0["flat"]).abs().max()) <= 1e-6 * scale, float((single - r0["flat"]).abs().max()) / scale
+
+
+def test_bench_runs_as_two_ranks_and_prints_one_line(tmp_path):
+    """The driver's N > 1 launch (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N) with both ranks on this
+    box's one GPU and gloo instead of RCCL: exactly one JSON line, n_gpus 2, whole-job value = both ranks' episodes."""
+    env = dict(os.environ, LA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--episodes", "1", "--workload", "cfg1", "--no-cpu-baseline", "--no-eager-baseline"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["global_episodes_per_step"] == 2
+    assert abs(rec["value"] - 2 / (rec["ms_per_step"] * 1e-3)) <= 1e-2 * rec["value"]

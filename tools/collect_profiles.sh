@@ -10,13 +10,13 @@ mkdir -p $OUT
 # 1. the official bench line (with roofline + cpu_baseline)
 timeout 900 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.stderr
 # 2. rocprofv3 kernel stats of the same command (eager launches so that every kernel is a separate dispatch record too)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --no-cpu-baseline > $OUT/prof_graph.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --no-cpu-baseline --no-eager-baseline > $OUT/prof_graph.log 2>&1
 cp $(find $OUT/prof -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv 2>/dev/null
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eager -o bench -- python bench.py --no-cpu-baseline --no-graphs > $OUT/prof_eager.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eager -o bench -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs > $OUT/prof_eager.log 2>&1
 cp $(find $OUT/prof_eager -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_eager_kernel_stats.csv 2>/dev/null
 # 3. HBM-side traffic of the GEMM kernels: one counter per pass, no other trace domains
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
 python tools/pmc_traffic.py $(find $OUT/pmc -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic.json > /dev/null 2> $OUT/traffic.stderr
 # 3b. the same two passes on cfg4 (decoder-dominated: the fused two-way kernels' stream traffic)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -o f -- python bench.py --workload cfg4 --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
@@ -24,9 +24,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OU
 python tools/pmc_traffic.py $(find $OUT/pmc4 -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc4 -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic_cfg4.json cfg4 > /dev/null 2>> $OUT/traffic.stderr
 # 3c. the other workloads (each carries its own kernel table; traffic stays null where no PMC file matches) and the two
 #     numerics variants of the headline: plain 16-bit operands (round-1 numerics, misses 1e-3) and bf16
-for w in cfg1 cfg3 cfg4 cfg5 cfg3_train; do timeout 600 python bench.py --workload $w --no-cpu-baseline > $OUT/${R}_bench_$w.json 2>> $OUT/bench.stderr; done
-timeout 600 python bench.py --no-cpu-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
-timeout 600 python bench.py --no-cpu-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
+for w in cfg1 cfg3 cfg4 cfg5 cfg3_train; do timeout 600 python bench.py --workload $w --no-cpu-baseline --no-eager-baseline > $OUT/${R}_bench_$w.json 2>> $OUT/bench.stderr; done
+timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
 timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>&1
 # 4. parity report + per-op micro benchmarks
 timeout 900 python tools/parity_report.py > $OUT/${R}_parity.log 2>&1
