@@ -38,6 +38,10 @@ enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1, LA_ATTN_RELPOS_WIN16 = 2 };
 const char* la_last_error(void);
 int la_version(void);
 
+/* Tuning hook of la_gemm (measurement A/B only, results are identical): 1 = 64-deep quadrant-phase main loop where it
+ * applies (default), 0 = the 32-deep persistent kernel everywhere; v < 0 only queries.  Returns the previous value. */
+int la_gemm_variant(int v);
+
 /* Epilogue of la_gemm: out = map( act(A.W^T + bias) + residual ).
  *  map LA_MAP_GROUP        dst_row = (row / p0) * p1 + row % p0 + p2        (CLS-gap insertion for the HF ViT)
  *  map LA_MAP_WINDOW_MERGE rows are window-partitioned tokens (p0 = window, p1 = #win y, p2 = #win x,

@@ -60,8 +60,13 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant",
 ]
+
+
+def gemm_variant(v: int = -1) -> int:
+    """la_gemm_variant: select the main loop of the large encoder GEMMs (1 = BK 64 quadrant phases, 0 = BK 32); returns the previous one."""
+    return int(lib().la_gemm_variant(int(v)))
 
 
 def _check(rc: int, what: str) -> None:

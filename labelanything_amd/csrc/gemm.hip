@@ -7,6 +7,7 @@
 // written to the other LDS stage after them.  Tiles are handed to XCDs in contiguous chunks (xcd_remap) so
 // the workgroups sharing an A row-panel / the whole W hit the same L2.
 #include <cstdlib>
+#include <type_traits>
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
@@ -1273,9 +1274,13 @@ __device__ __forceinline__ int slab_swz(int r) { return ((r & 1) << 2) | ((r >> 
 
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M,
-                                              const LaGemmEpilogue& e, int lane) {
+                                              const LaGemmEpilogue& e, int lane, bool nostore = false) {
   const int fr = lane & 31, fh = lane >> 5;
   const float bias0 = e.bias ? e.bias[col0 + fr] : 0.f, bias1 = e.bias ? e.bias[col0 + 32 + fr] : 0.f;
+  // consume the two loads HERE: hipcc does not see the LDS-DMA pieces, and a load whose first use sits on only some of the paths
+  // below leaves "pending" state at the tile loop's back edge - the compiler then drops an s_waitcnt vmcnt(0) into the first k-step
+  // of the NEXT tile, which in reality drains the finished tile's whole store burst and the pieces just issued
+  asm volatile("" ::"v"(bias0), "v"(bias1));
   const bool vtile = EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0;
   constexpr unsigned NOROW = 0xffffffffu;
   if (EPI == 1 && rtab != nullptr) {
@@ -1411,7 +1416,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
           if (EPI == 1 && rtab != nullptr) {
             const unsigned d = rtab[i * 32 + h * 16 + sr];
             if (d != NOROW) *reinterpret_cast<uint4*>(out + (size_t)d * e.ld16 + col0 + rch * 8) = v;
-          } else if (row < M) {
+          } else if (row < M && !nostore) {
             *reinterpret_cast<uint4*>(out + (size_t)row * e.ld16 + col0 + rch * 8) = v;
           }
         }
@@ -1622,8 +1627,219 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
   }
 }
 
+// =================================================================================================================
+// v9 "t256q": the persistent 256 x 256 tile with a 64-deep k-step in four QUADRANT phases (one weight plane).
+// Why: with BK = 32 an LDS-DMA piece is 16 rows x 64 B - half a cache line per row, every 128-B line of A and W passes the
+// vector-memory front end twice, and the k-step was paced by exactly that (profiles/r02_gemm_notes.md: the pieces, not their
+// source, not the fragment reads).  Here a piece is 8 rows x 128 B = 8 whole lines.
+// Per wave (128 x 64 block = acc[4][2]) a 64-deep k-tile is four phases of 8 MFMA 32x32x16 (256 cycles) each:
+//     q0  acc[0..1][0] += A_sub0 . W_j0      reads A_sub0 (8 x b128) + W_j0 (4)          DMA quarter Q0 of the NEXT k-tile
+//     q1  acc[0..1][1] += A_sub0 . W_j1      reads W_j1 (4)                               Q1
+//     q2  acc[2..3][1] += A_sub1 . W_j1      reads A_sub1 (8, same registers as A_sub0)   Q2
+//     q3  acc[2..3][0] += A_sub1 . W_j0      (W_j0 kept in registers)                      Q3
+// Quarters are ordered by FIRST USE: Q0 = the A_sub0 rows of both wave groups, Q1 = the W_j0 rows of the four wave columns,
+// Q2 = W_j1, Q3 = A_sub1 - so a quarter issued in phase q of k-tile kt is first read 3-4 phases later and TWO k-tile buffers
+// (2 x 64 KiB) are enough.  Counted waits (each wave issues 2 pieces per phase; in steady state 8 are outstanding before phase 3's wait):
+//     end of q3: vmcnt(4) -> Q0, Q1 of the next k-tile landed      end of q0: vmcnt(4) -> Q2 of this one      end of q1: vmcnt(4) -> Q3
+// always one barrier ahead of the first reader.  The two wave groups run one barrier out of phase (group 1's L interval = group
+// 0's M interval) exactly as in t256p; the seam (epilogue through the private slabs, next tile's first k-tile already in flight,
+// store slack in the first two waits of a tile) is the same as well.
+// =================================================================================================================
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
+                                                             int M, int N, int K, LaGemmEpilogue e, int gm) {
+  constexpr int BK_ = 64;
+  constexpr int OPB = 256 * BK_ * 2;                 // 32 KiB per operand k-tile
+  constexpr int BUFB = 2 * OPB;                      // 64 KiB per k-tile
+  constexpr int SDECL = (EPI == 3) ? 32 : 16;        // stores per wave of an interior, non-V^T tile (never more than are issued)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool nostore = (gm >> 8) & 1;                // measurement ablations (la_gemm_variant bits 8 / 23: results wrong by construction)
+  const bool noepi = (gm >> 23) & 1;
+  gm &= 0xff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wi = wave & 3;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ntn = N / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
+  char* slab = smem + 2 * BUFB + wave * 2048;
+  unsigned* rtab = nullptr;
+  if (EPI == 1 && e.map != LA_MAP_NONE) rtab = reinterpret_cast<unsigned*>(smem + 2 * BUFB + 8 * 2048 + wave * 512);
+
+  // first tile row of piece i (0, 1) of this wave in quarter q
+  auto piece_row0 = [&](int q, int i) {
+    const int p = wave * 2 + i;
+    if (q == 0 || q == 3) return (p >> 3) * 128 + (p & 7) * 8 + (q == 3 ? 64 : 0);
+    return (p >> 2) * 64 + (p & 3) * 8 + (q == 2 ? 32 : 0);
+  };
+  // per-lane source offsets of the 8 pieces of a k-tile (ONE set: the next tile's offsets replace them at the head of a tile's last
+  // k-tile, when every piece of the current tile has been issued - a second set cost 8 VGPRs and, at 256, spills whose reloads the
+  // compiler guards with s_waitcnt vmcnt(0): each one drains the DMA ring and the epilogue's own store burst)
+  unsigned soff[4][2];
+  auto plan = [&](int tile, int& m0, int& n0) {
+    int tm_, tn_;
+    tile_coords(xcd_remap(tile, ntiles), ntm, ntn, gm, tm_, tn_);
+    m0 = tm_ * 256;
+    n0 = tn_ * 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = piece_row0(q, i) + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+        if (q == 0 || q == 3) soff[q][i] = (unsigned)(((size_t)a_row(e, min(m0 + r, M - 1)) * lda + ch) * sizeof(T));
+        else soff[q][i] = (unsigned)(((size_t)(n0 + r) * ldw + ch) * sizeof(T));
+      }
+  };
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma_q = [&](int q, int kt, int buf) {
+    const bool isw = (q == 1 || q == 2);
+    const T* src = isw ? Wt + kt * BK_ : A + a_koff(e, kt * BK_);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16s(src, soff[q][i], lds0 + buf * BUFB + (isw ? OPB : 0) + piece_row0(q, i) * 128);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK_;                            // >= 2 (host side)
+  uint4 af[2][4], wf[4];
+  auto read_a = [&](int buf, int sub) {
+    const char* sa = smem + buf * BUFB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        af[i][ks] = *reinterpret_cast<const uint4*>(sa + swz_off(grp * 128 + (sub * 2 + i) * 32 + fr, ks * 2 + fh));
+  };
+  auto read_w = [&](int buf, int j) {
+    const char* sw = smem + buf * BUFB + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(sw + swz_off(wi * 64 + j * 32 + fr, ks * 2 + fh));
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  int m0, n0, m0n = 0, n0n = 0;
+  int tile = blockIdx.x;
+  plan(tile, m0, n0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_q(q, 0, 0);
+  dma_wait<4>();                                     // Q0, Q1 of k-tile 0 ...
+  bar();                                             // ... for everybody
+  if (grp == 1) bar();                               // group 1 runs one interval behind
+  int buf = 0;
+  bool seam_slack = false;
+  for (;;) {
+    const int next = tile + gridDim.x;
+    const bool more = next < ntiles;
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool last = kt + 1 == nk;
+      const bool feed = !last || more;               // a k-tile follows in the stream
+      if (last && more) plan(next, m0n, n0n);        // every piece of this tile is on its way: the offsets now describe the next tile
+      // counted wait at the end of phase q (q = 3, 0, 1); see the header
+      auto retire = [&](int q) {
+        if (q == 3) {
+          if (feed) dma_wait<4>();
+        } else if (!feed) {
+          if (q == 0) dma_wait<2>();
+          else dma_wait<0>();
+        } else if (seam_slack && kt == 0) {
+          dma_wait<4 + SDECL>();
+        } else {
+          dma_wait<4>();
+        }
+      };
+      auto phase = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // ---- L: fragment reads first, then the two DMA pieces (their issue stall overlaps the LDS latency) -------------------
+        if (q == 0) {
+          read_w(buf, 0);
+          read_a(buf, 0);
+        } else if (q == 1) {
+          read_w(buf, 1);
+        } else if (q == 2) {
+          read_a(buf, 1);
+        } else {
+          read_w(buf, 0);                            // W_j0 again: 4 reads in the otherwise empty L(q3) instead of 16 registers held
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (feed) dma_q(q, last ? 0 : kt + 1, buf ^ 1);
+        if (grp == 1 && q != 2) retire(q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bar();
+        // ---- M ----------------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int ib = (q >= 2) ? 2 : 0, jb = (q == 1 || q == 2) ? 1 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[ib + i][jb] = Half16<T>::mfma32(af[i][ks], wf[ks], acc[ib + i][jb]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0 && q != 2) retire(q);
+        if (q != 3 || !last || grp == 0) bar();      // group 1 keeps its last M interval open: both groups' epilogues share it
+      };
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+      phase(std::integral_constant<int, 3>{});
+      buf ^= 1;
+    }
+    if (noepi) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      epilogue_wave<T, EPI>(slab, rtab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane, nostore);
+    }
+    seam_slack = (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0) && !nostore && !noepi;
+    bar();
+    if (!more) break;
+    if (grp == 1) bar();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    m0 = m0n;
+    n0 = n0n;
+    tile = next;
+  }
+}
+
+static int g_gemm_variant = 1;       // 1: BK = 64 quadrant-phase kernel where it applies, 0: the BK = 32 persistent kernel everywhere
+
+template <typename T, int EPI>
+static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  constexpr int LDS = 2 * 65536 + 8 * 2048 + 8 * 512;       // two k-tile buffers + 2 KiB slab per wave + row tables: 148 KiB
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256q_kernel<T, EPI>), LDS, attr_mask);
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (ncu <= 0) ncu = 256;
+  }
+  const int ntiles = ((M + 255) / 256) * (N / 256);
+  const int grid = ntiles < ncu ? ntiles : ncu;
+  hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800100));
+}
+
 template <typename T, int NPL, int EPI>
 static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  if (NPL == 1 && (g_gemm_variant & 0xff) == 1 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0))
+    return launch_t256q<T, EPI>(A, lda, W, ldw, M, N, K, e, st);
   constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768 + 8 * 512) + 8 * 2048;      // ring + 2 KiB slab per wave (+ row tables): 148 / 160 KiB
   static unsigned long long attr_mask = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), LDS, attr_mask);
@@ -1980,6 +2196,12 @@ static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, in
 }
 
 }  // namespace la
+
+extern "C" int la_gemm_variant(int v) {
+  const int prev = la::g_gemm_variant;
+  if (v >= 0) la::g_gemm_variant = v;
+  return prev;
+}
 
 extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue* epi, int dt,
                        void* stream) {

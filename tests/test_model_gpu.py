@@ -27,6 +27,7 @@ TOL = {
     torch.float16: dict(emb=1e-3, cls=1e-3, low=1e-3, logits=1e-3),
     torch.bfloat16: dict(emb=6.5e-3, cls=1.5e-3, low=9e-3, logits=8e-3),
 }
+ARGMAX_FLIPS = {torch.float16: 0.005, torch.bfloat16: 0.02}      # largest share of near-tie pixels that may flip
 ARGMAX_MARGIN = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # 2 x the logit tolerance
 
 
@@ -60,7 +61,8 @@ def test_episode_matches_reference_fixture(name, dt):
     # and equals the reference's argmax wherever the reference's top-2 margin is outside the tolerance band
     n_diff, n_real = argmax_disagreement(out["logits"], gold["argmax"].long(), ref_logits, margin_rel=ARGMAX_MARGIN[dt])
     assert n_real == 0, f"{n_real} of {n_diff} differing pixels have a reference margin above the tolerance band"
-    assert n_diff <= 0.005 * am.numel(), f"{n_diff} of {am.numel()} pixels flip inside the near-tie band"
+    # measured: fp16 0.03 - 0.3 % of the pixels sit inside the band and flip, bf16 (8x wider band) up to 1 %
+    assert n_diff <= ARGMAX_FLIPS[dt] * am.numel(), f"{n_diff} of {am.numel()} pixels flip inside the near-tie band"
     assert out["logits"].shape == (b, gold["class_embeddings"].shape[1], *gold["argmax"].shape[-2:])
 
 
