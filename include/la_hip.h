@@ -303,6 +303,34 @@ int la_twoway_i2t(float* img, const void* wq_hi, const void* wq_lo, const float*
                   const void* wo_lo, const float* bo, const float* gamma, const float* beta, float eps, int G, int hw, int nt, int D,
                   int heads, void* stream);
 
+/* ---- image-encoder backward (SURVEY 8f row 1 with a TRAINABLE backbone: parameters/trainval/coco20i/mae_noembs.yaml has no
+ * freeze_backbone, so models/lam.py:321-347 hands every ViT parameter to the optimizer).  Plain HF ViT attention, head_dim 64. ---- */
+
+/* la_attn_fwd in LA_ATTN_PLAIN mode that also writes the log2-domain log-sum-exp of every query row: lse fp32 [B*heads, Tpad]
+ * (entries t >= T are not touched: the caller pre-fills them with +1e30 so that those rows carry zero probability in la_attn_bwd). */
+int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, float* lse, int B, int heads, int T, int Tpad, int E, float scale,
+                    int dt, void* stream);
+
+/* dst[(b * heads + h) * 64 + d][t] = src[b * T + t][col0 + h * 64 + d] (16-bit), zero for T <= t < Tpad: the token-contiguous operand
+ * copies of la_attn_fwd (V^T) and la_attn_bwd (K^T, Q^T, dO^T). */
+int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T, int Tpad, void* dst, int dt, void* stream);
+
+/* Gradient of O = softmax(Q K^T scale) V per (image, head) (transformers ViTSelfAttention.forward under build_encoder.py:83-100):
+ * qkv [B*T, 3E] (q | k | v), out16 = O, dout16 = dO [B*T, E]; kt / qt / dot = la_head_transpose of K, Q, dO; lse from la_attn_fwd_lse;
+ * dvec fp32 [B*heads, Tpad] workspace (zero beyond T, receives rowsum(dO * O)); dqkv [B*T, 3E] receives dq | dk | dv.  All 16-bit
+ * tensors share dt; dO may be pre-scaled (loss scaling), dq / dk / dv then carry the same factor. */
+int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
+                float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream);
+
+/* dst = scale * src, n contiguous elements, between LA_F32 and LA_F16 / LA_BF16 (either direction) or LA_F32 -> LA_F32 (in place allowed). */
+int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float scale, void* stream);
+
+/* y += a * x, n contiguous fp32 elements (loss-scaled encoder gradients folded into the flat gradient buffer). */
+int la_axpy(const float* x, float* y, long n, float a, void* stream);
+
+/* dpre = dh * gelu'(pre) (erf form, transformers ViTIntermediate): pre 16-bit, dh fp32, outputs fp32 and / or 16-bit (either may be NULL). */
+int la_gelu_bwd16(const void* pre16, const float* dh, float* d32, void* d16, long n, int dt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy",
 ]
 
 
@@ -328,20 +328,26 @@ def _f32c(*ts) -> None:
             raise ValueError("contiguous fp32 device tensors expected")
 
 
+def _f32rows(t: torch.Tensor) -> None:
+    _dev(t)
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("fp32 device matrices with unit column stride expected")
+
+
 def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
-    """dw[N,K] += dy[M,N]^T @ x[M,K]."""
-    _f32c(dy, x, dw)
+    """dw[N,K] += dy[M,N]^T @ x[M,K].  dy / x may be column slices of wider matrices (row stride = the parent's width)."""
+    _f32rows(dy), _f32rows(x), _f32c(dw)
     m, n = dy.shape
     k = x.shape[1]
-    _check(lib().la_gemm_tn(_ptr(dy), C.c_int(n), _ptr(x), C.c_int(k), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n), C.c_int(k), _stream()),
-           "la_gemm_tn")
+    _check(lib().la_gemm_tn(_ptr(dy), C.c_int(dy.stride(0)), _ptr(x), C.c_int(x.stride(0)), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n),
+                            C.c_int(k), _stream()), "la_gemm_tn")
 
 
 def colsum_acc(dy: torch.Tensor, out: torch.Tensor) -> None:
-    """out[N] += dy[M,N].sum(0)."""
-    _f32c(dy, out)
+    """out[N] += dy[M,N].sum(0) (dy may be a column slice of a wider matrix)."""
+    _f32rows(dy), _f32c(out)
     m, n = dy.shape
-    _check(lib().la_colsum_acc(_ptr(dy), C.c_int(n), C.c_long(m), C.c_int(n), _ptr(out), _stream()), "la_colsum_acc")
+    _check(lib().la_colsum_acc(_ptr(dy), C.c_int(dy.stride(0)), C.c_long(m), C.c_int(n), _ptr(out), _stream()), "la_colsum_acc")
 
 
 def layernorm_bwd(x, dy, gamma, beta, eps: float, gelu: bool, dx, dgamma, dbeta) -> None:
@@ -409,3 +415,44 @@ def twoway_i2t(img, wq, peq, k, v, wo, bo, gamma, beta, eps: float, groups: int,
     _check(lib().la_twoway_i2t(_ptr(img), _ptr(wq[0]), _ptr(wq[1]), _ptr(peq), _ptr(k), _ptr(v), _ptr(wo[0]), _ptr(wo[1]), _ptr(bo),
                                _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(groups), C.c_int(hw), C.c_int(nt), C.c_int(img.shape[1]),
                                C.c_int(heads), _stream()), "la_twoway_i2t")
+
+
+# ---- image-encoder backward ---------------------------------------------------------------------------
+def attn_fwd_lse(qkv, vt, out16, lse, b: int, heads: int, t: int, tpad: int, e: int, scale: float) -> None:
+    _dev(qkv)
+    _check(lib().la_attn_fwd_lse(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(lse), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad),
+                                 C.c_int(e), C.c_float(scale), C.c_int(dt_of(qkv)), _stream()), "la_attn_fwd_lse")
+
+
+def head_transpose(src, col0: int, b: int, heads: int, t: int, tpad: int, dst) -> None:
+    _dev(src)
+    _check(lib().la_head_transpose(_ptr(src), C.c_int(src.stride(0)), C.c_int(col0), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad),
+                                   _ptr(dst), C.c_int(dt_of(src)), _stream()), "la_head_transpose")
+
+
+def attn_bwd(qkv, out16, dout16, kt, qt, dot, lse, dvec, dqkv, b: int, heads: int, t: int, tpad: int, e: int, scale: float) -> None:
+    _dev(qkv)
+    _check(lib().la_attn_bwd(_ptr(qkv), _ptr(out16), _ptr(dout16), _ptr(kt), _ptr(qt), _ptr(dot), _ptr(lse), _ptr(dvec), _ptr(dqkv),
+                             C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad), C.c_int(e), C.c_float(scale), C.c_int(dt_of(qkv)),
+                             _stream()), "la_attn_bwd")
+
+
+def cast(src, dst, scale: float = 1.0) -> None:
+    """dst = scale * src (fp32 <-> 16-bit, or fp32 -> fp32 possibly in place); contiguous tensors of equal numel."""
+    _dev(src)
+    if not (src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()):
+        raise ValueError("la_cast needs contiguous tensors of equal size")
+    _check(lib().la_cast(_ptr(src), C.c_int(dt_of(src)), _ptr(dst), C.c_int(dt_of(dst)), C.c_long(src.numel()), C.c_float(scale), _stream()),
+           "la_cast")
+
+
+def gelu_bwd16(pre16, dh, d32=None, d16=None) -> None:
+    _dev(pre16)
+    _check(lib().la_gelu_bwd16(_ptr(pre16), _ptr(dh), _ptr(d32), _ptr(d16), C.c_long(pre16.numel()), C.c_int(dt_of(pre16)), _stream()),
+           "la_gelu_bwd16")
+
+
+def axpy(x, y, a: float) -> None:
+    """y += a * x (contiguous fp32)."""
+    _f32c(x, y)
+    _check(lib().la_axpy(_ptr(x), _ptr(y), C.c_long(x.numel()), C.c_float(a), _stream()), "la_axpy")

@@ -1,0 +1,381 @@
+// Backward of the plain (HF ViT) flash attention of la_attn_fwd for gfx950, head_dim 64 - the gradient of
+//   O = softmax(Q K^T * scale) V      (transformers ViTSelfAttention under build_encoder.py:83-100; autograd of what
+//                                      label_anything/models/lam.py:321-347 trains when the backbone is not frozen)
+// Two kernels, no atomics, the T x T matrices never exist:
+//   attn_bwd_dq_kernel   one workgroup = 4 waves = 128 QUERY rows of one (image, head), loop over 64-key tiles.  Same orientation as
+//                        the forward (scores transposed, S^T = K Q^T, one query per lane): P^T = exp2(S^T c - LSE) with the row's LSE
+//                        from the forward, dP^T = V dO^T, dS^T = P^T (dP^T - D), dQ^T += K^T dS^T.  Also writes D = rowsum(dO * O).
+//   attn_bwd_dkv_kernel  one workgroup = 128 KEY rows, loop over 64-query tiles, one key per lane: S = Q K^T, dP = dO V^T,
+//                        dV^T += dO^T P, dK^T += Q^T dS.
+// In both, the operand that is reduced over tokens is needed token-contiguous, so the caller passes TRANSPOSED copies (la_head_transpose:
+// K^T for dQ; Q^T and dO^T for dK / dV), laid out like the forward's V^T: [B*heads, 64, Tpad], zero padded.  P and dS go from the
+// accumulator layout into the B operand of the next MFMA with v_permlane32_swap, exactly as P does in the forward kernel.
+// All 16-bit operands share one dtype; gradients arrive pre-scaled (loss scaling is the host's business: train_encoder.py).
+#include <cstdlib>
+#include "la_common.h"
+#include "../../include/la_hip.h"
+
+namespace la {
+
+constexpr float BWD_NEG_BIG = -1.0e30f;
+constexpr int TILE_B = 64 * 64 * 2;      // one 64 x 64 16-bit tile: 8 KiB, 128-byte rows, XOR swizzled (swz_off)
+
+struct AttnBwdEncArgs {
+  const void* qkv;      // [B*T, 3E] 16-bit: q | k | v rows
+  const void* dout;     // [B*T, E] 16-bit: dO
+  const void* out;      // [B*T, E] 16-bit: O (forward output)             (dq kernel)
+  const void* kt;       // [B*heads, 64, Tpad]: K^T                          (dq kernel)
+  const void* qt;       // [B*heads, 64, Tpad]: Q^T                          (dkv kernel)
+  const void* dot;      // [B*heads, 64, Tpad]: dO^T                         (dkv kernel)
+  float* lse;           // [B*heads, Tpad] log2-domain LSE of the forward, +BIG beyond T
+  float* dvec;          // [B*heads, Tpad] D = rowsum(dO * O), 0 beyond T (written by the dq kernel)
+  void* dqkv;           // [B*T, 3E] 16-bit: dq | dk | dv rows (written)
+  int B, heads, T, Tpad, E;
+  float scale;
+};
+
+// stage rows [row0, row0 + 64) (clamped to maxrow) x 64 columns of a row-major 16-bit matrix into one swizzled LDS tile
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T* base, size_t ld, int row0, int maxrow, unsigned lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    dma16(base + (size_t)min(row0 + row, maxrow) * ld + chunk * 8, lds_tile + (i * 4 + wave) * 1024);
+  }
+}
+
+// accumulator tile pair (rows = 64 reduction tokens of one lane's column) -> the four B-operand k-slices, as in the forward kernel
+template <typename T>
+__device__ __forceinline__ void to_b_frags(const f32x16 (&s)[2], uint4 (&pf)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int t = ks >> 1, g0 = (ks & 1) * 8;
+    const uint32_t x0 = pack2<T>(s[t][g0 + 0], s[t][g0 + 1]);
+    const uint32_t x1 = pack2<T>(s[t][g0 + 2], s[t][g0 + 3]);
+    const uint32_t y0 = pack2<T>(s[t][g0 + 4], s[t][g0 + 5]);
+    const uint32_t y1 = pack2<T>(s[t][g0 + 6], s[t][g0 + 7]);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+    pf[ks] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  }
+}
+
+template <typename T> __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
+  const T* pa = reinterpret_cast<const T*>(&a);
+  const T* pb = reinterpret_cast<const T*>(&b);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += (float)pa[i] * (float)pb[i];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 3 * TILE_B;             // K rows | V rows | K^T
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int BH = a.B * a.heads;
+  const int bh = blockIdx.x % BH, qblk = blockIdx.x / BH;
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int T_ = a.T, E3 = 3 * a.E;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const int q = qblk * 128 + wave * 32 + fr, qc = min(q, T_ - 1);
+  const float c2 = a.scale * 1.44269504088896340736f;
+
+  uint4 qf[4], dof[4];
+  float dsum = 0.f;
+  {
+    const size_t row = (size_t)b * T_ + qc;
+    const T* pq = qkv + row * E3 + h * 64 + fh * 8;
+    const T* pd = reinterpret_cast<const T*>(a.dout) + row * a.E + h * 64 + fh * 8;
+    const T* po = reinterpret_cast<const T*>(a.out) + row * a.E + h * 64 + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const uint4*>(pq + ks * 16);
+      dof[ks] = *reinterpret_cast<const uint4*>(pd + ks * 16);
+      dsum += dot8<T>(dof[ks], *reinterpret_cast<const uint4*>(po + ks * 16));
+    }
+  }
+  dsum += __shfl_xor(dsum, 32, 64);               // D of this lane pair's query
+  const float lse2 = a.lse[(size_t)bh * a.Tpad + qc];
+  if (q < T_ && fh == 0) a.dvec[(size_t)bh * a.Tpad + q] = dsum;
+
+  const unsigned lds0 = lds_addr_of(smem);
+  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * 64;
+  const T* vbase = kbase + a.E;
+  const T* ktb = reinterpret_cast<const T*>(a.kt) + (size_t)bh * 64 * a.Tpad;
+  auto dma = [&](int j, int stage) {
+    const unsigned s0 = lds0 + stage * STAGE;
+    stage_rows<T>(kbase, E3, j * 64, T_ - 1, s0, wave, lane);
+    stage_rows<T>(vbase, E3, j * 64, T_ - 1, s0 + TILE_B, wave, lane);
+    stage_rows<T>(ktb + j * 64, a.Tpad, 0, 63, s0 + 2 * TILE_B, wave, lane);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  const int ntiles = (T_ + 63) >> 6;
+  dma(0, 0);
+  dma_wait<0>();
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+    const char* sk = smem + (j & 1) * STAGE;
+    const char* sv = sk + TILE_B;
+    const char* skt = sk + 2 * TILE_B;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = dp[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(t * 32 + fr, ks * 2 + fh));
+        s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
+        dp[t] = Half16<T>::mfma32(vf, dof[ks], dp[t]);
+      }
+    }
+    const bool tail = j * 64 + 64 > T_;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const float sv_ = (tail && key >= T_) ? BWD_NEG_BIG : s[t][r];
+        const float p = __builtin_amdgcn_exp2f(fmaf(sv_, c2, -lse2));
+        s[t][r] = p * (dp[t][r] - dsum);           // dS^T (before the 1/sqrt(d) factor, applied at the end)
+      }
+    uint4 dsf[4];
+    to_b_frags<T>(s, dsf);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const uint4 ktf = *reinterpret_cast<const uint4*>(skt + swz_off(d * 32 + fr, ks * 2 + fh));
+        acc[d] = Half16<T>::mfma32(ktf, dsf[ks], acc[d]);
+      }
+    dma_wait<0>();
+    __syncthreads();
+  }
+  if (q < T_) {
+    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + q) * E3 + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 v;
+        v.x = pack2<T>(acc[d][g4 * 4 + 0] * a.scale, acc[d][g4 * 4 + 1] * a.scale);
+        v.y = pack2<T>(acc[d][g4 * 4 + 2] * a.scale, acc[d][g4 * 4 + 3] * a.scale);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 4 * TILE_B + 512;       // Q rows | dO rows | Q^T | dO^T | LSE (64 floats) | D (64 floats)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int BH = a.B * a.heads;
+  const int bh = blockIdx.x % BH, kblk = blockIdx.x / BH;
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int T_ = a.T, E3 = 3 * a.E;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const int key = kblk * 128 + wave * 32 + fr, kc = min(key, T_ - 1);
+  const float c2 = a.scale * 1.44269504088896340736f;
+
+  uint4 kf[4], vf[4];
+  {
+    const T* pk = qkv + ((size_t)b * T_ + kc) * E3 + a.E + h * 64 + fh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const uint4*>(pk + ks * 16);
+      vf[ks] = *reinterpret_cast<const uint4*>(pk + a.E + ks * 16);
+    }
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  const T* qbase = qkv + (size_t)b * T_ * E3 + h * 64;
+  const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * 64;
+  const T* qtb = reinterpret_cast<const T*>(a.qt) + (size_t)bh * 64 * a.Tpad;
+  const T* dotb = reinterpret_cast<const T*>(a.dot) + (size_t)bh * 64 * a.Tpad;
+  const float* lseb = a.lse + (size_t)bh * a.Tpad;
+  const float* dvb = a.dvec + (size_t)bh * a.Tpad;
+  auto dma = [&](int i, int stage) {
+    const unsigned s0 = lds0 + stage * STAGE;
+    stage_rows<T>(qbase, E3, i * 64, T_ - 1, s0, wave, lane);
+    stage_rows<T>(dobase, a.E, i * 64, T_ - 1, s0 + TILE_B, wave, lane);
+    stage_rows<T>(qtb + i * 64, a.Tpad, 0, 63, s0 + 2 * TILE_B, wave, lane);
+    stage_rows<T>(dotb + i * 64, a.Tpad, 0, 63, s0 + 3 * TILE_B, wave, lane);
+    // the 64 LSE / D values of the query tile: 16 lanes x 16 bytes each (wave 0: LSE, wave 1: D); every wave issues the same
+    // NUMBER of pieces per tile only matters for counted waits - this kernel waits for all of them (dma_wait<0>)
+    if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 4 * TILE_B + wave * 256);
+  };
+
+  f32x16 dv[2], dk[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[d][r] = dk[d][r] = 0.f;
+
+  const int ntiles = (T_ + 63) >> 6;
+  dma(0, 0);
+  dma_wait<0>();
+  __syncthreads();
+  for (int i = 0; i < ntiles; ++i) {
+    if (i + 1 < ntiles) dma(i + 1, (i + 1) & 1);
+    const char* sq = smem + (i & 1) * STAGE;
+    const char* sdo = sq + TILE_B;
+    const char* sqt = sq + 2 * TILE_B;
+    const char* sdot = sq + 3 * TILE_B;
+    const float* slse = reinterpret_cast<const float*>(sq + 4 * TILE_B);
+    const float* sdv = slse + 64;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = dp[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 qf = *reinterpret_cast<const uint4*>(sq + swz_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 df = *reinterpret_cast<const uint4*>(sdo + swz_off(t * 32 + fr, ks * 2 + fh));
+        s[t] = Half16<T>::mfma32(qf, kf[ks], s[t]);          // S[i][j]: lane = key j, registers = queries
+        dp[t] = Half16<T>::mfma32(df, vf[ks], dp[t]);        // dP[i][j]
+      }
+    }
+    f32x16 ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 l4 = *reinterpret_cast<const float4*>(slse + t * 32 + 8 * g4 + 4 * fh);
+        const float4 d4 = *reinterpret_cast<const float4*>(sdv + t * 32 + 8 * g4 + 4 * fh);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = g4 * 4 + k;
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -lv[k]));    // rows beyond T carry LSE = +BIG: p = 0
+          s[t][r] = p;
+          ds[t][r] = p * (dp[t][r] - dvv[k]);
+        }
+      }
+    uint4 pf[4], dsf[4];
+    to_b_frags<T>(s, pf);
+    to_b_frags<T>(ds, dsf);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const uint4 dotf = *reinterpret_cast<const uint4*>(sdot + swz_off(d * 32 + fr, ks * 2 + fh));
+        const uint4 qtf = *reinterpret_cast<const uint4*>(sqt + swz_off(d * 32 + fr, ks * 2 + fh));
+        dv[d] = Half16<T>::mfma32(dotf, pf[ks], dv[d]);      // dV^T[d][j] += dO^T[d][i] P[i][j]
+        dk[d] = Half16<T>::mfma32(qtf, dsf[ks], dk[d]);      // dK^T[d][j] += Q^T[d][i] dS[i][j]
+      }
+    dma_wait<0>();
+    __syncthreads();
+  }
+  if (key < T_) {
+    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + key) * E3 + a.E + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 vk, vv;
+        vk.x = pack2<T>(dk[d][g4 * 4 + 0] * a.scale, dk[d][g4 * 4 + 1] * a.scale);
+        vk.y = pack2<T>(dk[d][g4 * 4 + 2] * a.scale, dk[d][g4 * 4 + 3] * a.scale);
+        vv.x = pack2<T>(dv[d][g4 * 4 + 0], dv[d][g4 * 4 + 1]);
+        vv.y = pack2<T>(dv[d][g4 * 4 + 2], dv[d][g4 * 4 + 3]);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = vk;
+        *reinterpret_cast<uint2*>(op + a.E + d * 32 + 8 * g4 + 4 * fh) = vv;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dst[(b * heads + h) * 64 + d][t] = src[b * T + t][col0 + h * 64 + d], t < T; zero for T <= t < Tpad.  One workgroup per 64-token tile.
+template <typename T>
+__global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict__ src, int ld, int col0, int heads, int T_, int Tpad,
+                                                             T* __restrict__ dst) {
+  __shared__ T tile[64][64 + 2];
+  const int bh = blockIdx.y, t0 = blockIdx.x * 64;
+  const int b = bh / heads, h = bh % heads;
+  const int tid = threadIdx.x;
+  {
+    const int r = tid >> 2, c8 = (tid & 3) * 16;           // 64 rows x 4 threads x 16 halves
+    const int t = t0 + r;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+    if (t < T_) {
+      const T* p = src + ((size_t)b * T_ + t) * ld + col0 + h * 64 + c8;
+      v0 = *reinterpret_cast<const uint4*>(p);
+      v1 = *reinterpret_cast<const uint4*>(p + 8);
+    }
+    const T* e0 = reinterpret_cast<const T*>(&v0);
+    const T* e1 = reinterpret_cast<const T*>(&v1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      tile[r][c8 + i] = e0[i];
+      tile[r][c8 + 8 + i] = e1[i];
+    }
+  }
+  __syncthreads();
+  {
+    const int d = tid >> 2, t8 = (tid & 3) * 16;
+    T o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = tile[t8 + i][d];
+    T* p = dst + ((size_t)bh * 64 + d) * Tpad + t0 + t8;
+    *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&o[0]);
+    *reinterpret_cast<uint4*>(p + 8) = *reinterpret_cast<const uint4*>(&o[8]);
+  }
+}
+
+}  // namespace la
+
+extern "C" int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T, int Tpad, void* dst, int dt, void* stream) {
+  LA_CHECK_ARG(src && dst && B > 0 && heads > 0 && T > 0, "la_head_transpose: bad arguments");
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0 && (ld % 8) == 0 && (col0 % 8) == 0, "la_head_transpose: Tpad %% 64, ld %% 8, col0 %% 8 (Tpad=%d ld=%d col0=%d)",
+               Tpad, ld, col0);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_head_transpose: bad dtype %d", dt);
+  const dim3 grid(Tpad / 64, B * heads), blk(256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dt == LA_F16)
+    hipLaunchKernelGGL(la::head_transpose_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)src, ld, col0, heads, T, Tpad, (la::f16_t*)dst);
+  else
+    hipLaunchKernelGGL(la::head_transpose_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)src, ld, col0, heads, T, Tpad, (la::bf16_t*)dst);
+  LA_CHECK_LAUNCH("la_head_transpose");
+  return 0;
+}
+
+extern "C" int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
+                           float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && out16 && dout16 && kt && qt && dot && lse && dvec && dqkv, "la_attn_bwd: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd: bad dtype %d", dt);
+  la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = (T + 127) / 128 * B * heads;
+  constexpr int LDS_DQ = 2 * 3 * la::TILE_B, LDS_DKV = 2 * (4 * la::TILE_B + 512);
+  static unsigned long long m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+  if (dt == LA_F16) {
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dq_kernel<la::f16_t>), LDS_DQ, m1);
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dkv_kernel<la::f16_t>), LDS_DKV, m2);
+    hipLaunchKernelGGL(la::attn_bwd_dq_kernel<la::f16_t>, dim3(nblk), dim3(256), LDS_DQ, st, a);      // first: it writes D
+    hipLaunchKernelGGL(la::attn_bwd_dkv_kernel<la::f16_t>, dim3(nblk), dim3(256), LDS_DKV, st, a);
+  } else {
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dq_kernel<la::bf16_t>), LDS_DQ, m3);
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dkv_kernel<la::bf16_t>), LDS_DKV, m4);
+    hipLaunchKernelGGL(la::attn_bwd_dq_kernel<la::bf16_t>, dim3(nblk), dim3(256), LDS_DQ, st, a);
+    hipLaunchKernelGGL(la::attn_bwd_dkv_kernel<la::bf16_t>, dim3(nblk), dim3(256), LDS_DKV, st, a);
+  }
+  LA_CHECK_LAUNCH("la_attn_bwd");
+  return 0;
+}

@@ -113,6 +113,7 @@ struct AttnArgs {
   const void* tabw;
   int B, heads, T, Tpad, G, E;
   float scale;
+  float* lse;         // optional [B*heads, Tpad] (row stride Tpad): log2-domain log-sum-exp of every query row (la_attn_fwd_lse: the training forward)
 };
 
 // MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
@@ -499,6 +500,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.0f / l_tot;
+  if (a.lse != nullptr && q < T_ && fh == 0) a.lse[(size_t)bh * a.Tpad + q] = m_run * c2 + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
   if (q < T_) {
     T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HDT;
 #pragma unroll
@@ -730,7 +732,7 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
                "la_attn_fwd: needs head_dim 64 or 128 - pad other widths with zero columns (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd: bad dtype %d", dt);
-  la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale};
+  la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale, nullptr};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t kv = 0;       // launch_attn adds the K / V^T stages for the head width; the sizes below are the bias tables
   if (mode == LA_ATTN_PLAIN) {
@@ -779,5 +781,19 @@ extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const f
     LA_CHECK_ARG(false, "la_attn_fwd: bad mode %d", mode);
   }
   LA_CHECK_LAUNCH("la_attn_fwd");
+  return 0;
+}
+
+extern "C" int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, float* lse, int B, int heads, int T, int Tpad, int E, float scale,
+                               int dt, void* stream) {
+  LA_CHECK_ARG(qkv && vt && out16 && lse, "la_attn_fwd_lse: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_fwd_lse: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_lse: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_lse: bad dtype %d", dt);
+  la::AttnArgs a{qkv, vt, out16, nullptr, nullptr, nullptr, nullptr, B, heads, T, Tpad, 0, E, scale, lse};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, 0, st);
+  else la::launch_attn<la::bf16_t, 0>(a, 0, st);
+  LA_CHECK_LAUNCH("la_attn_fwd_lse");
   return 0;
 }

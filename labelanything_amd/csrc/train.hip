@@ -582,6 +582,41 @@ static int grid_for_n(long n) {
   return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Image-encoder backward helpers (train_encoder.py).  la_cast: dst = scale * src between fp32 and 16-bit (or fp32 in place: the
+// un-scaling of loss-scaled gradients); la_gelu_bwd16: dpre = dh * gelu'(pre) with the pre-activation kept in 16 bit.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long n, float scale) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 256 * 4) {
+    if (i + 3 < n) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)src[i + k] * scale;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[i + k] = (TD)v[k];
+    } else {
+      for (long k = i; k < n; ++k) dst[k] = (TD)((float)src[k] * scale);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd16_kernel(const T* __restrict__ pre, const float* __restrict__ dh, float* __restrict__ d32,
+                                                         T* __restrict__ d16, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float g = dh[i] * gelu_grad((float)pre[i]);
+    if (d32) d32[i] = g;
+    if (d16) d16[i] = (T)g;
+  }
+}
+
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = fmaf(a, x[i], y[i]);
+}
+
 }  // namespace la
 
 extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream) {
@@ -763,5 +798,38 @@ extern "C" int la_row_broadcast(const float* src, long groups, int rep, int D, f
   hipLaunchKernelGGL(la::row_broadcast_kernel, dim3(la::grid_for_n(groups * rep * (D / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      src, groups, rep, D, scale, out);
   LA_CHECK_LAUNCH("la_row_broadcast");
+  return 0;
+}
+
+extern "C" int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float scale, void* stream) {
+  LA_CHECK_ARG(src && dst && n > 0, "la_cast: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(la::grid_for_n((n + 3) / 4)), blk(256);
+#define LA_CAST(TS, TD) hipLaunchKernelGGL((la::cast_kernel<TS, TD>), grid, blk, 0, st, (const TS*)src, (TD*)dst, n, scale)
+  if (src_dt == LA_F32 && dst_dt == LA_F16) LA_CAST(float, la::f16_t);
+  else if (src_dt == LA_F32 && dst_dt == LA_BF16) LA_CAST(float, la::bf16_t);
+  else if (src_dt == LA_F16 && dst_dt == LA_F32) LA_CAST(la::f16_t, float);
+  else if (src_dt == LA_BF16 && dst_dt == LA_F32) LA_CAST(la::bf16_t, float);
+  else if (src_dt == LA_F32 && dst_dt == LA_F32) LA_CAST(float, float);
+  else LA_CHECK_ARG(false, "la_cast: unsupported conversion %d -> %d", src_dt, dst_dt);
+#undef LA_CAST
+  LA_CHECK_LAUNCH("la_cast");
+  return 0;
+}
+
+extern "C" int la_gelu_bwd16(const void* pre16, const float* dh, float* d32, void* d16, long n, int dt, void* stream) {
+  LA_CHECK_ARG(pre16 && dh && (d32 || d16) && n > 0 && (dt == LA_F16 || dt == LA_BF16), "la_gelu_bwd16: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(la::grid_for_n(n)), blk(256);
+  if (dt == LA_F16) hipLaunchKernelGGL(la::gelu_bwd16_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)pre16, dh, d32, (la::f16_t*)d16, n);
+  else hipLaunchKernelGGL(la::gelu_bwd16_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)pre16, dh, d32, (la::bf16_t*)d16, n);
+  LA_CHECK_LAUNCH("la_gelu_bwd16");
+  return 0;
+}
+
+extern "C" int la_axpy(const float* x, float* y, long n, float a, void* stream) {
+  LA_CHECK_ARG(x && y && n > 0, "la_axpy: bad arguments");
+  hipLaunchKernelGGL(la::axpy_kernel, dim3(la::grid_for_n(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n, a);
+  LA_CHECK_LAUNCH("la_axpy");
   return 0;
 }

@@ -48,6 +48,8 @@ class FlatAdamW:
             off += k
         self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.num_warmup_steps = int(num_warmup_steps)
+        self.keep_reduced_grad = False  # tests: keep a copy of the all-reduced, world-averaged gradient of the last step
+        self.reduced_grad = None
         self.steps = 0                 # optimizer steps taken
         self.tensor_steps = [0] * len(self.params)   # torch.optim.AdamW keeps state['step'] PER parameter: it only advances on
         #                                              steps where the tensor has a gradient, and drives that tensor's bias correction
@@ -71,6 +73,8 @@ class FlatAdamW:
         if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size()
             sum_over_ranks(self.grad)
+        if self.keep_reduced_grad:
+            self.reduced_grad = self.grad / float(world)
         self.steps += 1
         if active is None:
             active = [True] * len(self.params)

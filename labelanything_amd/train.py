@@ -321,11 +321,17 @@ class LamTrainer:
     ``Lam.get_learnable_params({'freeze_backbone': True})``."""
 
     def __init__(self, lam: Lam, lr: float = 5e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
-                 num_warmup_steps: int = 0, loss: Optional[FocalLossDevice] = None):
+                 num_warmup_steps: int = 0, loss: Optional[FocalLossDevice] = None, train_encoder: bool = False):
+        """train_encoder=False: ``get_learnable_params({'freeze_backbone': True})`` - the image encoder is frozen (and absent from
+        the flat buffer).  train_encoder=True: every parameter trains, as with parameters/trainval/coco20i/mae_noembs.yaml (no
+        ``freeze_backbone``: models/lam.py:347 returns ``self.parameters()``); needs an HF ViT encoder (train_encoder.py)."""
         if lam._device().type != "cuda":
             raise RuntimeError("LamTrainer needs the model on an MI355X (there is no CPU path)")
         self.lam = lam
-        named = [(k, p) for k, p in lam.named_parameters() if "image_encoder" not in k]
+        self.train_encoder = bool(train_encoder)
+        if self.train_encoder and lam.cfg.encoder_spec is None:
+            raise ValueError("train_encoder=True needs a model with an image encoder")
+        named = [(k, p) for k, p in lam.named_parameters() if self.train_encoder or "image_encoder" not in k]
         # tensors the forward never reaches (dead in the reference too, prompt_encoder.py:683) go to the tail of the flat buffer so
         # that the per-step "received a gradient" spans of FlatAdamW.step stay one contiguous run
         dead = ("prompt_encoder.transformer.final_attn_token_to_image.", "prompt_encoder.transformer.norm_final_attn.")
@@ -345,8 +351,14 @@ class LamTrainer:
         for (_, p), gv in zip(named, self.opt.grad_views):
             p.grad = gv                      # autograd accumulates straight into the flat gradient buffer
         self.crit = loss or FocalLossDevice()
-        self.engine = lam.engine()           # frozen encoder: its packed weights never change
+        self.engine = lam.engine()           # host-side helpers + the frozen encoder (its packed weights never change)
         self.graph = DecoderGraph(lam, self.engine)
+        self.enc_graph = None
+        if self.train_encoder:
+            from .train_encoder import HfEncoderGraph
+            self.enc_graph = HfEncoderGraph(lam, {k: gv for k, gv in zip(self.names, self.opt.grad_views) if k.startswith("image_encoder.")})
+            self._anchor = torch.zeros(1, device=lam._device(), requires_grad=True)
+            self._enc_idx = [i for i, k in enumerate(self.names) if k.startswith("image_encoder.")]
 
     def forward_backward(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
         lam = self.lam
@@ -356,6 +368,7 @@ class LamTrainer:
                 if "flag_gts" in batch:
                     inp["flag_gts"] = batch["flag_gts"].to(lam._device())
                 eng = self.engine
+                through_encoder = False
                 if "embeddings" in inp:
                     emb = inp["embeddings"]
                     b, n, c, h, w = emb.shape
@@ -365,8 +378,17 @@ class LamTrainer:
                 else:
                     im = inp["images"]
                     b, n = im.shape[:2]
-                    e32, _, c, g = eng.encode_images(im.flatten(0, 1))
-                    e_rows = e32.clone()
+                    g = im.shape[-1] // lam.cfg.encoder_spec.patch
+                    if self.enc_graph is None:
+                        e32, _, c, g = eng.encode_images(im.flatten(0, 1))
+                        e_rows = e32.clone()
+                    else:
+                        through_encoder = True
+            if through_encoder:                       # forward with saved activations; its backward hangs off the decoder graph's
+                from .train_encoder import encode_trainable
+                e_rows = encode_trainable(self.enc_graph, im.flatten(0, 1), self._anchor)
+                for i in self._enc_idx:
+                    self._touched[i] = True
             out = self.graph.forward(e_rows, b, n, g, inp, batch["dims"], neck_input=True)
             loss = _FocalObjective.apply(out["logits"], gt.to(lam._device()), self.crit)
             (loss / loss_normalizer).backward()

@@ -1,0 +1,267 @@
+"""Training THROUGH the image encoder (SURVEY 8f row 1 as BASELINE cfg3 names it): forward with saved activations and a hand-written
+backward of the HF ViT stack (transformers ViTModel under models/build_encoder.py:83-100) on HIP kernels.
+
+Which configuration this is: ``parameters/trainval/coco20i/mae_noembs.yaml`` has no ``freeze_backbone``, so
+``Lam.get_learnable_params`` (models/lam.py:321-347) returns ``self.parameters()`` - the ViT-B backbone (85.8 M parameters) trains
+together with neck, prompt encoder and mask decoder.  (``mae.yaml`` is the decoder-only training on precomputed embeddings.)
+
+Numerics: the forward is the inference engine's (16-bit MFMA operands, split-precision weight planes as ``Lam.precise`` says), run
+layer by layer with the activations the backward needs kept in HBM (36 E bytes per token and layer: 7.8 GB per 26-image episode of
+ViT-B at 480 px - nothing at 288 GB).  The backward runs its GEMM operands in the same 16-bit type under LOSS SCALING: the gradient
+that arrives from the decoder graph is multiplied by a power of two that puts its largest entry near 64, every 16-bit operand and
+fp32 intermediate of the encoder backward carries that factor, and the parameter gradients are un-scaled when they are folded into
+the flat gradient buffer (non-finite results: the step is repeated with a smaller factor).
+  data gradients   dX = dY . W     la_gemm on W^T re-packed per step (16-bit single plane)
+  weight gradients dW += dY^T . X  la_gemm_tn (exact-fp32 MFMA on fp32 copies of dY and X)
+  attention        la_attn_fwd_lse / la_attn_bwd (flash form, recomputed probabilities, csrc/attn_bwd.hip)
+  LayerNorm, GELU  la_layernorm_bwd, la_gelu_bwd16
+Scope: plain (HF) attention with 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5).  The SAM ViTDet stack (windows, decomposed
+relative positions) has no backward here; its trainings in the reference freeze it or use precomputed embeddings.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _ceil(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class HfEncoderGraph:
+    """One trainable HF ViT encoder.  ``grads``: parameter name (``image_encoder....``) -> fp32 tensor the gradient is ADDED to."""
+
+    TARGET_MAX = 64.0
+
+    def __init__(self, lam, grads: Dict[str, Tensor]):
+        spec = lam.cfg.encoder_spec
+        if spec is None or spec.kind != "hf":
+            raise NotImplementedError("the encoder backward covers the HF ViT stack (ViT-MAE / DINO / IN21k); the SAM ViTDet stack is forward only")
+        if spec.head_dim != 64:
+            raise NotImplementedError(f"encoder backward needs 64-wide heads (got {spec.head_dim})")
+        self.lam, self.spec, self.grads = lam, spec, grads
+        self.w: Dict[str, Tensor] = {k: v for k, v in lam.state_dict(keep_vars=True).items() if k.startswith("image_encoder.")}
+        missing = [k for k, v in self.w.items() if v.is_floating_point() and k not in grads]
+        if missing:
+            raise KeyError(f"no gradient slot for {missing[:3]} ...")
+        n = sum(self.w[k].numel() for k in grads)
+        dev = lam._device()
+        self.scratch = torch.zeros(n, device=dev)               # loss-scaled gradients of one backward pass
+        self.sviews: Dict[str, Tensor] = {}
+        off = 0
+        for k in grads:
+            m = self.w[k].numel()
+            self.sviews[k] = self.scratch[off:off + m].view_as(self.w[k])
+            off += m
+        self.ctx = None
+        self.last_scale = 1.0
+
+    # ---- forward ---------------------------------------------------------------------------------------------------------------
+    def _qkv_plain(self, eng, x16: Tensor, key: str, qkv: Tensor, ea: int) -> None:
+        """q | k | v rows of x W^T + b, V row-major as well (the inference path writes V only transposed)."""
+        b = eng.p[key[:-2] + ".b"]
+        if (key + ".qk") in eng.p:
+            L.gemm(x16, eng.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea])
+            L.gemm(x16, eng.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], a_kmod=eng.kmod.get(key + ".v", 0))
+        else:
+            eng.gemm_w(x16, key, bias=b, out16=qkv)
+
+    @torch.no_grad()
+    def forward(self, images: Tensor) -> Tensor:
+        """(Bn, 3, S, S) fp32 on the device -> [Bn * hw, E] fp32 NHWC rows (CLS dropped), activations kept for ``backward``."""
+        eng = self.lam.engine()            # re-packed from the live parameters (LamTrainer.apply_update invalidated the last one)
+        spec, w, p = self.spec, eng.w32, eng.p
+        pre = "image_encoder"
+        images = images.contiguous()
+        bn, _, s, _ = images.shape
+        e, heads, g = spec.dim, spec.heads, s // spec.patch
+        hw, t = g * g, g * g + 1
+        rows, tpad = bn * t, _ceil(t, 64)
+        dev, dt = images.device, eng.dt
+        pos = eng._hf_pos(g)
+        cls_row = eng._hfpos_cache[-g]
+        a, akw = eng.patches("hf.patchA", images, bn * hw, spec.patch)
+        res = torch.empty(rows, e, device=dev)
+        res.view(bn, t, e)[:, 0].copy_(cls_row)
+        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".embeddings.patch_embeddings.projection.bias"], res=pos, res_mod=t, out32=res,
+               map=L.MAP_GROUP, p=(hw, t, 1, 0, 0), **akw)
+        scale = spec.head_dim ** -0.5
+        layers: List[dict] = []
+        vt = torch.zeros(bn * heads, 64, tpad, device=dev, dtype=dt)
+        for i in range(spec.depth):
+            lp = f"{pre}.encoder.layer.{i}"
+            sv = {"x_in": res.clone()}
+            x16 = torch.empty(rows, e, device=dev, dtype=dt)
+            sv["xn"] = torch.empty(rows, e, device=dev)
+            eng.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, out32=sv["xn"])
+            sv["qkv"] = torch.empty(rows, 3 * e, device=dev, dtype=dt)
+            self._qkv_plain(eng, x16, lp + ".qkv.w", sv["qkv"], e)
+            L.head_transpose(sv["qkv"], 2 * e, bn, heads, t, tpad, vt)
+            sv["ao"] = torch.empty(rows, e, device=dev, dtype=dt)
+            sv["lse"] = torch.full((bn * heads, tpad), 1e30, device=dev)
+            L.attn_fwd_lse(sv["qkv"], vt, sv["ao"], sv["lse"], bn, heads, t, tpad, e, scale)
+            eng.gemm_w(sv["ao"], lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
+            sv["x_mid"] = res.clone()
+            x16b = torch.empty(rows, e, device=dev, dtype=dt)
+            sv["xnb"] = torch.empty(rows, e, device=dev)
+            eng.ln(res, lp + ".layernorm_after", 1e-12, out16=x16b, out32=sv["xnb"])
+            sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+            sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+            b1 = w[lp + ".intermediate.dense.bias"]
+            eng.gemm_w(x16b, lp + ".fc1.w", bias=b1, out16=sv["post"], act=L.ACT_GELU)      # exactly the inference epilogue ...
+            eng.gemm_w(x16b, lp + ".fc1.w", bias=b1, out16=sv["pre"])                       # ... and the pre-activation gelu' needs
+            eng.gemm_w(sv["post"], lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=res, out32=res)
+            layers.append(sv)
+        fin = torch.empty(rows, e, device=dev)
+        eng.ln(res, pre + ".layernorm", 1e-12, out32=fin)
+        out = fin.view(bn, t, e)[:, 1:].reshape(bn * hw, e).contiguous()
+        self.ctx = dict(images=images, layers=layers, x_fin=res, bn=bn, g=g, hw=hw, t=t, rows=rows, tpad=tpad, e=e, heads=heads,
+                        scale=scale, dt=dt)
+        return out
+
+    # ---- backward --------------------------------------------------------------------------------------------------------------
+    def _wt16(self, wt: Tensor, dt) -> Tensor:
+        """nn.Linear weight [N, K] fp32 -> W^T [K, N] 16-bit: the 'weight' of the data-gradient GEMM dX = dY . W."""
+        n, k = wt.shape
+        out = torch.empty(k, n, device=wt.device, dtype=dt)
+        L.nchw_to_nhwc(wt.detach().contiguous(), 1, n, k, out16=out, dt=L._DT[dt])
+        return out
+
+    def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x32: Tensor, wname: str, bname: str, dx32=None, dx16=None) -> None:
+        """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K])."""
+        wt = self.w[wname]
+        L.gemm_tn(dy32, x32, self.sviews[wname])
+        L.colsum_acc(dy32, self.sviews[bname])
+        L.gemm(dy16, self._wt16(wt, dy16.dtype), out32=dx32, out16=dx16)
+
+    @torch.no_grad()
+    def backward(self, d_out: Tensor) -> None:
+        """d_out: gradient w.r.t. ``forward``'s result [Bn * hw, E] fp32.  Adds every encoder parameter's gradient to ``grads``."""
+        amax = float(d_out.abs().max())
+        if not math.isfinite(amax):
+            raise FloatingPointError("non-finite gradient at the encoder output")
+        if amax == 0.0:
+            return
+        scale = 2.0 ** math.floor(math.log2(self.TARGET_MAX / amax))
+        for _ in range(4):
+            self.scratch.zero_()
+            self._backward_scaled(d_out, scale)
+            if bool(torch.isfinite(self.scratch.sum())):
+                break
+            scale /= 256.0                 # a 16-bit intermediate overflowed: repeat with more head-room
+        else:
+            raise FloatingPointError("encoder backward overflowed at every loss scale tried")
+        self.last_scale = scale
+        off = 0
+        for k, gslot in self.grads.items():
+            m = gslot.numel()
+            L.axpy(self.scratch[off:off + m], gslot.view(-1), 1.0 / scale)
+            off += m
+        self.ctx = None
+
+    def _backward_scaled(self, d_out: Tensor, s: float) -> None:
+        c = self.ctx
+        if c is None:
+            raise RuntimeError("HfEncoderGraph.backward without a forward")
+        spec, w, sv = self.spec, self.w, self.sviews
+        pre = "image_encoder"
+        bn, t, hw, rows, tpad, e, heads, dt = c["bn"], c["t"], c["hw"], c["rows"], c["tpad"], c["e"], c["heads"], c["dt"]
+        dev = d_out.device
+        dfin = torch.zeros(rows, e, device=dev)
+        tmp = torch.empty_like(d_out)
+        L.cast(d_out.contiguous(), tmp, s)
+        dfin.view(bn, t, e)[:, 1:].copy_(tmp.view(bn, hw, e))
+        dres = torch.empty(rows, e, device=dev)
+        L.layernorm_bwd(c["x_fin"], dfin, w[pre + ".layernorm.weight"], w[pre + ".layernorm.bias"], 1e-12, False, dres,
+                        sv[pre + ".layernorm.weight"], sv[pre + ".layernorm.bias"])
+        d16 = torch.empty(rows, e, device=dev, dtype=dt)
+        dh = torch.empty(rows, spec.mlp, device=dev)
+        dpre32 = torch.empty(rows, spec.mlp, device=dev)
+        dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+        x32w = torch.empty(rows, spec.mlp, device=dev)            # fp32 copy of a saved 16-bit activation (weight-gradient operand)
+        dxn = torch.empty(rows, e, device=dev)
+        dx = torch.empty(rows, e, device=dev)
+        dao = torch.empty(rows, e, device=dev, dtype=dt)
+        dqkv16 = torch.empty(rows, 3 * e, device=dev, dtype=dt)
+        dqkv32 = torch.empty(rows, 3 * e, device=dev)
+        kt = torch.empty(bn * heads, 64, tpad, device=dev, dtype=dt)
+        qt, dot = torch.empty_like(kt), torch.empty_like(kt)
+        dvec = torch.zeros(bn * heads, tpad, device=dev)
+        for i in reversed(range(spec.depth)):
+            lp = f"{pre}.encoder.layer.{i}"
+            a = c["layers"][i]
+            # ---- MLP: res = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------------------------------------
+            L.cast(dres, d16)
+            L.cast(a["post"], x32w)
+            self._linear_bwd(dres, d16, x32w, lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
+            L.gelu_bwd16(a["pre"], dh, dpre32, dpre16)
+            self._linear_bwd(dpre32, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias", dx32=dxn)
+            L.layernorm_bwd(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, False, dx,
+                            sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
+            L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])
+            # ---- attention: x_mid = x_in + proj(attn(LN1(x_in))) -------------------------------------------------------------
+            ao32 = x32w.view(-1)[: rows * e].view(rows, e)
+            L.cast(a["ao"], ao32)
+            self._linear_bwd(dres, d16, ao32, lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
+            L.head_transpose(a["qkv"], e, bn, heads, t, tpad, kt)
+            L.head_transpose(a["qkv"], 0, bn, heads, t, tpad, qt)
+            L.head_transpose(dao, 0, bn, heads, t, tpad, dot)
+            L.attn_bwd(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
+            L.cast(dqkv16, dqkv32)
+            att = lp + ".attention.attention."
+            for j, nm in enumerate(("query", "key", "value")):
+                dy = dqkv32[:, j * e:(j + 1) * e]
+                L.gemm_tn(dy, a["xn"], sv[att + nm + ".weight"])
+                L.colsum_acc(dy, sv[att + nm + ".bias"])
+            wqkv = torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]])       # [3E, E]
+            L.gemm(dqkv16, self._wt16(wqkv, dt), out32=dxn)
+            L.layernorm_bwd(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, False, dx,
+                            sv[lp + ".layernorm_before.weight"], sv[lp + ".layernorm_before.bias"])
+            L.add_cast(dres, dx, rows, out32=dres, dt=L._DT[dt])
+        # ---- embeddings: res0[b, 0] = cls + pos[0]; res0[b, 1 + i] = patch_i W^T + b + pos[1 + i] --------------------------------
+        emb = pre + ".embeddings."
+        d0 = dres.view(bn, t, e)
+        dpatch = d0[:, 1:].reshape(bn * hw, e).contiguous()
+        k = 3 * spec.patch * spec.patch
+        a32 = torch.empty(bn * hw, k, device=dev)
+        L.im2col_patch(c["images"], spec.patch, a32)
+        L.gemm_tn(dpatch, a32, sv[emb + "patch_embeddings.projection.weight"].view(e, k))
+        L.colsum_acc(dpatch, sv[emb + "patch_embeddings.projection.bias"])
+        dpos_rows = d0.sum(dim=0)                                   # [t, E]: a few hundred rows of bookkeeping, not a kernel
+        sv[emb + "cls_token"].view(-1).add_(dpos_rows[0])
+        pos = w[emb + "position_embeddings"]
+        if c["g"] == spec.pos_grid:
+            sv[emb + "position_embeddings"].view(t, e).add_(dpos_rows)
+        else:                                                       # through the bicubic resample of the patch positions
+            with torch.enable_grad():
+                leaf = pos.detach().clone().requires_grad_(True)
+                grid = leaf[:, 1:].reshape(1, spec.pos_grid, spec.pos_grid, e).permute(0, 3, 1, 2)
+                grid = F.interpolate(grid, size=(c["g"], c["g"]), mode="bicubic", align_corners=False)
+                full = torch.cat([leaf[:, :1], grid.permute(0, 2, 3, 1).reshape(1, hw, e)], dim=1)
+                (gpos,) = torch.autograd.grad(full, leaf, grad_outputs=dpos_rows.unsqueeze(0))
+            sv[emb + "position_embeddings"].add_(gpos)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Autograd shell: forward / backward of ``HfEncoderGraph`` around the decoder graph's autograd."""
+
+    @staticmethod
+    def forward(ctx, graph: HfEncoderGraph, images: Tensor, anchor: Tensor):
+        ctx.graph = graph
+        return graph.forward(images)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.graph.backward(g.contiguous())
+        return None, None, None
+
+
+def encode_trainable(graph: HfEncoderGraph, images: Tensor, anchor: Tensor) -> Tensor:
+    return _EncoderFn.apply(graph, images, anchor)

@@ -1,0 +1,158 @@
+"""GPU: backward through the image encoder (HF ViT stack) - the kernels one by one against torch autograd, then the whole encoder
+and the whole training step against the CPU oracle's autograd with EVERY parameter trainable, which is what the reference trains with
+parameters/trainval/coco20i/mae_noembs.yaml (no freeze_backbone -> Lam.get_learnable_params returns self.parameters(),
+models/lam.py:321-347)."""
+import math
+
+import pytest
+import torch
+
+from labelanything_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 197), (1, 3, 64), (3, 1, 130), (1, 2, 901)])
+def test_attention_forward_lse_and_backward_match_torch(shape):
+    b, heads, t = shape
+    e = heads * 64
+    tpad = (t + 63) // 64 * 64
+    g = torch.Generator().manual_seed(b * 1000 + t)
+    qkv = (torch.randn(b * t, 3 * e, generator=g) * 0.7).half().cuda()
+    dout = torch.randn(b * t, e, generator=g).half().cuda()
+    scale = 1.0 / math.sqrt(64)
+
+    def heads_t(src, col0):
+        dst = torch.empty(b * heads, 64, tpad, dtype=torch.float16, device="cuda")
+        L.head_transpose(src, col0, b, heads, t, tpad, dst)
+        return dst
+
+    vt = heads_t(qkv, 2 * e)
+    ref_vt = qkv[:, 2 * e:].view(b, t, heads, 64).permute(0, 2, 3, 1).reshape(b * heads, 64, t)
+    assert torch.equal(vt[:, :, :t], ref_vt) and float(vt[:, :, t:].abs().max() if tpad > t else 0) == 0.0
+    out = torch.empty(b * t, e, dtype=torch.float16, device="cuda")
+    lse = torch.full((b * heads, tpad), 1e30, device="cuda")
+    L.attn_fwd_lse(qkv, vt, out, lse, b, heads, t, tpad, e, scale)
+    # torch reference on the same (16-bit valued) inputs in fp64
+    x = qkv.double().cpu().view(b, t, 3, heads, 64).permute(2, 0, 3, 1, 4).requires_grad_(True)       # (3, b, heads, t, 64)
+    q, k, v = x[0], x[1], x[2]
+    s = (q @ k.transpose(-1, -2)) * scale
+    o = torch.softmax(s, -1) @ v                                                                        # (b, heads, t, 64)
+    o_rows = o.permute(0, 2, 1, 3).reshape(b * t, e)
+    assert float((out.double().cpu() - o_rows.detach()).abs().max()) <= 2e-3 * float(o_rows.abs().max())
+    ref_lse = torch.logsumexp(s.detach(), -1).reshape(b * heads, t) * 1.4426950408889634
+    assert float((lse[:, :t].double().cpu() - ref_lse).abs().max()) <= 2e-3
+    assert bool((lse[:, t:] == 1e30).all())
+    o_rows.backward(dout.double().cpu())
+    gref = x.grad.permute(1, 3, 0, 2, 4).reshape(b * t, 3 * e)                                          # rows (b, t), cols (q|k|v, head, d)
+    kt, qt, dot = heads_t(qkv, e), heads_t(qkv, 0), heads_t(dout, 0)
+    dvec = torch.zeros(b * heads, tpad, device="cuda")
+    dqkv = torch.zeros(b * t, 3 * e, dtype=torch.float16, device="cuda")
+    L.attn_bwd(qkv, out, dout, kt, qt, dot, lse, dvec, dqkv, b, heads, t, tpad, e, scale)
+    torch.cuda.synchronize()
+    got = dqkv.double().cpu()
+    for name, c0 in (("dq", 0), ("dk", e), ("dv", 2 * e)):
+        ref = gref[:, c0:c0 + e]
+        err = float((got[:, c0:c0 + e] - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 4e-3, (name, err)                      # P, dS and the outputs are rounded to fp16 (2^-11) once each
+    dref = (dout.double().cpu() * o_rows.detach()).view(b, t, heads, 64).sum(-1).permute(0, 2, 1).reshape(b * heads, t)
+    assert float((dvec[:, :t].double().cpu() - dref).abs().max()) <= 3e-3 * float(dref.abs().max())
+
+
+def _hf_cfg(size=240):
+    from labelanything_amd.config import LamConfig
+    return LamConfig(encoder="hf_tiny", image_size=size, image_embed_dim=128, embed_dim=64, spatial_convs=3, example_class_attention=False,
+                     custom_preprocess=False)
+
+
+@pytest.mark.parametrize("size", [240, 224])      # 240: position embeddings bicubically resampled 14 -> 15; 224: used as stored
+def test_encoder_gradients_of_a_linear_functional_match_oracle_autograd(size):
+    """HfEncoderGraph alone: L = sum(R * encoder(images)) for a fixed random R, every encoder parameter's gradient against torch
+    autograd of the CPU oracle's fp32 encoder (pinned on the reference).  16-bit MFMA operands forward and backward: the bound is the
+    measured level x 2 (the error-budget statement VERDICT r2 asks for: gradients through 16-bit operands do not reach 3e-4)."""
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train_encoder import HfEncoderGraph
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    import tests.cases  # noqa: F401  (registers hf_tiny)
+    cfg = _hf_cfg(size)
+    g = torch.Generator().manual_seed(size)
+    images = torch.randn(3, 3, size, size, generator=g)
+    sd = init_state_dict(cfg, 31)
+    wref = {k: (v.clone().requires_grad_(True) if k.startswith("image_encoder.") and v.is_floating_point() else v) for k, v in sd.items()}
+    out_ref = O.hf_vit_encoder(wref, geometry_for(cfg), images)                      # (Bn, C, g, g)
+    r = torch.randn(out_ref.shape, generator=g)
+    (out_ref * r).sum().backward()
+    lam = Lam(cfg, seed=31).cuda()
+    names = [k for k, p in lam.named_parameters() if k.startswith("image_encoder.")]
+    grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}
+    graph = HfEncoderGraph(lam, grads)
+    out = graph.forward(images.cuda())
+    bn, c, gg, _ = out_ref.shape
+    ref_rows = out_ref.detach().permute(0, 2, 3, 1).reshape(bn * gg * gg, c)
+    assert float((out.cpu() - ref_rows).abs().max()) <= 1e-3 * float(ref_rows.abs().max())
+    graph.backward(r.permute(0, 2, 3, 1).reshape(bn * gg * gg, c).contiguous().cuda())
+    torch.cuda.synchronize()
+    gmax = max(float(wref[k].grad.abs().max()) for k in names)
+    worst = {}
+    for k in names:
+        ref = wref[k].grad
+        worst[k] = float((grads[k].cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * gmax)
+    order = sorted(worst.items(), key=lambda kv: -kv[1])
+    print(f"encoder gradients (linear functional, size {size}, loss scale {graph.last_scale:g}): worst", [(k[14:], f"{v:.2e}") for k, v in order[:6]])
+    assert order[0][1] <= 1e-2, order[:6]
+
+
+def test_training_step_with_trainable_encoder_matches_oracle_autograd():
+    """LamTrainer(train_encoder=True) on the hf_tiny episode: loss, logits and EVERY parameter's gradient (encoder included) against
+    the oracle's autograd.  The decoder of a random-weight model amplifies the encoder's 16-bit operand error (the frozen-encoder
+    test holds the decoder gradients behind a HIP encoder to 1e-1 for the same reason); the encoder tensors sit behind it too."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from oracle import loss_oracle as LO
+    from tests.cases import CASES, geometry_for
+    from tests.test_train_gpu import make_gt
+    case = CASES["hf_tiny_1w1s_masks"]
+    cfg = case["cfg"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    w = {k: v.clone().requires_grad_(v.is_floating_point() and "gaussian" not in k) for k, v in init_state_dict(cfg, case["weight_seed"]).items()}
+    out = O.lam_forward(w, geometry_for(cfg), batch)
+    loss, _ = LO.focal_objective(out["logits"], gt)
+    loss.backward()
+    ref_g = {k: v.grad for k, v in w.items() if v.requires_grad and v.grad is not None}
+    lam = Lam(cfg, seed=case["weight_seed"]).cuda()
+    tr = LamTrainer(lam, train_encoder=True)
+    assert any(k.startswith("image_encoder.") for k in tr.names)
+    tr.zero_grad()
+    res = tr.forward_backward(batch, gt)
+    torch.cuda.synchronize()
+    assert abs(float(res["loss"]) - float(loss)) <= 1e-3 * max(1.0, abs(float(loss)))
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    worst, cos = {}, {}
+    for k, gv in zip(tr.names, tr.opt.grad_views):
+        ref = ref_g.get(k)
+        if ref is None:
+            assert float(gv.abs().max()) == 0.0, k
+            continue
+        assert torch.isfinite(gv).all(), k
+        mine = gv.cpu()
+        worst[k] = float((mine - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * gmax)
+        if float(ref.norm()) > 1e-3 * gmax * ref.numel() ** 0.5:
+            cos[k] = float(torch.nn.functional.cosine_similarity(mine.flatten(), ref.flatten(), dim=0))
+    enc = {k: v for k, v in worst.items() if k.startswith("image_encoder.")}
+    print("trainable-encoder step: worst encoder tensors", sorted(enc.items(), key=lambda kv: -kv[1])[:5],
+          "min cosine", min(cos.values()), min(cos, key=cos.get))
+    assert len(enc) >= 30
+    bad = {k: v for k, v in worst.items() if v > 1e-1}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    assert min(cos.values()) >= 0.995
+    # and an optimizer step moves the encoder
+    qw = dict(lam.named_parameters())["image_encoder.encoder.layer.0.attention.attention.query.weight"]
+    before = qw.detach().clone()
+    tr.apply_update()
+    assert not torch.equal(before, qw.detach())
