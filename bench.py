@@ -94,7 +94,8 @@ class KernelTimer:
         names = ["twoway_t2i", "twoway_i2t", "gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
                  "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
-                 "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc"]
+                 "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
+                 "attn_fwd_lse", "attn_bwd", "head_transpose", "cast", "gelu_bwd16", "axpy"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -124,6 +125,10 @@ class KernelTimer:
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
                     flops = 4.0 * b * heads * t * t * 64
+                elif _n == "attn_fwd_lse":
+                    flops = 4.0 * a[4] * a[5] * a[6] * a[6] * 64
+                elif _n == "attn_bwd":                       # 7 T x T x 64 products (S and dP twice: one kernel per output side)
+                    flops = 14.0 * a[9] * a[10] * a[11] * a[11] * 64
                 elif _n in ("twoway_t2i", "twoway_i2t"):     # the (groups, hw, D) fp32 stream: read once (t2i), read + written (i2t)
                     nbytes = a[0].numel() * 4.0 * (2 if _n == "twoway_i2t" else 1)
                 tag = _n
@@ -262,6 +267,8 @@ def main():
     ap.add_argument("--precise", default="default", help="encoder GEMM groups in split precision: 'default' (the parity-tested "
                     "configuration, engine.resolve_precise), 'none' (plain 16-bit operands everywhere: faster, misses the 1e-3 logit tolerance), "
                     "or a comma list of groups")
+    ap.add_argument("--train-encoder", action="store_true", help="cfg3_train only: train the ViT backbone too (mae_noembs.yaml has no "
+                    "freeze_backbone): forward with saved activations + encoder backward + 96 M-parameter gradient all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the torch-eager-on-GPU comparator that fills vs_baseline (cfg2, 1 GPU)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -296,7 +303,7 @@ def main():
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
     if train:
         from labelanything_amd.train import LamTrainer
-        trainer = LamTrainer(lam, lr=5e-5, num_warmup_steps=1000)           # mae_noembs.yaml:30-37
+        trainer = LamTrainer(lam, lr=5e-5, num_warmup_steps=1000, train_encoder=a.train_encoder)           # mae_noembs.yaml:30-37
         c = batch["flag_examples"].shape[2]
         gt = torch.randint(0, c, (a.episodes, WORKLOADS[a.workload]["episode"]["image_size"], WORKLOADS[a.workload]["episode"]["image_size"]),
                            generator=torch.Generator().manual_seed(99 + rank)).to(dev)
@@ -373,7 +380,7 @@ def main():
         eps = a.episodes * world * a.steps / elapsed
         line = {
             "metric": "episodes/sec (query+support fwd) ViT-B 1024px 1-shot" if a.workload == "cfg2" else
-                      (f"episodes/sec (training steps) {a.workload}" if train else f"episodes/sec (forward) {a.workload}"),
+                      (f"episodes/sec (training steps{', trainable encoder' if a.train_encoder else ''}) {a.workload}" if train else f"episodes/sec (forward) {a.workload}"),
             "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",

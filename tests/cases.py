@@ -102,3 +102,14 @@ TRAIN_CASE = dict(
                  embeddings_channels=96, grid=8, dims=[[100, 128]] * 5),
     lr=1e-3, weight_decay=1e-2, steps=3, warmup=2,
 )
+
+
+# Same fixture with a TRAINABLE image encoder (tests/golden/train_step_encoder.safetensors): the reduced HF ViT at 240 px (position
+# embeddings resampled 14 -> 15) + LAM neck + decoder, masks + points, no freeze_backbone - parameters/trainval/coco20i/mae_noembs.yaml.
+TRAIN_ENC_CASE = dict(
+    cfg=LamConfig(encoder="hf_tiny", image_size=240, image_embed_dim=128, embed_dim=64, spatial_convs=3, example_class_attention=False,
+                  custom_preprocess=False),
+    weight_seed=22,
+    episode=dict(batch=1, n_ways=1, k_shots=2, image_size=240, seed=122, prompts=("mask", "point")),
+    lr=1e-3, weight_decay=1e-2, steps=2, warmup=2,
+)

@@ -156,3 +156,55 @@ def test_training_step_with_trainable_encoder_matches_oracle_autograd():
     before = qw.detach().clone()
     tr.apply_update()
     assert not torch.equal(before, qw.detach())
+
+
+def test_steps_with_trainable_encoder_match_the_reference_fixture():
+    """tests/golden/train_step_encoder.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up with
+    NO frozen parameters (tools/make_golden_train.py, hf_tiny at 240 px): losses, per-tensor gradient norms of the first step, the
+    full gradient and the final value of 13 tensors (10 of them inside the image encoder)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from tests.cases import TRAIN_ENC_CASE as case
+    from tests.helpers import GOLDEN, rel_err
+    gold = load_file(os.path.join(GOLDEN, "train_step_encoder.safetensors"))
+    with open(os.path.join(GOLDEN, "train_step_encoder.json")) as fh:
+        keys = json.load(fh)["keys"]
+    batch = make_episode(**case["episode"])
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    start = {k: p.detach().clone() for k, p in lam.named_parameters()}
+    tr = LamTrainer(lam, lr=case["lr"], weight_decay=case["weight_decay"], num_warmup_steps=case["warmup"], train_encoder=True)
+    assert sorted(tr.names) == keys
+    losses = []
+    for step in range(case["steps"]):
+        tr.zero_grad()
+        res = tr.forward_backward(batch, gold["gt"])
+        losses.append(float(res["loss"]))
+        if step == 0:
+            assert rel_err(res["logits"], gold["logits0"]) <= 1e-3
+            g0 = {k: gv.clone() for k, gv in zip(tr.names, tr.opt.grad_views)}
+        tr.apply_update()
+    assert torch.allclose(torch.tensor(losses), gold["loss"], rtol=2e-3, atol=0), (losses, gold["loss"])
+    gn = torch.stack([g0[k].norm() for k in keys]).cpu()
+    floor_g = 1e-2 * float(gold["grad_norm"].max())
+    rel_n = (gn - gold["grad_norm"]).abs() / gold["grad_norm"].clamp_min(floor_g)
+    print("trainable-encoder fixture: worst gradient-norm error", float(rel_n.max()), keys[int(rel_n.argmax())])
+    assert float(rel_n.max()) <= 5e-2
+    params = dict(lam.named_parameters())
+    gmax = max(float(v.abs().max()) for k, v in gold.items() if k.startswith("grad."))
+    worst = 0.0
+    for k, v in gold.items():
+        if k.startswith("grad."):
+            err = float((g0[k[5:]].cpu() - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gmax)
+            worst = max(worst, err)
+            assert err <= 6e-2, (k, err)
+        if k.startswith("final."):
+            name = k[6:]
+            mine, ref0 = params[name].detach().cpu(), start[name].cpu()
+            sig = gold["grad." + name].abs() > 5e-2 * gold["grad." + name].abs().max()             # entries with a clear gradient
+            step_ref, step_mine = (v - ref0)[sig], (mine - ref0)[sig]
+            assert float((step_mine - step_ref).abs().max()) <= 5e-2 * float(step_ref.abs().max()), name
+    print("trainable-encoder fixture: worst entry-wise gradient error", worst)

@@ -28,33 +28,65 @@ FULL = ["neck.0.weight", "neck.3.bias", "prompt_encoder.mask_downscaling.0.weigh
         "mask_decoder.class_mlp.layers.2.weight"]
 
 
+FULL_ENC = ["image_encoder.embeddings.patch_embeddings.projection.weight", "image_encoder.embeddings.position_embeddings",
+            "image_encoder.embeddings.cls_token", "image_encoder.encoder.layer.0.attention.attention.query.weight",
+            "image_encoder.encoder.layer.0.layernorm_before.weight", "image_encoder.encoder.layer.1.attention.attention.value.weight",
+            "image_encoder.encoder.layer.1.attention.output.dense.bias", "image_encoder.encoder.layer.1.intermediate.dense.weight",
+            "image_encoder.encoder.layer.1.output.dense.weight", "image_encoder.layernorm.weight", "neck.0.weight",
+            "prompt_encoder.transformer.layers.0.cross_attn_token_to_image.v_proj.weight", "mask_decoder.output_upscaling.0.weight"]
+
+
 def main():
+    from tests.cases import TRAIN_CASE, TRAIN_ENC_CASE
+    run(TRAIN_CASE, "train_step", FULL, seed_gt=9)
+    run(TRAIN_ENC_CASE, "train_step_encoder", FULL_ENC, seed_gt=11)
+
+
+def _to_4x(k: str) -> str:
+    """This container's transformers names the ViT tensors differently from the 4.x names the repo (and the published checkpoints)
+    use; inverse of tools/make_golden.py:_hf_4x_to_local."""
+    if not k.startswith("image_encoder."):
+        return k
+    k = k.replace("image_encoder.encoder.layers.", "image_encoder.layers.")
+    if "image_encoder.layers." not in k:
+        return k
+    return (k.replace("image_encoder.layers.", "image_encoder.encoder.layer.")
+             .replace("attention.q_proj", "attention.attention.query").replace("attention.k_proj", "attention.attention.key")
+             .replace("attention.v_proj", "attention.attention.value").replace("attention.o_proj", "attention.output.dense")
+             .replace("mlp.fc1", "intermediate.dense").replace("mlp.fc2", "output.dense"))
+
+
+def run(case, out_name, full, seed_gt):
     from label_anything.experiment.utils import WrapperModule
     from label_anything.loss import LabelAnythingLoss
     from transformers import get_scheduler
-    from tests.cases import TRAIN_CASE, geometry_for
+    from tests.cases import geometry_for
     from tests.test_train_gpu import make_gt
     from oracle import lam_oracle as O
     from oracle import loss_oracle as LO
     from labelanything_amd.episodes import make_episode
 
-    case = TRAIN_CASE
     lam, sd = MG.build_reference(case)
     lam.train()                                     # dropout is 0 everywhere on this path; train() as the reference's loop does
     cfg = case["cfg"]
     batch = make_episode(**case["episode"])
     c = batch["flag_examples"].shape[2]
-    gt = make_gt(batch, c, seed=9)
+    gt = make_gt(batch, c, seed=seed_gt)
     gr = torch.Generator().manual_seed(case["weight_seed"] + 7)
-    rows = torch.cat([torch.zeros(1, dtype=torch.long), torch.randperm(cfg.bank_size - 1, generator=gr)[: c - 1] + 1])
-    lam.prompt_encoder.class_encoder.sample_rows = lambda C, device, _r=rows: _r.to(device)
+    rows = None
+    if cfg.bank_size:
+        rows = torch.cat([torch.zeros(1, dtype=torch.long), torch.randperm(cfg.bank_size - 1, generator=gr)[: c - 1] + 1])
+        lam.prompt_encoder.class_encoder.sample_rows = lambda C, device, _r=rows: _r.to(device)
     model = WrapperModule(lam, LabelAnythingLoss({"focal": {"weight": 1.0}}, class_weighting=True))
-    params = model.get_learnable_params({})      # no image encoder in this model: every parameter is learnable (lam.py:321-347)
-    named = {k: p for k, p in lam.named_parameters()}
-    assert len(params) == len(named)
+    # no freeze_backbone (mae_noembs.yaml): every parameter is learnable, the image encoder included (lam.py:321-347)
+    params = model.get_learnable_params({})
+    named = {_to_4x(k): p for k, p in lam.named_parameters()}
+    assert len(params) == len(named) and all(k in sd for k in named), [k for k in named if k not in sd][:4]
     opt = torch.optim.AdamW(params, lr=case["lr"], weight_decay=case["weight_decay"])
     sched = get_scheduler("constant_with_warmup", opt, num_warmup_steps=case["warmup"], num_training_steps=100)
-    out = {"selected_rows": rows, "gt": gt}
+    out = {"gt": gt}
+    if rows is not None:
+        out["selected_rows"] = rows
     start = {k: p.detach().clone() for k, p in named.items()}
     losses = []
     for step in range(case["steps"]):
@@ -83,11 +115,11 @@ def main():
     out["loss"] = torch.tensor(losses)
     out["grad_norm"] = torch.stack([grads[k].norm() for k in keys])
     out["delta_norm"] = torch.stack([(named[k].detach() - start[k]).norm() for k in keys])
-    for k in FULL:
+    for k in full:
         out["grad." + k] = grads[k].contiguous()
         out["final." + k] = named[k].detach().clone().contiguous()
-    save_file(out, os.path.join(ROOT, "tests", "golden", "train_step.safetensors"))
-    with open(os.path.join(ROOT, "tests", "golden", "train_step.json"), "w") as fh:
+    save_file(out, os.path.join(ROOT, "tests", "golden", out_name + ".safetensors"))
+    with open(os.path.join(ROOT, "tests", "golden", out_name + ".json"), "w") as fh:
         import json
         json.dump({"keys": keys, "losses": losses, "generated_by": "tools/make_golden_train.py", "torch": torch.__version__}, fh, indent=1)
     print("losses", losses, "tensors", len(keys), "bytes", sum(v.numel() * v.element_size() for v in out.values()))
