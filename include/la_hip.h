@@ -84,6 +84,10 @@ typedef struct LaGemmEpilogue {
   int vt_ws;           /* > 0: token t of a ws x ws window goes to slot (t / ws) * 16 + t % ws of the V^T row (LA_ATTN_RELPOS_WIN16) */
   int amap;            /* source-row map (LA_MAP_NONE or LA_MAP_WINDOW_PART), see above */
   int a_kmod;          /* > 0: period of the A columns (split-precision weights [W_hi | W_lo]), see above */
+  int ksplit;          /* != 0 (16-bit operands): out32 += A . W^T - the bare product ADDED with fp32 atomics, the K range cut into
+                          independent chunks so that a product with few output tiles and a very long K (a weight gradient
+                          dW[N, K] = dY^T X over all tokens, operands passed transposed) still fills the chip.  N % 256 == 0, K % 64 == 0;
+                          no bias / residual / activation / maps / out16. */
 } LaGemmEpilogue;
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.
@@ -324,6 +328,10 @@ int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const vo
 
 /* dst = scale * src, n contiguous elements, between LA_F32 and LA_F16 / LA_BF16 (either direction) or LA_F32 -> LA_F32 (in place allowed). */
 int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float scale, void* stream);
+
+/* dst[c][r] = src[r][c] (fp32 or 16-bit [R, ld] -> 16-bit [C, Rp], zero for R <= r < Rp, Rp % 64 == 0): the token-contiguous operands of
+ * a split-K weight-gradient la_gemm (LaGemmEpilogue.ksplit). */
+int la_transpose16(const void* src, int src_dt, int ld, int R, int C, void* dst, int dst_dt, int Rp, void* stream);
 
 /* y += a * x, n contiguous fp32 elements (loss-scaled encoder gradients folded into the flat gradient buffer). */
 int la_axpy(const float* x, float* y, long n, float a, void* stream);

@@ -30,7 +30,7 @@ class LaGemmEpilogue(C.Structure):
         ("act", C.c_int), ("map", C.c_int),
         ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int), ("p3", C.c_int), ("p4", C.c_int),
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_T", C.c_int), ("vt_Tpad", C.c_int),
-        ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int), ("a_kmod", C.c_int),
+        ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int), ("a_kmod", C.c_int), ("ksplit", C.c_int),
     ]
 
 
@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16",
 ]
 
 
@@ -100,7 +100,7 @@ def _dev(t: torch.Tensor) -> None:
 # ----------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, out32=None, out16=None,
          act=ACT_NONE, map=MAP_NONE, p=(0, 0, 0, 0, 0), vt=None, vt_col0=0, vt_T=0, vt_Tpad=0, vt_hd=64,
-         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0) -> None:
+         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0, ksplit=0) -> None:
     """C = epilogue(a @ w.T).  a: [M,K] 16-bit (row stride lda), w: [N,K] 16-bit.  a_kmod > 0: w is [N, j*a_kmod] (split-precision
     planes [W_hi | W_lo]) and the columns of a repeat with period a_kmod."""
     _dev(a)
@@ -123,6 +123,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, ou
     e.vt_ws = vt_ws
     e.amap = amap
     e.a_kmod = a_kmod
+    e.ksplit = ksplit
     rc = lib().la_gemm(_ptr(a), C.c_int(a.stride(0) if lda is None else lda), _ptr(w), C.c_int(w.stride(0)),
                        C.c_int(m), C.c_int(n), C.c_int(k), C.byref(e), C.c_int(dt_of(a)), _stream())
     _check(rc, "la_gemm")
@@ -456,3 +457,13 @@ def axpy(x, y, a: float) -> None:
     """y += a * x (contiguous fp32)."""
     _f32c(x, y)
     _check(lib().la_axpy(_ptr(x), _ptr(y), C.c_long(x.numel()), C.c_float(a), _stream()), "la_axpy")
+
+
+def transpose16(src, dst) -> None:
+    """dst[c, r] = src[r, c]; src fp32 / 16-bit [R, C] (row stride src.stride(0)), dst 16-bit [C, Rp] with Rp >= R, Rp % 64 == 0 (zero padded)."""
+    _dev(src)
+    r, c = src.shape
+    if src.stride(1) != 1 or not dst.is_contiguous() or dst.shape[0] != c:
+        raise ValueError("transpose16: src needs unit column stride, dst contiguous [C, Rp]")
+    _check(lib().la_transpose16(_ptr(src), C.c_int(dt_of(src)), C.c_int(src.stride(0)), C.c_int(r), C.c_int(c), _ptr(dst), C.c_int(dt_of(dst)),
+                                C.c_int(dst.shape[1]), _stream()), "la_transpose16")

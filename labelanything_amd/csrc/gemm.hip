@@ -1645,9 +1645,13 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
 // 0's M interval) exactly as in t256p; the seam (epilogue through the private slabs, next tile's first k-tile already in flight,
 // store slack in the first two waits of a tile) is the same as well.
 // =================================================================================================================
+// EPI 4 (split-K weight gradients): no bias / activation / residual - the accumulators are ADDED to out32 with fp32 atomics, straight
+// from the accumulator layout (a register is 32 consecutive columns of one row per half wave: 128-byte segments).  ksplit > 1 cuts the
+// K range into chunks of kchunk (a multiple of 64) that run as independent tiles: dW[N, K] = dY^T X over 10^4 - 10^5 tokens has
+// 9 - 36 output tiles only, the chunks are what fills the chip.
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
-                                                             int M, int N, int K, LaGemmEpilogue e, int gm) {
+                                                             int M, int N, int K, LaGemmEpilogue e, int gm, int ksplit, int kchunk) {
   constexpr int BK_ = 64;
   constexpr int OPB = 256 * BK_ * 2;                 // 32 KiB per operand k-tile
   constexpr int BUFB = 2 * OPB;                      // 64 KiB per k-tile
@@ -1659,7 +1663,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wi = wave & 3;
   const int fr = lane & 31, fh = lane >> 5;
-  const int ntn = N / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
+  const int ntn = N / 256, ntm = (M + 255) / 256, ntmn = ntm * ntn, ntiles = ntmn * ksplit;
   char* slab = smem + 2 * BUFB + wave * 2048;
   unsigned* rtab = nullptr;
   if (EPI == 1 && e.map != LA_MAP_NONE) rtab = reinterpret_cast<unsigned*>(smem + 2 * BUFB + 8 * 2048 + wave * 512);
@@ -1674,11 +1678,17 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
   // k-tile, when every piece of the current tile has been issued - a second set cost 8 VGPRs and, at 256, spills whose reloads the
   // compiler guards with s_waitcnt vmcnt(0): each one drains the DMA ring and the epilogue's own store burst)
   unsigned soff[4][2];
-  auto plan = [&](int tile, int& m0, int& n0) {
+  int kb_issue = 0;                                  // first k of the chunk the offsets in soff belong to
+  auto plan = [&](int tile, int& m0, int& n0, int& kb, int& nkt) {
     int tm_, tn_;
-    tile_coords(xcd_remap(tile, ntiles), ntm, ntn, gm, tm_, tn_);
+    const int tt = xcd_remap(tile, ntiles);
+    const int chunk = tt / ntmn;
+    tile_coords(tt - chunk * ntmn, ntm, ntn, gm, tm_, tn_);
     m0 = tm_ * 256;
     n0 = tn_ * 256;
+    kb = chunk * kchunk;
+    nkt = (min(K, kb + kchunk) - kb) / BK_;
+    kb_issue = kb;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1692,7 +1702,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
   const unsigned lds0 = lds_addr_of(smem);
   auto dma_q = [&](int q, int kt, int buf) {
     const bool isw = (q == 1 || q == 2);
-    const T* src = isw ? Wt + kt * BK_ : A + a_koff(e, kt * BK_);
+    const T* src = isw ? Wt + kb_issue + kt * BK_ : A + a_koff(e, kb_issue + kt * BK_);
 #pragma unroll
     for (int i = 0; i < 2; ++i) dma16s(src, soff[q][i], lds0 + buf * BUFB + (isw ? OPB : 0) + piece_row0(q, i) * 128);
   };
@@ -1705,7 +1715,6 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = K / BK_;                            // >= 2 (host side)
   uint4 af[2][4], wf[4];
   auto read_a = [&](int buf, int sub) {
     const char* sa = smem + buf * BUFB;
@@ -1725,9 +1734,9 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
     asm volatile("" ::: "memory");
   };
 
-  int m0, n0, m0n = 0, n0n = 0;
+  int m0, n0, kb0, nk, m0n = 0, n0n = 0, kbn = 0, nkn = 0;       // nk: 64-deep k-tiles of the current tile (>= 2, host side)
   int tile = blockIdx.x;
-  plan(tile, m0, n0);
+  plan(tile, m0, n0, kb0, nk);
 #pragma unroll
   for (int q = 0; q < 4; ++q) dma_q(q, 0, 0);
   dma_wait<4>();                                     // Q0, Q1 of k-tile 0 ...
@@ -1741,7 +1750,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
     for (int kt = 0; kt < nk; ++kt) {
       const bool last = kt + 1 == nk;
       const bool feed = !last || more;               // a k-tile follows in the stream
-      if (last && more) plan(next, m0n, n0n);        // every piece of this tile is on its way: the offsets now describe the next tile
+      if (last && more) plan(next, m0n, n0n, kbn, nkn);        // every piece of this tile is on its way: the offsets now describe the next tile
       // counted wait at the end of phase q (q = 3, 0, 1); see the header
       auto retire = [&](int q) {
         if (q == 3) {
@@ -1797,10 +1806,23 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if (EPI == 4) {
+      const int fr_ = lane & 31, fh_ = lane >> 5;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + grp * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh_;
+          if (row < M) {
+            float* op = e.out32 + (size_t)row * e.ld32 + n0 + wi * 64 + fr_;
+            unsafeAtomicAdd(op, acc[i][0][r]);
+            unsafeAtomicAdd(op + 32, acc[i][1][r]);
+          }
+        }
     } else {
-      epilogue_wave<T, EPI>(slab, rtab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane, nostore);
+      epilogue_wave<T, (EPI == 4 ? 1 : EPI)>(slab, rtab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane, nostore);
     }
-    seam_slack = (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0) && !nostore && !noepi;
+    seam_slack = EPI != 4 && (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0) && !nostore && !noepi;
     bar();
     if (!more) break;
     if (grp == 1) bar();
@@ -1812,6 +1834,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     m0 = m0n;
     n0 = n0n;
+    nk = nkn;
     tile = next;
   }
 }
@@ -1830,10 +1853,28 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (ncu <= 0) ncu = 256;
   }
-  const int ntiles = ((M + 255) / 256) * (N / 256);
-  const int grid = ntiles < ncu ? ntiles : ncu;
+  int ksplit = 1, kchunk = K;
+  if (EPI == 4) {
+    // chunks of c k-tiles (every chunk, the last included, at least 2 deep), about four rounds of tiles over the chip
+    const int tmn = ((M + 255) / 256) * (N / 256), nkt = K / 64;
+    int want = (4 * ncu + tmn - 1) / tmn;
+    static const char* wenv = getenv("LA_KSPLIT_WANT");      // debugging: force the number of K chunks
+    if (wenv) want = atoi(wenv);
+    if (want > nkt / 2) want = nkt / 2;
+    if (want < 1) want = 1;
+    int c = (nkt + want - 1) / want;
+    if (c < 2) c = 2;
+    while (c < nkt && (nkt % c) == 1) ++c;
+    if (c > nkt) c = nkt;
+    kchunk = c * 64;
+    ksplit = (nkt + c - 1) / c;
+  }
+  const int ntiles = ((M + 255) / 256) * (N / 256) * ksplit;
+  int grid = ntiles < ncu ? ntiles : ncu;
+  static const char* genv = getenv("LA_KSPLIT_GRID");      // debugging: workgroups launched (0 = one per tile)
+  if (EPI == 4 && genv) grid = atoi(genv) > 0 ? atoi(genv) : ntiles;
   hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800100));
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800100), ksplit, kchunk);
 }
 
 template <typename T, int NPL, int EPI>
@@ -2234,6 +2275,19 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     const la::ConvA nocv{0, 0, 0, 0};
     if (N <= 32) la::launch_f32<32>(A, lda, W, ldw, M, N, K, *epi, nocv, st);
     else la::launch_f32<128>(A, lda, W, ldw, M, N, K, *epi, nocv, st);
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
+  if (epi->ksplit > 0) {
+    // split-K accumulate (weight gradients): out32 += A . W^T with fp32 atomics, K cut into independent chunks
+    LA_CHECK_ARG(epi->out32 && !epi->out16 && !epi->res && !epi->bias && !epi->vt && epi->act == LA_ACT_NONE && epi->map == LA_MAP_NONE &&
+                     epi->amap == LA_MAP_NONE && epi->a_kmod == 0,
+                 "la_gemm: ksplit accumulates the bare product into out32 (no bias / residual / activation / maps / second output)");
+    LA_CHECK_ARG((N % 256) == 0 && (K % 64) == 0 && K >= 128 && (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32) &&
+                     (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
+                 "la_gemm: ksplit needs N %% 256 == 0, K %% 64 == 0, K >= 128, 16-byte aligned operands below 4 GiB (M=%d N=%d K=%d)", M, N, K);
+    if (dt == LA_F16) la::launch_t256q<la::f16_t, 4>(A, lda, W, ldw, M, N, K, *epi, st);
+    else la::launch_t256q<la::bf16_t, 4>(A, lda, W, ldw, M, N, K, *epi, st);
     LA_CHECK_LAUNCH("la_gemm");
     return 0;
   }

@@ -613,6 +613,35 @@ __global__ __launch_bounds__(256) void gelu_bwd16_kernel(const T* __restrict__ p
 }
 
 
+// dst[c][r] = (T)src[r][c] for r < R, 0 for R <= r < Rp: the token-contiguous 16-bit operands of a split-K weight-gradient GEMM
+// (la_gemm ksplit: dW[N, K] = dY^T X runs as A = dY^T [N, Rp], W = X^T [K, Rp]).  64 x 64 tiles through LDS.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose16_kernel(const TS* __restrict__ src, int ld, int R, int Cn, TD* __restrict__ dst, int Rp) {
+  __shared__ TD tile[64][64 + 2];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  {
+    const int r = tid >> 2, cb = (tid & 3) * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int rr = r0 + r, cc = c0 + cb + i;
+      tile[r][cb + i] = (rr < R && cc < Cn) ? (TD)(float)src[(size_t)rr * ld + cc] : (TD)0.f;
+    }
+  }
+  __syncthreads();
+  {
+    const int c = tid >> 2, rb = (tid & 3) * 16;
+    if (c0 + c < Cn) {
+      TD o[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = tile[rb + i][c];
+      TD* p = dst + (size_t)(c0 + c) * Rp + r0 + rb;
+      *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&o[0]);
+      *reinterpret_cast<uint4*>(p + 8) = *reinterpret_cast<const uint4*>(&o[8]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = fmaf(a, x[i], y[i]);
 }
@@ -831,5 +860,22 @@ extern "C" int la_axpy(const float* x, float* y, long n, float a, void* stream) 
   LA_CHECK_ARG(x && y && n > 0, "la_axpy: bad arguments");
   hipLaunchKernelGGL(la::axpy_kernel, dim3(la::grid_for_n(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, y, n, a);
   LA_CHECK_LAUNCH("la_axpy");
+  return 0;
+}
+
+extern "C" int la_transpose16(const void* src, int src_dt, int ld, int R, int Cn, void* dst, int dst_dt, int Rp, void* stream) {
+  LA_CHECK_ARG(src && dst && R > 0 && Cn > 0 && ld >= Cn && Rp >= R && (Rp % 64) == 0, "la_transpose16: bad arguments (R=%d C=%d ld=%d Rp=%d)", R, Cn,
+               ld, Rp);
+  LA_CHECK_ARG(dst_dt == LA_F16 || dst_dt == LA_BF16, "la_transpose16: 16-bit destination expected");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(Rp / 64, (Cn + 63) / 64), blk(256);
+#define LA_TR(TS, TD) hipLaunchKernelGGL((la::transpose16_kernel<TS, TD>), grid, blk, 0, st, (const TS*)src, ld, R, Cn, (TD*)dst, Rp)
+  if (src_dt == LA_F32 && dst_dt == LA_F16) LA_TR(float, la::f16_t);
+  else if (src_dt == LA_F32 && dst_dt == LA_BF16) LA_TR(float, la::bf16_t);
+  else if (src_dt == LA_F16 && dst_dt == LA_F16) LA_TR(la::f16_t, la::f16_t);
+  else if (src_dt == LA_BF16 && dst_dt == LA_BF16) LA_TR(la::bf16_t, la::bf16_t);
+  else LA_CHECK_ARG(false, "la_transpose16: unsupported conversion %d -> %d", src_dt, dst_dt);
+#undef LA_TR
+  LA_CHECK_LAUNCH("la_transpose16");
   return 0;
 }

@@ -12,7 +12,9 @@ that arrives from the decoder graph is multiplied by a power of two that puts it
 fp32 intermediate of the encoder backward carries that factor, and the parameter gradients are un-scaled when they are folded into
 the flat gradient buffer (non-finite results: the step is repeated with a smaller factor).
   data gradients   dX = dY . W     la_gemm on W^T re-packed per step (16-bit single plane)
-  weight gradients dW += dY^T . X  la_gemm_tn (exact-fp32 MFMA on fp32 copies of dY and X)
+  weight gradients dW += dY^T . X  la_gemm with LaGemmEpilogue.ksplit on la_transpose16 copies (16-bit MFMA, the token range cut into
+                                   independent chunks that add into dW with fp32 atomics); shapes it does not take (output widths
+                                   that are not multiples of 256: the reduced test encoders) go to la_gemm_tn (exact-fp32 MFMA)
   attention        la_attn_fwd_lse / la_attn_bwd (flash form, recomputed probabilities, csrc/attn_bwd.hip)
   LayerNorm, GELU  la_layernorm_bwd, la_gelu_bwd16
 Scope: plain (HF) attention with 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5).  The SAM ViTDet stack (windows, decomposed
@@ -62,6 +64,8 @@ class HfEncoderGraph:
             off += m
         self.ctx = None
         self.last_scale = 1.0
+        self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
+        self._tbufs: Dict[tuple, Tensor] = {}
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
     def _qkv_plain(self, eng, x16: Tensor, key: str, qkv: Tensor, ea: int) -> None:
@@ -134,10 +138,42 @@ class HfEncoderGraph:
         L.nchw_to_nhwc(wt.detach().contiguous(), 1, n, k, out16=out, dt=L._DT[dt])
         return out
 
-    def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x32: Tensor, wname: str, bname: str, dx32=None, dx16=None) -> None:
-        """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K])."""
+    def _wgrad(self, dy16, dy32, x, dw: Tensor) -> None:
+        """dw[N, K] += dy[R, N]^T x[R, K].  dy16 / dy32: the same gradient in 16 bit and fp32 (either may be None; column slices
+        allowed); x: fp32 or 16-bit."""
+        dy = dy16 if dy16 is not None else dy32
+        r, n = dy.shape
+        k = x.shape[1]
+        if self.fast_wgrad and k % 256 == 0 and r >= 128:
+            rp = _ceil(r, 64)
+            dt = self.ctx["dt"]
+            dyt = self._tbuf("dyt", n, rp, dt)
+            xt = self._tbuf("xt", k, rp, dt)
+            L.transpose16(dy, dyt)
+            L.transpose16(x, xt)
+            L.gemm(dyt, xt, out32=dw.view(n, k), ksplit=1)
+        else:
+            x32 = x
+            if x.dtype != torch.float32:
+                x32 = self._tbuf("x32", r, k, torch.float32)
+                L.cast(x.contiguous(), x32)
+            if dy32 is None:
+                dy32 = self._tbuf("dy32", r, n, torch.float32)
+                L.cast(dy16.contiguous(), dy32)
+            L.gemm_tn(dy32, x32, dw.view(n, k))
+
+    def _tbuf(self, name: str, a: int, b: int, dtype) -> Tensor:
+        key = (name, a, b, dtype)
+        t = self._tbufs.get(key)
+        if t is None:
+            t = torch.empty(a, b, device=self.scratch.device, dtype=dtype)
+            self._tbufs[key] = t
+        return t
+
+    def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x, wname: str, bname: str, dx32=None, dx16=None) -> None:
+        """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K]); x: the layer's input, any dtype."""
         wt = self.w[wname]
-        L.gemm_tn(dy32, x32, self.sviews[wname])
+        self._wgrad(dy16, dy32, x, self.sviews[wname])
         L.colsum_acc(dy32, self.sviews[bname])
         L.gemm(dy16, self._wt16(wt, dy16.dtype), out32=dx32, out16=dx16)
 
@@ -185,7 +221,6 @@ class HfEncoderGraph:
         dh = torch.empty(rows, spec.mlp, device=dev)
         dpre32 = torch.empty(rows, spec.mlp, device=dev)
         dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
-        x32w = torch.empty(rows, spec.mlp, device=dev)            # fp32 copy of a saved 16-bit activation (weight-gradient operand)
         dxn = torch.empty(rows, e, device=dev)
         dx = torch.empty(rows, e, device=dev)
         dao = torch.empty(rows, e, device=dev, dtype=dt)
@@ -199,17 +234,14 @@ class HfEncoderGraph:
             a = c["layers"][i]
             # ---- MLP: res = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------------------------------------
             L.cast(dres, d16)
-            L.cast(a["post"], x32w)
-            self._linear_bwd(dres, d16, x32w, lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
+            self._linear_bwd(dres, d16, a["post"], lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
             L.gelu_bwd16(a["pre"], dh, dpre32, dpre16)
             self._linear_bwd(dpre32, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias", dx32=dxn)
             L.layernorm_bwd(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, False, dx,
                             sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
             L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])
             # ---- attention: x_mid = x_in + proj(attn(LN1(x_in))) -------------------------------------------------------------
-            ao32 = x32w.view(-1)[: rows * e].view(rows, e)
-            L.cast(a["ao"], ao32)
-            self._linear_bwd(dres, d16, ao32, lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
+            self._linear_bwd(dres, d16, a["ao"], lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
             L.head_transpose(a["qkv"], e, bn, heads, t, tpad, kt)
             L.head_transpose(a["qkv"], 0, bn, heads, t, tpad, qt)
             L.head_transpose(dao, 0, bn, heads, t, tpad, dot)
@@ -217,9 +249,8 @@ class HfEncoderGraph:
             L.cast(dqkv16, dqkv32)
             att = lp + ".attention.attention."
             for j, nm in enumerate(("query", "key", "value")):
-                dy = dqkv32[:, j * e:(j + 1) * e]
-                L.gemm_tn(dy, a["xn"], sv[att + nm + ".weight"])
-                L.colsum_acc(dy, sv[att + nm + ".bias"])
+                self._wgrad(dqkv16[:, j * e:(j + 1) * e], dqkv32[:, j * e:(j + 1) * e], a["xn"], sv[att + nm + ".weight"])
+                L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
             wqkv = torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]])       # [3E, E]
             L.gemm(dqkv16, self._wt16(wqkv, dt), out32=dxn)
             L.layernorm_bwd(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, False, dx,
@@ -232,7 +263,7 @@ class HfEncoderGraph:
         k = 3 * spec.patch * spec.patch
         a32 = torch.empty(bn * hw, k, device=dev)
         L.im2col_patch(c["images"], spec.patch, a32)
-        L.gemm_tn(dpatch, a32, sv[emb + "patch_embeddings.projection.weight"].view(e, k))
+        self._wgrad(None, dpatch, a32, sv[emb + "patch_embeddings.projection.weight"])
         L.colsum_acc(dpatch, sv[emb + "patch_embeddings.projection.bias"])
         dpos_rows = d0.sum(dim=0)                                   # [t, E]: a few hundred rows of bookkeeping, not a kernel
         sv[emb + "cls_token"].view(-1).add_(dpos_rows[0])

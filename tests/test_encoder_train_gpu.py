@@ -192,7 +192,7 @@ def test_steps_with_trainable_encoder_match_the_reference_fixture():
     floor_g = 1e-2 * float(gold["grad_norm"].max())
     rel_n = (gn - gold["grad_norm"]).abs() / gold["grad_norm"].clamp_min(floor_g)
     print("trainable-encoder fixture: worst gradient-norm error", float(rel_n.max()), keys[int(rel_n.argmax())])
-    assert float(rel_n.max()) <= 5e-2
+    assert float(rel_n.max()) <= 1e-2
     params = dict(lam.named_parameters())
     gmax = max(float(v.abs().max()) for k, v in gold.items() if k.startswith("grad."))
     worst = 0.0
@@ -200,7 +200,7 @@ def test_steps_with_trainable_encoder_match_the_reference_fixture():
         if k.startswith("grad."):
             err = float((g0[k[5:]].cpu() - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gmax)
             worst = max(worst, err)
-            assert err <= 6e-2, (k, err)
+            assert err <= 1e-2, (k, err)                     # measured 2.1e-3 (16-bit operands forward and backward)
         if k.startswith("final."):
             name = k[6:]
             mine, ref0 = params[name].detach().cpu(), start[name].cpu()
@@ -208,3 +208,25 @@ def test_steps_with_trainable_encoder_match_the_reference_fixture():
             step_ref, step_mine = (v - ref0)[sig], (mine - ref0)[sig]
             assert float((step_mine - step_ref).abs().max()) <= 5e-2 * float(step_ref.abs().max()), name
     print("trainable-encoder fixture: worst entry-wise gradient error", worst)
+
+
+@pytest.mark.parametrize("shape", [(46852, 768, 768), (23426, 3072, 768), (5000, 128, 256), (900, 768, 3072)])
+def test_split_k_weight_gradient_gemm_matches_torch(shape):
+    """la_gemm with LaGemmEpilogue.ksplit on la_transpose16 operands: dW += dY^T X accumulated with fp32 atomics over K chunks."""
+    r, n, k = shape
+    g = torch.Generator().manual_seed(r + n)
+    dy = torch.randn(r, n, generator=g).cuda()
+    x = torch.randn(r, k, generator=g).half().cuda()
+    rp = (r + 63) // 64 * 64
+    dyt = torch.empty(n, rp, dtype=torch.float16, device="cuda")
+    xt = torch.empty(k, rp, dtype=torch.float16, device="cuda")
+    L.transpose16(dy, dyt)
+    L.transpose16(x, xt)
+    assert torch.equal(dyt[:, :r], dy.half().t()) and torch.equal(xt[:, :r], x.t())
+    assert rp == r or (float(dyt[:, r:].abs().max()) == 0.0 and float(xt[:, r:].abs().max()) == 0.0)
+    dw0 = torch.randn(n, k, generator=g).cuda()
+    dw = dw0.clone()
+    L.gemm(dyt, xt, out32=dw, ksplit=1)
+    torch.cuda.synchronize()
+    ref = dw0.double() + dy.half().double().t() @ x.double()
+    assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 1e-5      # fp32 accumulation of exactly representable products
