@@ -339,6 +339,14 @@ int la_axpy(const float* x, float* y, long n, float a, void* stream);
 /* dpre = dh * gelu'(pre) (erf form, transformers ViTIntermediate): pre 16-bit, dh fp32, outputs fp32 and / or 16-bit (either may be NULL). */
 int la_gelu_bwd16(const void* pre16, const float* dh, float* d32, void* d16, long n, int dt, void* stream);
 
+/* ---- fp8 QK^T attention (BASELINE configs[4]; opt-in: Lam(attn_fp8=True), never the parity configuration) ----
+ * la_qk_fp8: the q | k columns of qkv16 [rows, 3E] as OCP e4m3 bytes [rows, 2E].
+ * la_attn_fwd_fp8: la_attn_fwd in LA_ATTN_PLAIN mode (head_dim 64) with S = Q K^T on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block
+ * scales) from those bytes; softmax and P V as in the 16-bit kernel (vt = V^T 16-bit, out 16-bit). */
+int la_qk_fp8(const void* qkv, long rows, int E, void* qk8, int dt, void* stream);
+int la_attn_fwd_fp8(const void* qk8, const void* vt, void* out16, int B, int heads, int T, int Tpad, int E, float scale, int dt,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8",
 ]
 
 
@@ -467,3 +467,15 @@ def transpose16(src, dst) -> None:
         raise ValueError("transpose16: src needs unit column stride, dst contiguous [C, Rp]")
     _check(lib().la_transpose16(_ptr(src), C.c_int(dt_of(src)), C.c_int(src.stride(0)), C.c_int(r), C.c_int(c), _ptr(dst), C.c_int(dt_of(dst)),
                                 C.c_int(dst.shape[1]), _stream()), "la_transpose16")
+
+
+# ---- fp8 QK^T attention (opt-in) --------------------------------------------------------------------------
+def qk_fp8(qkv, e: int, qk8) -> None:
+    _dev(qkv)
+    _check(lib().la_qk_fp8(_ptr(qkv), C.c_long(qkv.shape[0]), C.c_int(e), _ptr(qk8), C.c_int(dt_of(qkv)), _stream()), "la_qk_fp8")
+
+
+def attn_fwd_fp8(qk8, vt, out16, b: int, heads: int, t: int, tpad: int, e: int, scale: float) -> None:
+    _dev(qk8)
+    _check(lib().la_attn_fwd_fp8(_ptr(qk8), _ptr(vt), _ptr(out16), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad), C.c_int(e),
+                                 C.c_float(scale), C.c_int(dt_of(out16)), _stream()), "la_attn_fwd_fp8")

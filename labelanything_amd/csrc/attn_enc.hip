@@ -702,6 +702,171 @@ static void launch_attn(const AttnArgs& a, size_t extra, hipStream_t st) {
   else launch_attn_nh<T, MODE, 1>(a, 2 * (size_t)KV_STAGE + extra, st);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp8 QK^T variant of the plain attention (BASELINE configs[4]: "fp8 MFMA attention"; opt-in, la_attn_fwd_fp8).
+// Scores S^T = K Q^T on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 operands, unit block scales): ONE 64-deep instruction per 32 x 32
+// score tile at twice the 16-bit MFMA rate instead of four 16-deep ones, K tiles of 4 KiB instead of 8.  Softmax and O^T = V^T P^T
+// are exactly the 16-bit kernel's (P in 16 bit, fp32 accumulate).  Q and K arrive as e4m3 bytes [B*T, 2E] (la_qk_fp8).  Both
+// operands are loaded the same way - lane (row, half) holds bytes [32 half, 32 half + 32) of its row - so whatever order the
+// instruction gives the 64 k-slots, q and k elements of equal head dimension meet.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int swz64b_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(AttnArgs a, const unsigned char* __restrict__ qk8) {
+  constexpr int K8 = 64 * 64, VT = 64 * 64 * 2, STG = K8 + VT;      // K tile (fp8) 4 KiB + V^T tile (16 bit) 8 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int BH = a.B * a.heads;
+  const int bh = blockIdx.x % BH, qblk = blockIdx.x / BH;
+  const int h = bh % a.heads, b = bh / a.heads;
+  const int T_ = a.T, E2 = 2 * a.E;
+  const T* vt = reinterpret_cast<const T*>(a.vt);
+  const int q0 = qblk * 128 + wave * 32, q = q0 + fr, qc = min(q, T_ - 1);
+  const float c2 = a.scale * 1.44269504088896340736f;
+
+  i32x8 qf;
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(qk8 + ((size_t)b * T_ + qc) * E2 + h * 64 + fh * 32);
+    const uint4 lo = p[0], hi = p[1];
+    qf = i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  const unsigned char* kbase = qk8 + (size_t)b * T_ * E2 + a.E + h * 64;
+  auto dma = [&](int j, int stage) {
+    const unsigned sk = lds0 + stage * STG, sv = sk + K8;
+    {   // K tile: 64 rows x 64 bytes = 4 pieces of 16 rows, one per wave
+      const int row = wave * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      dma16(kbase + (size_t)min(j * 64 + row, T_ - 1) * E2 + chunk * 16, sk + wave * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // V^T tile as in attn_fwd_kernel
+      const int row = (i * 4 + wave) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      dma16(vt + ((size_t)bh * 64 + row) * a.Tpad + chunk * 8 + j * 64, sv + (i * 4 + wave) * 1024);
+    }
+  };
+  f32x16 oacc[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const int ntiles = (T_ + 63) >> 6;
+  dma(0, 0);
+  dma_wait<0>();
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+    const char* sk = smem + (j & 1) * STG;
+    const char* sv = sk + K8;
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(sk + swz64b_off(t * 32 + fr, fh * 2));
+      const uint4 hi = *reinterpret_cast<const uint4*>(sk + swz64b_off(t * 32 + fr, fh * 2 + 1));
+      const i32x8 kf{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    if (j * 64 + 64 > T_) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          if (key >= T_) s[t][r] = NEG_BIG;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = -m_run * c2;
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, mc));
+        s[t][r] = p;
+        psum += p;
+      }
+    l_run += psum;
+    uint4 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int t = ks >> 1, g0 = (ks & 1) * 8;
+      const uint32_t x0 = pack2<T>(s[t][g0 + 0], s[t][g0 + 1]);
+      const uint32_t x1 = pack2<T>(s[t][g0 + 2], s[t][g0 + 3]);
+      const uint32_t y0 = pack2<T>(s[t][g0 + 4], s[t][g0 + 5]);
+      const uint32_t y1 = pack2<T>(s[t][g0 + 6], s[t][g0 + 7]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      pf[ks] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(d * 32 + fr, ks * 2 + fh));
+        oacc[d] = Half16<T>::mfma32(vf, pf[ks], oacc[d]);
+      }
+    dma_wait<0>();
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  if (q < T_) {
+    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 v;
+        v.x = pack2<T>(oacc[d][g4 * 4 + 0] * inv_l, oacc[d][g4 * 4 + 1] * inv_l);
+        v.y = pack2<T>(oacc[d][g4 * 4 + 2] * inv_l, oacc[d][g4 * 4 + 3] * inv_l);
+        *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
+      }
+  }
+}
+
+// q | k columns of qkv16 [rows, 3E] -> e4m3 bytes [rows, 2E] (v_cvt_pk_fp8_f32: OCP e4m3 with saturation on gfx950)
+template <typename T>
+__global__ __launch_bounds__(256) void qk_fp8_kernel(const T* __restrict__ qkv, long rows, int E, unsigned char* __restrict__ out) {
+  const int per_row = (2 * E) / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * per_row; i += (long)gridDim.x * 256) {
+    const long r = i / per_row;
+    const int c = (int)(i % per_row) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>(qkv + r * 3 * E + c);
+    const T* e = reinterpret_cast<const T*>(&v);
+    unsigned w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)e[0], (float)e[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)e[2], (float)e[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)e[4], (float)e[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)e[6], (float)e[7], w1, true);
+    *reinterpret_cast<uint2*>(out + r * 2 * E + c) = make_uint2(w0, w1);
+  }
+}
+
 }  // namespace la
 
 extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, const void* tabh, const void* tabw, float* relh,
@@ -795,5 +960,32 @@ extern "C" int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, flo
   if (dt == LA_F16) la::launch_attn<la::f16_t, 0>(a, 0, st);
   else la::launch_attn<la::bf16_t, 0>(a, 0, st);
   LA_CHECK_LAUNCH("la_attn_fwd_lse");
+  return 0;
+}
+
+extern "C" int la_qk_fp8(const void* qkv, long rows, int E, void* qk8, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && qk8 && rows > 0 && E > 0 && (E % 8) == 0 && (dt == LA_F16 || dt == LA_BF16), "la_qk_fp8: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long n = rows * (2 * E / 8);
+  const dim3 grid((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256)), blk(256);
+  if (dt == LA_F16) hipLaunchKernelGGL(la::qk_fp8_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)qkv, rows, E, (unsigned char*)qk8);
+  else hipLaunchKernelGGL(la::qk_fp8_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)qkv, rows, E, (unsigned char*)qk8);
+  LA_CHECK_LAUNCH("la_qk_fp8");
+  return 0;
+}
+
+extern "C" int la_attn_fwd_fp8(const void* qk8, const void* vt, void* out16, int B, int heads, int T, int Tpad, int E, float scale, int dt,
+                               void* stream) {
+  LA_CHECK_ARG(qk8 && vt && out16, "la_attn_fwd_fp8: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_fwd_fp8: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_fp8: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_fp8: bad dtype %d", dt);
+  la::AttnArgs a{nullptr, vt, out16, nullptr, nullptr, nullptr, nullptr, B, heads, T, Tpad, 0, E, scale, nullptr};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nblk = (T + 127) / 128 * B * heads;
+  constexpr int LDS = 2 * (64 * 64 + 64 * 64 * 2);
+  if (dt == LA_F16) hipLaunchKernelGGL(la::attn_fwd_fp8_kernel<la::f16_t>, dim3(nblk), dim3(256), LDS, st, a, (const unsigned char*)qk8);
+  else hipLaunchKernelGGL(la::attn_fwd_fp8_kernel<la::bf16_t>, dim3(nblk), dim3(256), LDS, st, a, (const unsigned char*)qk8);
+  LA_CHECK_LAUNCH("la_attn_fwd_fp8");
   return 0;
 }

@@ -98,6 +98,9 @@ class LamEngine:
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
         self.precise = frozenset(resolve_precise(cfg, precise, dtype))
+        # opt-in (Lam.attn_fp8): QK^T of the plain (HF) attention on the fp8 MFMA - BASELINE configs[4].  3 mantissa bits on q and k cost
+        # 1e-2-class logit error (profiles/r03_attn_fp8.log): never the parity configuration
+        self.attn_fp8 = False
         self.patch_split = False                 # set by _patch_weight
         # decoder_dtype "f16x2": the IMAGE-side GEMM operands of the prompt encoder / mask decoder (the (P, hw, D) stream) are pairs
         # of fp16 planes [hi | lo] and their weights [W_hi | W_hi | W_lo] (LA_F16X2, la_hip.h): 3 fast-MFMA products instead of the
@@ -599,7 +602,12 @@ class LamEngine:
             lp = f"{pre}.encoder.layer.{i}"
             self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
             self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
-            L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
+            if self.attn_fp8 and hdp == 64:
+                qk8 = self.arena.get("hf.qk8", (rows, 2 * ea), torch.uint8, False)
+                L.qk_fp8(qkv, ea, qk8)
+                L.attn_fwd_fp8(qk8, vt, ao, bn, heads, t, tpad, ea, scale)
+            else:
+                L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
             self.gemm_w(ao, lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
             self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
             self.gemm_w(x16, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)

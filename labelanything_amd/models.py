@@ -104,6 +104,7 @@ class Lam(nn.Module):
         self._plist = None
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = False          # replay the device-side launch sequence from a HIP graph (per input plan)
+        self.attn_fp8 = False            # opt-in: fp8 (e4m3) QK^T in the HF encoder's attention (BASELINE configs[4]); outside the 1e-3 tolerance
         self.selected_rows: Optional[torch.Tensor] = None   # fix the RandomMatrixEncoder rows (parity / reproducibility)
 
     # -- engine management --------------------------------------------------------------------------
@@ -125,6 +126,7 @@ class Lam(nn.Module):
             self._graphs = {}
             self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype, self.decoder_dtype, self.precise)
             self._engine_key = key
+        self._engine.attn_fp8 = bool(self.attn_fp8)
         return self._engine
 
     def invalidate(self) -> None:

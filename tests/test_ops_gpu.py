@@ -686,3 +686,42 @@ def test_fused_twoway_image_side_kernels(L, g, hw, nt):
     assert rel_err(img, ref_i2t) < 2e-5
     with pytest.raises(RuntimeError, match="nt="):
         L.twoway_i2t(img, _planes(wq), peq, rnd(g * 40, di), rnd(g * 40, di), _planes(wo), bo, gamma, beta, 1e-5, g, hw, 40, heads)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 197), (1, 12, 901)])
+def test_fp8_qk_attention_matches_torch_on_e4m3_rounded_operands(L, shape):
+    """la_qk_fp8 + la_attn_fwd_fp8 (opt-in, BASELINE configs[4]): S = Q K^T on the scaled fp8 MFMA.  Against torch with q and k
+    rounded to e4m3 the kernel is at 16-bit-P accuracy (this pins the operand layout of v_mfma_scale_f32_32x32x64_f8f6f4); against
+    the UNROUNDED operands the output moves by a few percent - the price of 3 mantissa bits, reported, not asserted tight."""
+    import math
+    b, heads, t = shape
+    e = heads * 64
+    tpad = (t + 63) // 64 * 64
+    g = torch.Generator().manual_seed(t)
+    qkv = (torch.randn(b * t, 3 * e, generator=g) * 0.8).half().cuda()
+    scale = 1.0 / math.sqrt(64)
+    vt = torch.empty(b * heads, 64, tpad, dtype=torch.float16, device="cuda")
+    L.head_transpose(qkv, 2 * e, b, heads, t, tpad, vt)
+    qk8 = torch.empty(b * t, 2 * e, dtype=torch.uint8, device="cuda")
+    L.qk_fp8(qkv, e, qk8)
+    ref8 = qkv[:, :2 * e].float().to(torch.float8_e4m3fn)
+    assert torch.equal(qk8.view(torch.float8_e4m3fn).float(), ref8.float())
+    out = torch.empty(b * t, e, dtype=torch.float16, device="cuda")
+    L.attn_fwd_fp8(qk8, vt, out, b, heads, t, tpad, e, scale)
+    torch.cuda.synchronize()
+
+    def ref_attn(qk):
+        q = qk[:, :e].double().view(b, t, heads, 64).permute(0, 2, 1, 3)
+        k = qk[:, e:].double().view(b, t, heads, 64).permute(0, 2, 1, 3)
+        v = qkv[:, 2 * e:].double().cpu().view(b, t, heads, 64).permute(0, 2, 1, 3)
+        o = torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v
+        return o.permute(0, 2, 1, 3).reshape(b * t, e)
+
+    o8 = ref_attn(ref8.float().cpu())
+    o16 = ref_attn(qkv[:, :2 * e].float().cpu())
+    got = out.double().cpu()
+    err8 = float((got - o8).abs().max() / o8.abs().max())
+    err16 = float((got - o16).abs().max() / o16.abs().max())
+    print(f"fp8 QK^T attention {shape}: vs e4m3-rounded operands {err8:.2e}, vs the 16-bit operands {err16:.2e}")
+    assert err8 <= 3e-3
+    assert err16 <= 0.2
