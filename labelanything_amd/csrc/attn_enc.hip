@@ -360,8 +360,15 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   };
   if (MODE == 4) fill_relh_half(0);
   __syncthreads();
+  // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
+  const bool idle_wave = q0 >= T_;
   for (int j = 0; j < ntiles; ++j) {
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+    if (idle_wave) {
+      dma_wait<0>();
+      __syncthreads();
+      continue;
+    }
     const char* sk = smem + (j & 1) * KVS;
     const char* sv = sk + NH * SUB;
     if (MODE == 4 && j == 32) fill_relh_half(1);

@@ -1439,7 +1439,8 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = min(row0 + (half * 2 + ii) * 32 + 8 * g4 + rr4 + 4 * j, M - 1);
-            rv[ii][g4][j] = *reinterpret_cast<const float4*>(e.res + (size_t)row * e.ldr + col0 + rch * 4);
+            rv[ii][g4][j] = e.res ? *reinterpret_cast<const float4*>(e.res + (size_t)row * e.ldr + col0 + rch * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);            // (no residual: plain fp32 output, e.g. a data gradient)
           }
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
@@ -1920,7 +1921,7 @@ static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, i
                        (!e.vt || (size_t)((M + e.vt_T - 1) / e.vt_T + 4096) * e.vt_heads * e.vt_hd * e.vt_Tpad < (1ull << 32));
   if (al && scatter) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) return launch_t256p<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
-  if (al && plain && e.act == LA_ACT_NONE && e.res && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (e.ldr % 4) == 0)
+  if (al && plain && e.act == LA_ACT_NONE && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (!e.res || (e.ldr % 4) == 0))
     return launch_t256p<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);
   if (plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) launch_t256_epi<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   else if (plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) launch_t256_epi<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);

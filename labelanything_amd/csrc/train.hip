@@ -617,28 +617,45 @@ __global__ __launch_bounds__(256) void gelu_bwd16_kernel(const T* __restrict__ p
 // (la_gemm ksplit: dW[N, K] = dY^T X runs as A = dY^T [N, Rp], W = X^T [K, Rp]).  64 x 64 tiles through LDS.
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose16_kernel(const TS* __restrict__ src, int ld, int R, int Cn, TD* __restrict__ dst, int Rp) {
-  __shared__ TD tile[64][64 + 2];
+  // 64 x 64 tile as 32-bit words of two adjacent COLUMNS: tile[r][c / 2].  Output row c needs (r, c), (r + 1, c), ...: two words
+  // of rows r, r + 1 give the pairs of columns c and c + 1 with one v_perm each - half the LDS instructions of a 16-bit tile.
+  __shared__ unsigned tile[64][32 + 1];
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
   {
     const int r = tid >> 2, cb = (tid & 3) * 16;
+    const int rr = r0 + r;
+    TD v[16];
+    if (rr < R && c0 + cb + 15 < Cn && (ld % 8) == 0 && sizeof(TS) == 2) {
+      const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb);
+      const uint4 b2 = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb + 8);
+      *reinterpret_cast<uint4*>(&v[0]) = a;
+      *reinterpret_cast<uint4*>(&v[8]) = b2;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int rr = r0 + r, cc = c0 + cb + i;
-      tile[r][cb + i] = (rr < R && cc < Cn) ? (TD)(float)src[(size_t)rr * ld + cc] : (TD)0.f;
+      for (int i = 0; i < 16; ++i) {
+        const int cc = c0 + cb + i;
+        v[i] = (rr < R && cc < Cn) ? (TD)(float)src[(size_t)rr * ld + cc] : (TD)0.f;
+      }
     }
+    const unsigned* w = reinterpret_cast<const unsigned*>(v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[r][cb / 2 + i] = w[i];
   }
   __syncthreads();
   {
-    const int c = tid >> 2, rb = (tid & 3) * 16;
-    if (c0 + c < Cn) {
-      TD o[16];
+    // thread -> column pair cp (0..31) and 8 consecutive row pairs: writes 16 rows x 2 columns
+    const int cp = tid >> 3, rb = (tid & 7) * 8;
+    unsigned lo[4], hi[4];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = tile[rb + i][c];
-      TD* p = dst + (size_t)(c0 + c) * Rp + r0 + rb;
-      *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&o[0]);
-      *reinterpret_cast<uint4*>(p + 8) = *reinterpret_cast<const uint4*>(&o[8]);
+    for (int i = 0; i < 4; ++i) {
+      const unsigned a = tile[rb + 2 * i][cp], b2 = tile[rb + 2 * i + 1][cp];
+      lo[i] = __builtin_amdgcn_perm(b2, a, 0x05040100);     // (row, c) | (row + 1, c) << 16
+      hi[i] = __builtin_amdgcn_perm(b2, a, 0x07060302);     // (row, c + 1) | (row + 1, c + 1) << 16
     }
+    const int c = c0 + 2 * cp;
+    if (c < Cn) *reinterpret_cast<uint4*>(dst + (size_t)c * Rp + r0 + rb) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (c + 1 < Cn) *reinterpret_cast<uint4*>(dst + (size_t)(c + 1) * Rp + r0 + rb) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
   }
 }
 

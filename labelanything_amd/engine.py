@@ -76,6 +76,24 @@ PRECISE_DEFAULT = "auto"
 PRECISE_GROUPS = ("patch", "qkv", "v", "proj", "lin1", "lin2", "neck")
 
 
+_BICUBIC: Dict[tuple, Tensor] = {}
+
+
+def bicubic_matrix_t(gin: int, gout: int, device) -> Tensor:
+    """B^T [gin^2, gout^2] of the linear map ``F.interpolate(x, (gout, gout), mode='bicubic', align_corners=False)`` on a gin x gin
+    grid (transformers ViTEmbeddings.interpolate_pos_encoding under build_encoder.py:83-100), built once per geometry by pushing
+    the identity through torch's own CPU kernel - the resample of the position table then is one small exact-fp32 product (and its
+    backward the transposed one) instead of torch's device kernels (30 ms per step in the trainable-encoder step, most of it the
+    atomics of upsample_bicubic2d_backward)."""
+    key = (gin, gout, str(device))
+    m = _BICUBIC.get(key)
+    if m is None:
+        eye = torch.eye(gin * gin).view(gin * gin, 1, gin, gin)
+        m = F.interpolate(eye, size=(gout, gout), mode="bicubic", align_corners=False).reshape(gin * gin, gout * gout).contiguous().to(device)
+        _BICUBIC[key] = m
+    return m
+
+
 def resolve_precise(cfg: LamConfig, precise, dtype: torch.dtype = torch.float16) -> tuple:
     """'auto' -> the measured default for this encoder width and operand type; None / () -> no split precision; else the given
     groups.  bf16 operands (8 mantissa bits) always take the full set: its activations alone cost more than fp16's weights."""
@@ -562,9 +580,10 @@ class LamEngine:
             pos = self.w32["image_encoder.embeddings.position_embeddings"]
             if g != spec.pos_grid:  # bicubic resample of the patch positions (constant per resolution)
                 e = pos.shape[-1]
-                grid = pos[:, 1:].reshape(1, spec.pos_grid, spec.pos_grid, e).permute(0, 3, 1, 2)
-                grid = F.interpolate(grid, size=(g, g), mode="bicubic", align_corners=False)
-                pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, g * g, e)], dim=1)
+                bt = bicubic_matrix_t(spec.pos_grid, g, pos.device)                        # [gin^2, gout^2]
+                grid = torch.zeros(g * g, e, device=pos.device)
+                L.gemm_tn(bt, pos[0, 1:].contiguous(), grid)                               # grid = B . pos  (exact-fp32 MFMA)
+                pos = torch.cat([pos[:, :1], grid.unsqueeze(0)], dim=1)
             t = pos[0].contiguous()
             cls_row = (self.w32["image_encoder.embeddings.cls_token"][0, 0] + t[0]).contiguous()
             self._hfpos_cache[g] = t

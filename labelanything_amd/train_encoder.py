@@ -26,7 +26,6 @@ import math
 from typing import Dict, List
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -66,6 +65,7 @@ class HfEncoderGraph:
         self.last_scale = 1.0
         self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
         self._tbufs: Dict[tuple, Tensor] = {}
+        self._b_ready: Dict[tuple, bool] = {}
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
     def _qkv_plain(self, eng, x16: Tensor, key: str, qkv: Tensor, ea: int) -> None:
@@ -270,14 +270,16 @@ class HfEncoderGraph:
         pos = w[emb + "position_embeddings"]
         if c["g"] == spec.pos_grid:
             sv[emb + "position_embeddings"].view(t, e).add_(dpos_rows)
-        else:                                                       # through the bicubic resample of the patch positions
-            with torch.enable_grad():
-                leaf = pos.detach().clone().requires_grad_(True)
-                grid = leaf[:, 1:].reshape(1, spec.pos_grid, spec.pos_grid, e).permute(0, 3, 1, 2)
-                grid = F.interpolate(grid, size=(c["g"], c["g"]), mode="bicubic", align_corners=False)
-                full = torch.cat([leaf[:, :1], grid.permute(0, 2, 3, 1).reshape(1, hw, e)], dim=1)
-                (gpos,) = torch.autograd.grad(full, leaf, grad_outputs=dpos_rows.unsqueeze(0))
-            sv[emb + "position_embeddings"].add_(gpos)
+        else:                                                       # through the bicubic resample of the patch positions: dpos = B^T d
+            from .engine import bicubic_matrix_t
+            bt = bicubic_matrix_t(spec.pos_grid, c["g"], dev)       # [gin^2, gout^2]
+            b = self._tbuf("bicubic_b", c["g"] * c["g"], spec.pos_grid * spec.pos_grid, torch.float32)
+            if not self._b_ready.get((spec.pos_grid, c["g"])):
+                b.copy_(bt.t())
+                self._b_ready[(spec.pos_grid, c["g"])] = True
+            gp = sv[emb + "position_embeddings"].view(-1, e)        # [1 + gin^2, E]
+            gp[0].add_(dpos_rows[0])
+            L.gemm_tn(b, dpos_rows[1:].contiguous(), gp[1:])
 
 
 class _EncoderFn(torch.autograd.Function):
