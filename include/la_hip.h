@@ -347,6 +347,27 @@ int la_qk_fp8(const void* qkv, long rows, int E, void* qk8, int dt, void* stream
 int la_attn_fwd_fp8(const void* qk8, const void* vt, void* out16, int B, int heads, int T, int Tpad, int E, float scale, int dt,
                     void* stream);
 
+/* ---- token-mean correction of single-plane weights ("mean planes") ----
+ * A weight rounded to one 16-bit plane errs by a_i . W_lo^T on token i; the part of that which survives attention and pooling is the
+ * part that is the same for every token of an image: mean_i(a_i) . W_lo^T.  It is added back as a per-image vector: la_colmean16 takes
+ * the token means of the 16-bit A operand, a few-row la_gemm forms the vectors, la_layernorm_g / la_add_rowvec fold them into the
+ * residual stream.  (image_encoder.py:134-255, build_encoder.py:83-100: same products, ~22-bit weights on the part that matters.) */
+
+/* out[g][c] = mean over the rows_per_group rows of group g of src[row][c] (16-bit [groups * rows_per_group, ld]; out fp32 [groups, D]).
+ * Deterministic: fixed 128-row chunks into scratch (fp32 [groups * ceil(rows_per_group / 128) * D]), folded in order - a group's mean
+ * does not depend on the other groups of the launch.  wpart > 0: src is window-partitioned (LA_MAP_WINDOW_PART order of an H x W grid,
+ * ws = wpart): the rows of group g are gathered in image order, pad slots are skipped. */
+int la_colmean16(const void* src, int ld, int groups, int rows_per_group, int D, float* out, float* scratch, int wpart, int H, int W, int dt,
+                 void* stream);
+
+/* la_layernorm of x[r] + xg[r / rows_per_group] (xg fp32 [rows / rows_per_group, E]): the pending per-image corrections enter every
+ * consumer of the residual stream without being written back. */
+int la_layernorm_g(const float* x, const float* xg, int rows_per_group, int ldx, int rows, int E, const float* gamma, const float* beta,
+                   float eps, float* out32, void* out16, int window, int H, int W, int dt, void* stream);
+
+/* x[r] += v[r / rows_per_group] in place (fp32 [rows, D]). */
+int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

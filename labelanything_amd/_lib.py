@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec",
 ]
 
 
@@ -479,3 +479,28 @@ def attn_fwd_fp8(qk8, vt, out16, b: int, heads: int, t: int, tpad: int, e: int, 
     _dev(qk8)
     _check(lib().la_attn_fwd_fp8(_ptr(qk8), _ptr(vt), _ptr(out16), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad), C.c_int(e),
                                  C.c_float(scale), C.c_int(dt_of(out16)), _stream()), "la_attn_fwd_fp8")
+
+
+# ---- token-mean correction of single-plane weights ---------------------------------------------------------
+def colmean16(src, groups: int, rows_per_group: int, out, scratch, wpart: int = 0, h: int = 0, w: int = 0) -> None:
+    """out[g] = mean of the rows of group g (fp32 [groups, D]); scratch fp32 >= groups * ceil(rows_per_group / 128) * D elements;
+    wpart: src window-partitioned, rows gathered in image order."""
+    _dev(src)
+    need = groups * ((rows_per_group + 127) // 128) * src.shape[1]
+    if scratch.numel() < need or scratch.dtype != torch.float32:
+        raise ValueError(f"colmean16 scratch needs {need} fp32 elements")
+    _check(lib().la_colmean16(_ptr(src), C.c_int(src.stride(0)), C.c_int(groups), C.c_int(rows_per_group), C.c_int(src.shape[1]), _ptr(out),
+                              _ptr(scratch), C.c_int(wpart), C.c_int(h), C.c_int(w), C.c_int(dt_of(src)), _stream()), "la_colmean16")
+
+
+def layernorm_g(x, xg, rows_per_group: int, gamma, beta, eps: float, *, out32=None, out16=None, window=0, H=0, W=0, dt=LA_F16) -> None:
+    _dev(x)
+    rows, e = x.shape
+    _check(lib().la_layernorm_g(_ptr(x), _ptr(xg), C.c_int(rows_per_group), C.c_int(x.stride(0)), C.c_int(rows), C.c_int(e), _ptr(gamma),
+                                _ptr(beta), C.c_float(eps), _ptr(out32), _ptr(out16), C.c_int(window), C.c_int(H), C.c_int(W), C.c_int(dt),
+                                _stream()), "la_layernorm_g")
+
+
+def add_rowvec(x, v, rows_per_group: int) -> None:
+    _f32c(x, v)
+    _check(lib().la_add_rowvec(_ptr(x), _ptr(v), C.c_long(x.shape[0]), C.c_int(rows_per_group), C.c_int(x.shape[1]), _stream()), "la_add_rowvec")

@@ -24,6 +24,8 @@ struct LnArgs {
   int pe_mod;
   int window, H, W;
   int split;          // LA_F16X2: the 16-bit outputs are [hi | lo] plane pairs (row stride 2 E)
+  int x2_group;       // > 0: x2 is [rows / x2_group, E] and row r adds x2[r / x2_group] (a per-image vector: the pending token-mean
+                      // corrections of single-plane weights, LamEngine mean planes)
 };
 
 template <typename T>
@@ -40,7 +42,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   for (int row = blockIdx.x * RPB + rl; row < a.rows; row += gridDim.x * RPB) {
     float4 v[NVT];
     const float4* xp = reinterpret_cast<const float4*>(a.x + (size_t)row * a.ldx);
-    const float4* yp = a.x2 ? reinterpret_cast<const float4*>(a.x2 + (size_t)row * a.ldx) : nullptr;
+    const float4* yp = a.x2 ? reinterpret_cast<const float4*>(a.x2 + (a.x2_group > 0 ? (size_t)(row / a.x2_group) * a.E : (size_t)row * a.ldx))
+                            : nullptr;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NVT; ++i) {
@@ -147,21 +150,129 @@ static void launch_ln(const LnArgs& a, hipStream_t st) {
 
 }  // namespace la
 
-extern "C" int la_layernorm(const float* x, const float* x2, int ldx, int rows, int E, const float* gamma, const float* beta,
-                            float eps, int gelu, float* out32, void* out16, void* out16_pe, const float* pe, int pe_mod,
-                            int window, int H, int W, int dt, void* stream) {
-  LA_CHECK_ARG(x && gamma && beta, "la_layernorm: null pointer");
-  LA_CHECK_ARG(rows > 0 && E > 0 && (E % 4) == 0 && E <= 4 * 64 * la::LN_MAXV && (ldx % 4) == 0,
-               "la_layernorm: bad shape rows=%d E=%d ldx=%d", rows, E, ldx);
-  LA_CHECK_ARG(out32 || out16 || out16_pe, "la_layernorm: no output");
-  LA_CHECK_ARG(!out16_pe || pe, "la_layernorm: out16_pe needs pe");
-  LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "la_layernorm: bad window geometry");
-  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32 || dt == LA_F16X2, "la_layernorm: bad dtype %d", dt);
-  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt == LA_F16X2 ? 1 : 0};
+static int ln_impl(const char* name, const float* x, const float* x2, int x2_group, int ldx, int rows, int E, const float* gamma,
+                   const float* beta, float eps, int gelu, float* out32, void* out16, void* out16_pe, const float* pe, int pe_mod, int window,
+                   int H, int W, int dt, void* stream) {
+  LA_CHECK_ARG(x && gamma && beta, "%s: null pointer", name);
+  LA_CHECK_ARG(rows > 0 && E > 0 && (E % 4) == 0 && E <= 4 * 64 * la::LN_MAXV && (ldx % 4) == 0, "%s: bad shape rows=%d E=%d ldx=%d", name, rows, E,
+               ldx);
+  LA_CHECK_ARG(out32 || out16 || out16_pe, "%s: no output", name);
+  LA_CHECK_ARG(!out16_pe || pe, "%s: out16_pe needs pe", name);
+  LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "%s: bad window geometry", name);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32 || dt == LA_F16X2, "%s: bad dtype %d", name, dt);
+  LA_CHECK_ARG(x2_group >= 0 && (x2_group == 0 || x2), "%s: x2_group needs x2", name);
+  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt == LA_F16X2 ? 1 : 0, x2_group};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dt == LA_F16 || dt == LA_F16X2) la::launch_ln<la::f16_t>(a, st);
   else if (dt == LA_BF16) la::launch_ln<la::bf16_t>(a, st);
   else la::launch_ln<float>(a, st);
-  LA_CHECK_LAUNCH("la_layernorm");
+  LA_CHECK_LAUNCH(name);
+  return 0;
+}
+
+extern "C" int la_layernorm(const float* x, const float* x2, int ldx, int rows, int E, const float* gamma, const float* beta,
+                            float eps, int gelu, float* out32, void* out16, void* out16_pe, const float* pe, int pe_mod,
+                            int window, int H, int W, int dt, void* stream) {
+  return ln_impl("la_layernorm", x, x2, 0, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt, stream);
+}
+
+extern "C" int la_layernorm_g(const float* x, const float* xg, int rows_per_group, int ldx, int rows, int E, const float* gamma,
+                              const float* beta, float eps, float* out32, void* out16, int window, int H, int W, int dt, void* stream) {
+  return ln_impl("la_layernorm_g", x, xg, rows_per_group, ldx, rows, E, gamma, beta, eps, 0, out32, out16, nullptr, nullptr, 0, window, H, W, dt,
+                 stream);
+}
+
+// ---- token means per image of a 16-bit operand, and the in-place add of a per-image vector (LamEngine mean planes) -----------------
+namespace la {
+// part[g][chunk][c] = sum over rows [chunk * CM_CHUNK, +CM_CHUNK) of group g of src[row][c]; colmean16_fold_kernel adds the chunks of a
+// group in index order and scales by 1 / rpg.  Chunk size and order are fixed, so a group's mean does not depend on how many groups
+// the launch has or on timing: the encoder stays bit-reproducible and episode-shard invariant (an atomic version moved the last bit
+// of the means from run to run, which the 16-bit roundings downstream turned into 1-ulp flips: 3e-4 between two runs).
+// wpart > 0: group g's rows are the H x W tokens of image g in IMAGE order while src is window-partitioned (ws = wpart,
+// LA_MAP_WINDOW_PART order, pad rows skipped).
+constexpr int CM_CHUNK = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void colmean16_kernel(const T* __restrict__ src, int ld, int rpg, int D, float* __restrict__ part, int wpart,
+                                                        int H, int W) {
+  __shared__ float red[256 * 8];
+  const int g = blockIdx.x, c0 = blockIdx.y * CM_CHUNK;
+  const int cols8 = D / 8, rl = 256 / cols8;              // row lanes
+  const int tid = threadIdx.x, cv = tid % cols8, rlane = tid / cols8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rlane < rl) {
+    const int r1 = min(c0 + CM_CHUNK, rpg);
+    for (int r = c0 + rlane; r < r1; r += rl) {
+      size_t srow;
+      if (wpart > 0) {
+        const int x = r % W, y = r / W;
+        const int nwx = (W + wpart - 1) / wpart, nwy = (H + wpart - 1) / wpart;
+        srow = ((size_t)(g * nwy + y / wpart) * nwx + x / wpart) * wpart * wpart + (y % wpart) * wpart + (x % wpart);
+      } else {
+        srow = (size_t)g * rpg + r;
+      }
+      const uint4 v = *reinterpret_cast<const uint4*>(src + srow * ld + cv * 8);
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (float)e[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
+  __syncthreads();
+  if (rlane == 0) {
+    float* dst = part + ((size_t)g * gridDim.y + blockIdx.y) * D + cv * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float s = 0.f;
+      for (int j = 0; j < rl; ++j) s += red[(j * cols8 + cv) * 8 + k];
+      dst[k] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colmean16_fold_kernel(const float* __restrict__ part, int chunks, int D, float inv, float* __restrict__ out) {
+  const int g = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < chunks; ++j) s += part[((size_t)g * chunks + j) * D + c];
+    out[(size_t)g * D + c] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, long rows, int rpg, int D) {
+  const int d4 = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * d4; i += (long)gridDim.x * 256) {
+    const long r = i / d4;
+    const int c = (int)(i % d4);
+    float4 a = reinterpret_cast<float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(v + (r / rpg) * D)[c];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(x)[i] = a;
+  }
+}
+}  // namespace la
+
+extern "C" int la_colmean16(const void* src, int ld, int groups, int rows_per_group, int D, float* out, float* scratch, int wpart, int H, int W,
+                            int dt, void* stream) {
+  LA_CHECK_ARG(src && out && scratch && groups > 0 && rows_per_group > 0 && D > 0 && (D % 8) == 0 && D <= 2048 && (ld % 8) == 0 &&
+                   (dt == LA_F16 || dt == LA_BF16),
+               "la_colmean16: bad arguments (D %% 8, D <= 2048, ld %% 8)");
+  LA_CHECK_ARG(wpart == 0 || (H > 0 && W > 0 && H * W == rows_per_group), "la_colmean16: window gather needs H * W == rows_per_group");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int chunks = (rows_per_group + la::CM_CHUNK - 1) / la::CM_CHUNK;
+  const dim3 grid(groups, chunks), blk(256);
+  if (dt == LA_F16) hipLaunchKernelGGL(la::colmean16_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)src, ld, rows_per_group, D, scratch, wpart, H, W);
+  else hipLaunchKernelGGL(la::colmean16_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)src, ld, rows_per_group, D, scratch, wpart, H, W);
+  hipLaunchKernelGGL(la::colmean16_fold_kernel, dim3(groups), blk, 0, st, scratch, chunks, D, 1.0f / (float)rows_per_group, out);
+  LA_CHECK_LAUNCH("la_colmean16");
+  return 0;
+}
+
+extern "C" int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D, void* stream) {
+  LA_CHECK_ARG(x && v && rows > 0 && rows_per_group > 0 && D > 0 && (D % 4) == 0, "la_add_rowvec: bad arguments");
+  const long n = rows * (D / 4);
+  hipLaunchKernelGGL(la::add_rowvec_kernel, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, v, rows, rows_per_group, D);
+  LA_CHECK_LAUNCH("la_add_rowvec");
   return 0;
 }

@@ -70,10 +70,19 @@ class Arena:
 # tried (without proj 7.0-9.4e-4 - inside the tolerance on every seed tried, but with 6 % to spare, for 3 % of the step; lin2's
 # plane would buy another ~1e-4 for 8 %); encoders narrower than 512 keep the full qkv, proj and lin2 planes (cheap there, and
 # their share of the error is larger: sam_tiny 8.3e-4 -> 6.0e-4).
+#   "vmean", "projmean": TOKEN-MEAN correction instead of a second plane (round 3).  With one plane token i errs by a_i . W_lo^T; what
+#        survives attention and pooling is the part every token of an image shares, mean_i(a_i) . W_lo^T - a per-image vector.  It is
+#        formed in fp32 from the column means of the 16-bit A operand (la_colmean16 + a few-row exact-fp32 la_gemm against the fp32
+#        residual W - W_hi) and carried as a pending per-image correction R of the residual stream that every LayerNorm adds on the fly
+#        (la_layernorm_g).  V: softmax rows sum to one, so the vector c_v = mean(x) Wv_lo^T that belongs on every V row of the image
+#        comes out of attention unchanged and goes through proj as c_v Wo^T (exact fp32); proj adds mean(o) Wo_lo^T.  Emulated
+#        (tools/error_budget.py --mean): cfg1 low-res logits 6.4e-4 (two planes 6.0e-4, one plane 9.5e-4), cfg2 6.5e-4 (two planes
+#        7.5e-4) - the second MFMA pass of V and proj (8.7 ms of the 100 ms cfg2 step) for two column means and three few-row GEMMs.
 PRECISE_FULL = ("patch", "qkv", "proj", "lin2", "neck")
-PRECISE_WIDE = ("patch", "v", "proj", "neck")
+PRECISE_WIDE = ("patch", "vmean", "projmean", "neck")
+PRECISE_WIDE_PLANES = ("patch", "v", "proj", "neck")          # round 2's default: second weight planes for V and proj
 PRECISE_DEFAULT = "auto"
-PRECISE_GROUPS = ("patch", "qkv", "v", "proj", "lin1", "lin2", "neck")
+PRECISE_GROUPS = ("patch", "qkv", "v", "proj", "lin1", "lin2", "neck", "vmean", "projmean")
 
 
 _BICUBIC: Dict[tuple, Tensor] = {}
@@ -199,6 +208,40 @@ class LamEngine:
         else:
             self.p[key] = t.to(self.dt)
             self.kmod.pop(key, None)
+
+    def _pack_mean(self, pre: str, wv: Tensor, wo: Tensor) -> None:
+        """fp32 operands of the token-mean corrections of one block: what the 16-bit plane of Wv / Wo lost, and Wo itself."""
+        if "vmean" in self.precise:
+            wv = wv.contiguous()
+            self.p[pre + ".v.lo32"] = (wv - wv.to(self.dt).float()).contiguous()               # [ea, E]
+            self.p[pre + ".o.w32"] = wo.contiguous().float()                                    # [E, ea]: c_v goes through proj exactly
+        if "projmean" in self.precise:
+            wo = wo.contiguous()
+            self.p[pre + ".o.lo32"] = (wo - wo.to(self.dt).float()).contiguous()               # [E, ea]
+
+    @property
+    def mean_planes(self) -> bool:
+        return "vmean" in self.precise or "projmean" in self.precise
+
+    def mean_fix(self, pre: str, xin: Tensor, ao: Tensor, rvec: Tensor, bn: int, rpg: int, wpart_x: int, wpart_o: int, g: int) -> None:
+        """rvec[img] += mean(x) Wv_lo^T Wo^T + mean(o) Wo_lo^T for one attention block (see PRECISE_WIDE).  xin: the 16-bit qkv operand,
+        ao: the attention output, both [rows, *]; wpart_*: window size when that buffer is window-partitioned (rows gathered in
+        image order, pads skipped), 0 when it is in image order."""
+        p = self.p
+        if (pre + ".v.lo32") in p:
+            e = xin.shape[1]
+            xbar = self.f32("mean.xbar", (bn, e))
+            L.colmean16(xin, bn, rpg, xbar, self.f32("mean.scr", (bn * _ceil(rpg, 128) // 128 * e,)), wpart_x, g if wpart_x else 0,
+                        g if wpart_x else 0)
+            cv = self.f32("mean.cv", (bn, p[pre + ".v.lo32"].shape[0]))
+            L.gemm(xbar, p[pre + ".v.lo32"], out32=cv)
+            L.gemm(cv, p[pre + ".o.w32"], res=rvec, out32=rvec)
+        if (pre + ".o.lo32") in p:
+            ea = ao.shape[1]
+            obar = self.f32("mean.obar", (bn, ea))
+            L.colmean16(ao, bn, rpg, obar, self.f32("mean.scr", (bn * _ceil(rpg, 128) // 128 * ea,)), wpart_o, g if wpart_o else 0,
+                        g if wpart_o else 0)
+            L.gemm(obar, p[pre + ".o.lo32"], res=rvec, out32=rvec)
 
     def _hw_qkv(self, key: str, t: Tensor, bias: Tensor, ea: int) -> None:
         """Pack a fused qkv weight [3 ea, K] + bias.  Group "qkv": planes for all rows; group "v": a one-plane [2 ea, K] q/k weight and
@@ -335,6 +378,8 @@ class LamEngine:
                 self._hw_qkv(bp + ".qkv.w", self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp),
                              self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(bp + ".proj.w", self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp), "proj")
+                self._pack_mean(bp, self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp)[2 * spec.heads * hdp:],
+                                self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp))
                 self._hw(bp + ".lin1.w", w[bp + ".mlp.lin1.weight"], "lin1")
                 self._hw(bp + ".lin2.w", w[bp + ".mlp.lin2.weight"], "lin2")
                 size = g if i in spec.global_idx else spec.window
@@ -358,6 +403,8 @@ class LamEngine:
                 self._hw_qkv(lp + ".qkv.w", self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp),
                              self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(lp + ".o.w", self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp), "proj")
+                self._pack_mean(lp, self._pad_heads_out(w[lp + ".attention.attention.value.weight"], spec.heads, hd, hdp),
+                                self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp))
                 self._hw(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], "lin1")
                 self._hw(lp + ".fc2.w", w[lp + ".output.dense.weight"], "lin2")
         if cfg.lam_neck:
@@ -421,8 +468,12 @@ class LamEngine:
             self._pe_cache[g] = t
         return t
 
-    def ln(self, x, name, eps, **kw):
-        L.layernorm(x, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
+    def ln(self, x, name, eps, rvec=None, rpg=0, **kw):
+        """LayerNorm of x (+ the pending per-image corrections rvec[row // rpg] of the mean planes, never written back)."""
+        if rvec is not None:
+            L.layernorm_g(x, rvec, rpg, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
+        else:
+            L.layernorm(x, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
 
     # ------------------------------------------------------------------------------------------------
     # conv neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d on NHWC rows (image_encoder.py:92-108, build_lam.py:150-171)
@@ -493,13 +544,18 @@ class LamEngine:
         nwy = (g + ws - 1) // ws
         x16 = self.buf("enc.x16", (rows, e))
         last16 = None
+        rvec = None
+        if self.mean_planes:           # pending per-image corrections of the single-plane V / proj weights (PRECISE_WIDE)
+            rvec = self.f32("enc.rvec", (bn, e), zero=True)
+            rvec.zero_()
+        rkw = dict(rvec=rvec, rpg=hw) if rvec is not None else {}
         for i in range(spec.depth):
             bp = f"{pre}.blocks.{i}"
             is_global = i in spec.global_idx
             if is_global:
                 nb, t, gg, arows = bn, hw, g, rows
                 xin = x16
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw)
             else:
                 nb, t, gg = bn * nwy * nwy, ws * ws, ws
                 arows = nb * t
@@ -515,10 +571,10 @@ class LamEngine:
                 pass
             elif scatter:
                 xin = x16
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw)
             else:
                 xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g, **rkw)
             if scatter:
                 qb = p[bp + ".qkv.b"]
 
@@ -550,19 +606,27 @@ class LamEngine:
                 relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
                 L.relpos_terms(qkv, nb, heads, gg, ea, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
                 L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS)
+            if rvec is not None:
+                xwin = 0 if (is_global or scatter) else ws
+                self.mean_fix(bp, xin, ao, rvec, bn, hw, xwin, 0 if is_global else ws, g)
             if is_global:
                 self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
             else:       # window_unpartition as a row gather on the A operand: again only the real tokens are computed
                 self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res, M=rows,
                             amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, g, g))
-            self.ln(res, bp + ".norm2", 1e-6, out16=x16)
+            self.ln(res, bp + ".norm2", 1e-6, out16=x16, **rkw)
             hbuf = self.buf("enc.mlp", (rows, spec.mlp))
             self.gemm_w(x16, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
-            if i == spec.depth - 1 and not (self.cfg.use_vit_sam_neck and "neck" in self.precise):
+            if i == spec.depth - 1 and not (self.cfg.use_vit_sam_neck and "neck" in self.precise) and rvec is None:
                 last16 = self.buf("enc.last16", (rows, e))
                 self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=last16)
             else:
                 self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
+        if rvec is not None:           # the stream leaves the block stack: fold the pending corrections in
+            L.add_rowvec(res, rvec, hw)
+            if not (self.cfg.use_vit_sam_neck and "neck" in self.precise):
+                last16 = self.buf("enc.last16", (rows, e))
+                L.add_cast(res, out16=last16, dt=self.dti)
         if not self.cfg.use_vit_sam_neck:
             return (res, last16, e) if not want_last_block else ((res, last16, e), res)
         out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck", x32=res)
@@ -617,9 +681,14 @@ class LamEngine:
         ao = self.buf("hf.ao", (rows, ea))
         hbuf = self.buf("hf.mlp", (rows, spec.mlp))
         scale = spec.head_dim ** -0.5
+        rvec = None
+        if self.mean_planes:
+            rvec = self.f32("hf.rvec", (bn, e), zero=True)
+            rvec.zero_()
+        rkw = dict(rvec=rvec, rpg=t) if rvec is not None else {}
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
-            self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
+            self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, **rkw)
             self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
             if self.attn_fp8 and hdp == 64:
                 qk8 = self.arena.get("hf.qk8", (rows, 2 * ea), torch.uint8, False)
@@ -627,13 +696,15 @@ class LamEngine:
                 L.attn_fwd_fp8(qk8, vt, ao, bn, heads, t, tpad, ea, scale)
             else:
                 L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
+            if rvec is not None:
+                self.mean_fix(lp, x16, ao, rvec, bn, t, 0, 0, g)
             self.gemm_w(ao, lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
-            self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16)
+            self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16, **rkw)
             self.gemm_w(x16, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)
             self.gemm_w(hbuf, lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=res, out32=res)
         fin = self.f32("hf.final", (rows, e))
         fin16 = self.buf("hf.final16", (rows, e))
-        self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16)
+        self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16, **rkw)
         out32 = self.f32("hf.out32", (bn * hw, e))
         out16 = self.buf("hf.out16", (bn * hw, e))
         out32.view(bn, hw, e).copy_(fin.view(bn, t, e)[:, 1:])          # drop CLS (plain strided copy)

@@ -331,6 +331,12 @@ class LamTrainer:
         self.train_encoder = bool(train_encoder)
         if self.train_encoder and lam.cfg.encoder_spec is None:
             raise ValueError("train_encoder=True needs a model with an image encoder")
+        if self.train_encoder:
+            # the saved-activation forward of train_encoder.py runs the plain GEMM sequence: second weight planes instead of the
+            # inference engine's token-mean corrections (same accuracy class)
+            swap = {"vmean": "v", "projmean": "proj"}
+            lam.precise = tuple(dict.fromkeys(swap.get(gname, gname) for gname in lam.precise))
+            lam.invalidate()
         named = [(k, p) for k, p in lam.named_parameters() if self.train_encoder or "image_encoder" not in k]
         # tensors the forward never reaches (dead in the reference too, prompt_encoder.py:683) go to the tail of the flat buffer so
         # that the per-step "received a gradient" spans of FlatAdamW.step stay one contiguous run

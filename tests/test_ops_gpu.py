@@ -725,3 +725,42 @@ def test_fp8_qk_attention_matches_torch_on_e4m3_rounded_operands(L, shape):
     print(f"fp8 QK^T attention {shape}: vs e4m3-rounded operands {err8:.2e}, vs the 16-bit operands {err16:.2e}")
     assert err8 <= 3e-3
     assert err16 <= 0.2
+
+
+@pytest.mark.parametrize("geom", [(3, 901, 768, 0), (2, 4096, 768, 0), (51, 901, 1024, 0), (2, 28 * 28, 128, 14), (1, 64 * 64, 768, 14)])
+def test_token_mean_kernels(L, geom):
+    """la_colmean16 (image order and window-partitioned sources), la_layernorm_g, la_add_rowvec: the pieces of the token-mean
+    correction of single-plane weights.  The means must not depend on the number of groups in the launch (bitwise)."""
+    import torch.nn.functional as F
+    groups, rpg, d, ws = geom
+    gen = torch.Generator().manual_seed(groups * rpg)
+    x = torch.randn(groups * rpg, d, generator=gen).half()
+    g = int(round(rpg ** 0.5))
+    if ws:
+        nw = (g + ws - 1) // ws
+        img = x.view(groups, g, g, d)
+        pad = nw * ws - g
+        win = F.pad(img, (0, 0, 0, pad, 0, pad), value=7.0)           # pad slots hold garbage that must be skipped
+        win = win.view(groups, nw, ws, nw, ws, d).permute(0, 1, 3, 2, 4, 5).reshape(-1, d).contiguous().cuda()
+        src = win
+    else:
+        src = x.cuda()
+    scr = torch.empty(groups * ((rpg + 127) // 128) * d, device="cuda")
+    out = torch.empty(groups, d, device="cuda")
+    L.colmean16(src, groups, rpg, out, scr, ws, g if ws else 0, g if ws else 0)
+    ref = x.float().view(groups, rpg, d).mean(1)
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6
+    if not ws and groups > 1:                                         # one group alone gives the same bits
+        out1 = torch.empty(1, d, device="cuda")
+        L.colmean16(src[rpg:2 * rpg], 1, rpg, out1, scr)
+        assert torch.equal(out1[0], out[1])
+    # LayerNorm of x + per-group vector, and the in-place fold
+    res = torch.randn(groups * rpg, d, generator=gen).cuda()
+    rv = torch.randn(groups, d, generator=gen).cuda() * 0.1
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=gen)).cuda(), (0.1 * torch.randn(d, generator=gen)).cuda()
+    o32 = torch.empty_like(res)
+    L.layernorm_g(res, rv, rpg, gamma, beta, 1e-6, out32=o32, dt=L.LA_F32)
+    full = res + rv.repeat_interleave(rpg, 0)
+    assert float((o32 - F.layer_norm(full, (d,), gamma, beta, 1e-6)).abs().max()) <= 2e-5
+    L.add_rowvec(res, rv, rpg)
+    assert torch.equal(res, full)

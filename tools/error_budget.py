@@ -10,7 +10,8 @@ low-res logits of the full episode, against the un-rounded oracle.  It is how th
     python tools/error_budget.py sam_tiny_2w2s_all_prompts [--dtype f16|bf16] [--only GROUPS] [--loo] [--split GROUPS]
 
 Modes per rounding point: "r" = rounded to 16 bit, "x" = exact, "s" = hi/lo split (hi = r16(x), lo = r16(x - hi); both
-kept, i.e. ~22 mantissa bits).
+kept, i.e. ~22 mantissa bits), and for weights "m" = rounded, with the product of the TOKEN MEAN of the A operand (per image /
+window) and the lo plane added back (--mean): the part of the weight-rounding error that is the same for every token.
 """
 from __future__ import annotations
 
@@ -53,7 +54,29 @@ class Policy:
         return hi + self.r16(x - hi)
 
 
+MEAN_GROUP = {"n": 0, "tokens": 0}       # SAM window blocks: windows per image / real tokens per image (set by sam_encoder)
+
+
+def mean_corrected(pol, a, wt, bias):
+    """a W_hi^T + mean_tokens(a) W_lo^T + bias (a: [batch, tokens..., K]).  In SAM window blocks the batch entries are windows
+    (zero-padded): the mean is taken over the REAL tokens of the whole image, as a device implementation would (one column mean
+    of the LayerNorm output / attention output per image)."""
+    hi = pol.r16(wt)
+    lo = pol.r16(wt - hi)
+    dims = tuple(range(1, a.dim() - 1))
+    g = MEAN_GROUP["n"]
+    if g > 1 and a.shape[0] % g == 0:
+        k = a.shape[-1]
+        am = a.reshape(a.shape[0] // g, -1, k).sum(dim=1, keepdim=True) / MEAN_GROUP["tokens"]        # [images, 1, K]
+        am = am.repeat_interleave(g, dim=0).view(a.shape[0], *([1] * len(dims)), k)
+    else:
+        am = a.mean(dim=dims, keepdim=True)
+    return F.linear(a, hi, bias) + F.linear(am, lo)
+
+
 def lin(pol, point, w, name, x, block=None):
+    if pol.modes.get(point + ".W") == "m":
+        return mean_corrected(pol, pol(point + ".A", x, block), w[name + ".weight"], w.get(name + ".bias"))
     wt = pol(point + ".W", w[name + ".weight"], block)
     return F.linear(pol(point + ".A", x, block), wt, w.get(name + ".bias"))
 
@@ -63,8 +86,13 @@ def sam_attention(pol, w, pre, x, heads, blk):
     hd = e // heads
     t = gh * gw
     wq = w[pre + ".qkv.weight"]
-    wq = torch.cat([pol("qk.W", wq[:2 * e], blk), pol("v.W", wq[2 * e:], blk)])
-    qkv = F.linear(pol("qkv.A", x.reshape(n, t, e), blk), wq, w[pre + ".qkv.bias"])
+    xa = pol("qkv.A", x.reshape(n, t, e), blk)
+    if pol.modes.get("v.W") == "m":
+        qkv = torch.cat([F.linear(xa, pol("qk.W", wq[:2 * e], blk), w[pre + ".qkv.bias"][:2 * e]),
+                         mean_corrected(pol, xa, wq[2 * e:], w[pre + ".qkv.bias"][2 * e:])], dim=-1)
+    else:
+        wq = torch.cat([pol("qk.W", wq[:2 * e], blk), pol("v.W", wq[2 * e:], blk)])
+        qkv = F.linear(xa, wq, w[pre + ".qkv.bias"])
     qkv = qkv.view(n, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = pol("attn.QK", qkv[0], blk), pol("attn.QK", qkv[1], blk), pol("attn.V", qkv[2], blk)
     scores = (q @ k.transpose(-1, -2)) * (hd ** -0.5)
@@ -93,8 +121,11 @@ def sam_encoder(pol, w, geo, images, pre="image_encoder"):
         y = O.layer_norm(w, bp + ".norm1", x, 1e-6)
         if win > 0:
             h, wd = y.shape[1], y.shape[2]
+            nimg = y.shape[0]
             y, padded = O.window_split(y, win)
+            MEAN_GROUP.update(n=y.shape[0] // nimg, tokens=h * wd)
             y = sam_attention(pol, w, bp + ".attn", y, geo.enc_heads, i)
+            MEAN_GROUP.update(n=0)
             y = O.window_merge(y, win, padded, (h, wd))
         else:
             y = sam_attention(pol, w, bp + ".attn", y, geo.enc_heads, i)
@@ -130,8 +161,10 @@ def hf_encoder(pol, w, geo, images, pre="image_encoder"):
         lp = f"{pre}.encoder.layer.{i}"
         y = O.layer_norm(w, lp + ".layernorm_before", x, 1e-12)
         ya = pol("qkv.A", y, i)
-        q, k, v = (F.linear(ya, pol("v.W" if n == "value" else "qk.W", w[f"{lp}.attention.attention.{n}.weight"], i),
-                            w[f"{lp}.attention.attention.{n}.bias"]).view(bn, t, heads, hd).transpose(1, 2)
+        q, k, v = ((mean_corrected(pol, ya, w[f"{lp}.attention.attention.{n}.weight"], w[f"{lp}.attention.attention.{n}.bias"])
+                    if (n == "value" and pol.modes.get("v.W") == "m") else
+                    F.linear(ya, pol("v.W" if n == "value" else "qk.W", w[f"{lp}.attention.attention.{n}.weight"], i),
+                             w[f"{lp}.attention.attention.{n}.bias"])).view(bn, t, heads, hd).transpose(1, 2)
                    for n in ("query", "key", "value"))
         q, k, v = pol("attn.QK", q, i), pol("attn.QK", k, i), pol("attn.V", v, i)
         scores = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
@@ -183,6 +216,7 @@ def main():
     ap.add_argument("--loo", action="store_true", help="round all points but one")
     ap.add_argument("--split", default="", help="comma list of points kept as hi/lo pairs (others rounded)")
     ap.add_argument("--exact", default="", help="comma list of points kept exact (others rounded)")
+    ap.add_argument("--mean", default="", help="comma list of WEIGHT points (v.W, proj.W, lin1.W, lin2.W) rounded + token-mean correction")
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     if a.threads:
@@ -214,7 +248,9 @@ def main():
             modes[p] = "s"
         for p in filter(None, a.exact.split(",")):
             modes[p] = "x"
-        report("all rounded" if modes == allr else f"split={a.split} exact={a.exact}", modes)
+        for p in filter(None, a.mean.split(",")):
+            modes[p] = "m"
+        report("all rounded" if modes == allr else f"split={a.split} exact={a.exact} mean={a.mean}", modes)
         if a.one_in:
             for p in POINTS:
                 report("only " + p, {p: "r"})
