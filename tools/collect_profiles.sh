@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run on the MI355X box (via gpurun) from the repo root: refreshes everything the judge reads under profiles/ for round $1.
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -25,6 +25,11 @@ python tools/pmc_traffic.py $(find $OUT/pmc4 -name 'f_counter_collection.csv' | 
 # 3c. the other workloads (each carries its own kernel table; traffic stays null where no PMC file matches) and the two
 #     numerics variants of the headline: plain 16-bit operands (round-1 numerics, misses 1e-3) and bf16
 for w in cfg1 cfg3 cfg4 cfg5 cfg3_train; do timeout 600 python bench.py --workload $w --no-cpu-baseline --no-eager-baseline > $OUT/${R}_bench_$w.json 2>> $OUT/bench.stderr; done
+timeout 600 python bench.py --workload cfg3_train --train-encoder --no-cpu-baseline > $OUT/${R}_bench_cfg3_train_encoder.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise patch,v,proj,neck > $OUT/${R}_bench_cfg2_weight_planes.json 2>> $OUT/bench.stderr
+timeout 600 python tools/attn_fp8_report.py > $OUT/${R}_attn_fp8.log 2>&1
+timeout 600 python tools/gemm_ab.py > $OUT/${R}_gemm_ab.log 2>&1
+timeout 900 python -m pytest tests/test_parity_seeds_gpu.py tests/test_encoder_train_gpu.py tests/test_train_gpu.py::test_cfg3_train_step_at_full_size -m gpu -q -s > $OUT/${R}_parity_seeds.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
 timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>&1

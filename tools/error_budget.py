@@ -111,9 +111,22 @@ def sam_attention(pol, w, pre, x, heads, blk):
     return lin(pol, "proj", w, pre + ".proj", o, blk)
 
 
+def patch_embed(pol, images, wt, bias, patch):
+    """Patch embedding conv (stride = kernel): with patch.W in mode "m" one 16-bit weight plane + the product of the image's MEAN patch
+    and the lo plane."""
+    a = pol("patch.A", images)
+    if pol.modes.get("patch.W") != "m":
+        return F.conv2d(a, pol("patch.W", wt), bias, stride=patch)
+    hi = pol.r16(wt)
+    lo = pol.r16(wt - hi)
+    y = F.conv2d(a, hi, bias, stride=patch)
+    n, c, hh, ww = a.shape
+    mp = a.view(n, c, hh // patch, patch, ww // patch, patch).mean(dim=(2, 4))           # mean patch per image [n, c, p, p]
+    return y + torch.einsum("ncyx,ocyx->no", mp, lo)[:, :, None, None]
+
+
 def sam_encoder(pol, w, geo, images, pre="image_encoder"):
-    x = F.conv2d(pol("patch.A", images), pol("patch.W", w[pre + ".patch_embed.proj.weight"]),
-                 w[pre + ".patch_embed.proj.bias"], stride=geo.patch).permute(0, 2, 3, 1)
+    x = patch_embed(pol, images, w[pre + ".patch_embed.proj.weight"], w[pre + ".patch_embed.proj.bias"], geo.patch).permute(0, 2, 3, 1)
     x = x + w[pre + ".pos_embed"]
     for i in range(geo.enc_depth):
         bp = f"{pre}.blocks.{i}"
@@ -151,8 +164,8 @@ def hf_encoder(pol, w, geo, images, pre="image_encoder"):
     g = images.shape[-1] // geo.patch
     e, heads = geo.enc_dim, geo.enc_heads
     hd = e // heads
-    x = F.conv2d(pol("patch.A", images), pol("patch.W", w[pre + ".embeddings.patch_embeddings.projection.weight"]),
-                 w[pre + ".embeddings.patch_embeddings.projection.bias"], stride=geo.patch)
+    x = patch_embed(pol, images, w[pre + ".embeddings.patch_embeddings.projection.weight"],
+                    w[pre + ".embeddings.patch_embeddings.projection.bias"], geo.patch)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat([w[pre + ".embeddings.cls_token"].expand(bn, -1, -1), x], dim=1)
     x = x + O.hf_pos_embed(w, pre, g, geo.hf_pos_grid)

@@ -6,7 +6,7 @@ import torch
 from labelanything_amd.models import Lam
 from labelanything_amd.episodes import make_episode
 from tests.cases import CASES
-from labelanything_amd.engine import PRECISE_DEFAULT, PRECISE_FULL, PRECISE_WIDE
+from labelanything_amd.engine import PRECISE_DEFAULT, PRECISE_FULL, PRECISE_WIDE, PRECISE_WIDE_PLANES
 from tests.helpers import load_golden, rel_err, reference_logits, argmax_disagreement
 
 
@@ -20,7 +20,8 @@ def main():
     if "--decoder" in sys.argv:     # exact-fp32 MFMA decoder against the fp16 plane-pair (3-product) image side
         variants = [(torch.float16, torch.float32, "auto"), (torch.float16, "f16x2", "auto")]
     if "--groups" in sys.argv:      # the default against leaner group sets (which planes are worth their MFMA passes)
-        variants = [(torch.float16, torch.float32, g) for g in (PRECISE_FULL, PRECISE_WIDE, ("patch", "qkv", "neck"), ("patch", "qkv", "lin2", "neck"))]
+        variants = [(torch.float16, torch.float32, g) for g in (PRECISE_FULL, PRECISE_WIDE, PRECISE_WIDE_PLANES, ("patch", "neck"),
+                                                                ("patch", "vmean", "neck"), ("patch", "qkv", "neck"))]
     for dt, ddt, precise in variants:
         for name, case in CASES.items():
             if only and name not in only:
