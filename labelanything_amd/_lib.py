@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libla_hip.so")
+LIB_PATH = os.environ.get("LA_HIP_LIB") or os.path.join(_HERE, "libla_hip.so")      # (override: same-box A/B of two builds, tools/)
 
 LA_F16, LA_BF16, LA_F32, LA_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -1275,6 +1275,10 @@ __device__ __forceinline__ int slab_swz(int r) { return ((r & 1) << 2) | ((r >> 
 template <typename T, int EPI>
 __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16 (&acc)[4][2], int row0, int col0, int n0, int M,
                                               const LaGemmEpilogue& e, int lane, bool nostore = false) {
+  // everything below that depends only on the lane (slab addresses, output offsets) is loop-invariant over the tiles of a persistent
+  // kernel; hoisted, it would sit in registers through the main loop, which has none to spare (spills there reload through
+  // scratch_load + s_waitcnt vmcnt(0)) - an opaque copy of the lane id keeps those few dozen integer operations in the epilogue
+  if (EPI != 3) asm volatile("" : "+v"(lane));       // (the fp32 form: its spills then move INTO the main loop - measured on the ISA)
   const int fr = lane & 31, fh = lane >> 5;
   const float bias0 = e.bias ? e.bias[col0 + fr] : 0.f, bias1 = e.bias ? e.bias[col0 + 32 + fr] : 0.f;
   // consume the two loads HERE: hipcc does not see the LDS-DMA pieces, and a load whose first use sits on only some of the paths
@@ -1377,8 +1381,71 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
       }
     return;
   }
+  if ((EPI == 1 || EPI == 2) && rtab == nullptr && row0 + 128 <= M) {
+    // 16-bit output of an interior tile, the common case.  Registers 2k, 2k + 1 of an accumulator are rows 2p, 2p + 1 of ONE column:
+    // bias (+ GELU) on the pair in packed fp32, one cvt_pk, one 32-bit LDS store - no lane exchange.  Slab = [8 row pairs][64
+    // columns] of such words; 16-byte unit u of a row pair sits at u ^ (u >> 3) (conflict-free reads below; on the store side the
+    // flip is the compile-time tj).  Read side: lane (pair p, 8-column group ch) fetches the pair's 8 columns as two 16-byte units
+    // and unzips them with v_perm into the two 16-byte row segments it stores: whole 128-byte lines per 8 lanes.
+    // The LDS queue of a wave is in order: chunk c + 1 is written right behind the READ INSTRUCTIONS of chunk c, and the read data is
+    // waited for (counted) only after those writes have been issued - no round trip is exposed between chunks.
+    T* out = reinterpret_cast<T*>(e.out16);
+    const int rp = lane >> 3, rch = lane & 7, rs = rch >> 2;
+    char* wb0 = slab + (2 * fh) * 256 + (fr >> 2) * 16 + (fr & 3) * 4;                   // pair 2 fh (+ kp + 4 q), logical unit fr >> 2
+    char* wb1 = wb0 + 128 + (((fr >> 2) & 1) ? -16 : 16);                                // logical unit 8 + (fr >> 2) -> physical ^ 1
+    const char* rb0 = slab + rp * 256 + (2 * rch + rs) * 16;
+    const char* rb1 = slab + rp * 256 + (2 * rch + 1 - rs) * 16;
+    T* op = out + (size_t)(row0 + 2 * rp) * e.ld16 + col0 + rch * 8;
+    const size_t cstride = (size_t)16 * e.ld16;
+    const f32x2 b0 = {bias0, bias0}, b1 = {bias1, bias1};
+    auto wr = [&](int c) {
+      const int i = c >> 1, h = c & 1;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int kp = 0; kp < 2; ++kp) {
+            const int r = h * 8 + q * 4 + 2 * kp;
+            f32x2 v = f32x2{acc[i][tj][r], acc[i][tj][r + 1]} + (tj ? b1 : b0);
+            if (EPI == 2) v = gelu_erf_pk(v);
+            *reinterpret_cast<uint32_t*>((tj ? wb1 : wb0) + (kp + 4 * q) * 256) = pack2<T>(v.x, v.y);
+          }
+    };
+    uint4 u0, u1;
+    auto rd = [&]() {
+      u0 = *reinterpret_cast<const uint4*>(rb0);
+      u1 = *reinterpret_cast<const uint4*>(rb1);
+    };
+    wr(0);
+    asm volatile("" ::: "memory");
+    rd();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      asm volatile("" ::: "memory");
+      if (c + 1 < 8) wr(c + 1);
+      asm volatile("" ::: "memory");
+      uint4 ev, od;
+      ev.x = __builtin_amdgcn_perm(u0.y, u0.x, 0x05040100u);
+      ev.y = __builtin_amdgcn_perm(u0.w, u0.z, 0x05040100u);
+      ev.z = __builtin_amdgcn_perm(u1.y, u1.x, 0x05040100u);
+      ev.w = __builtin_amdgcn_perm(u1.w, u1.z, 0x05040100u);
+      od.x = __builtin_amdgcn_perm(u0.y, u0.x, 0x07060302u);
+      od.y = __builtin_amdgcn_perm(u0.w, u0.z, 0x07060302u);
+      od.z = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
+      od.w = __builtin_amdgcn_perm(u1.w, u1.z, 0x07060302u);
+      if (!nostore) {
+        *reinterpret_cast<uint4*>(op) = ev;
+        *reinterpret_cast<uint4*>(op + e.ld16) = od;
+      }
+      op += cstride;
+      if (c + 1 < 8) rd();
+    }
+    return;
+  }
   if (EPI == 1 || EPI == 2) {
-    // 16-bit output.  Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ slab_swz(r).  Lane pairs (fr, fr ^ 1) trade one
+    // 16-bit output, general form (edge tiles, output row maps).
+    // Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ slab_swz(r).  Lane pairs (fr, fr ^ 1) trade one
     // value per register pair over DPP: the even lane ends up with columns (c, c + 1) of row k, the odd lane with the same columns
     // of row k + 1 - one 32-bit LDS store each.
     T* out = reinterpret_cast<T*>(e.out16);

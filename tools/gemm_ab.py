@@ -23,6 +23,8 @@ def run(name, a, w, bias, o16, res):
     m = o16.shape[0]
     if name.startswith("lin1"):
         L.gemm(a, w, bias=bias, out16=o16, act=L.ACT_GELU, M=m, lda=LDA)
+    elif name.startswith("nr_"):                    # fp32 output without the residual read (what the read burst of lin2 / proj costs)
+        L.gemm(a, w, bias=bias, out32=res, M=m, lda=LDA)
     elif name.startswith("lin2") or name.startswith("proj1"):
         L.gemm(a, w, bias=bias, res=res, out32=res, M=m, lda=LDA)
     else:
@@ -35,7 +37,7 @@ for name, m, n, k in SHAPES:
     w = (torch.randn(n, k, device="cuda", generator=g) / math.sqrt(k)).to(dt)
     bias = torch.randn(n, device="cuda", generator=g)
     o16 = torch.empty(m, n, device="cuda", dtype=dt)
-    res = torch.zeros(m, n, device="cuda") if name.startswith(("lin2", "proj1")) else None
+    res = torch.zeros(m, n, device="cuda") if name.startswith(("lin2", "proj1", "nr_")) else None
     outs, times = {}, {v: [] for v in variants}
     for v in variants:
         L.gemm_variant(v)
