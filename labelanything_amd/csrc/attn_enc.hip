@@ -17,6 +17,9 @@
 //               straight from global memory, U scattered to relw[q][qx - r + G - 1].
 #include <cstdlib>
 #include "la_common.h"
+#ifndef LA_ATTN_ABL
+#define LA_ATTN_ABL 0       // measurement ablations of attn_fwd_kernel (results wrong): 1 no exp, 2 no S MFMAs, 4 no PV MFMAs, 8 no staging / barrier
+#endif
 #include "../../include/la_hip.h"
 
 namespace la {
@@ -100,6 +103,18 @@ __global__ __launch_bounds__(256) void relpos_kernel(const T* __restrict__ qkv, 
       }
     }
   }
+}
+
+
+// max / sum of a value over the lane pair (l, l ^ 32): one v_permlane32_swap (both halves end up holding both values) instead of a
+// ds_bpermute round trip through the LDS queue in the middle of every key tile's dependency chain
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -363,7 +378,9 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
   const bool idle_wave = q0 >= T_;
   for (int j = 0; j < ntiles; ++j) {
+#if !(LA_ATTN_ABL & 8)
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+#endif
     if (idle_wave) {
       dma_wait<0>();
       __syncthreads();
@@ -402,6 +419,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         s[t] = Half16<T>::mfma32(kf0, qf[0], z);
       }
     }
+#if !(LA_ATTN_ABL & 2)
 #pragma unroll
     for (int ks = 1; ks < KS; ++ks) {
 #pragma unroll
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
       }
     }
+#endif
     if (MODE == 1) {
       const int GS = a.G + 1;
 #pragma unroll
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) + rh;
+    mx = xhalf_max(mx) + rh;
     if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
@@ -470,7 +489,13 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        // (scalar FMAs on purpose: v_pk_fma_f32 does not overlap with another wave's MFMA stream at all, v_fma_f32 partly, v_exp_f32
+        // fully - tools/probes/coissue.hip; the packed form of this loop measured 0.7 % slower)
+#if LA_ATTN_ABL & 1
+        const float p = fmaf(s[t][r], c2, mc);
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, mc));   // raw v_exp_f32 (no denormal fix-up)
+#endif
         s[t][r] = p;
         psum += p;
       }
@@ -491,6 +516,10 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     }
 
     // ---- O^T += V^T P^T -----------------------------------------------------------------------------------
+#if LA_ATTN_ABL & 4
+    asm volatile("" ::"v"(pf[0].x), "v"(pf[0].y), "v"(pf[0].z), "v"(pf[0].w), "v"(pf[1].x), "v"(pf[1].y), "v"(pf[1].z), "v"(pf[1].w));
+    asm volatile("" ::"v"(pf[2].x), "v"(pf[2].y), "v"(pf[2].z), "v"(pf[2].w), "v"(pf[3].x), "v"(pf[3].y), "v"(pf[3].z), "v"(pf[3].w));
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -499,13 +528,16 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         oacc[d] = Half16<T>::mfma32(vf, pf[ks], oacc[d]);
       }
     }
+#endif
 
+#if !(LA_ATTN_ABL & 8)
     dma_wait<0>();     // next tile (issued before this tile's MFMAs) has landed for this wave ...
     __syncthreads();   // ... and for all waves; orders the stage swap
+#endif
   }
 
   // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = xhalf_sum(l_run);
   const float inv_l = 1.0f / l_tot;
   if (a.lse != nullptr && q < T_ && fh == 0) a.lse[(size_t)bh * a.Tpad + q] = m_run * c2 + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
   if (q < T_) {
@@ -630,7 +662,7 @@ __global__ __launch_bounds__(256, 3) void attn_window_kernel(AttnArgs a, int qti
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
@@ -669,7 +701,7 @@ __global__ __launch_bounds__(256, 3) void attn_window_kernel(AttnArgs a, int qti
 #pragma unroll
       for (int d = 0; d < 2; ++d) oacc[d] = Half16<T>::mfma32(vf[d][ks], pf[ks], oacc[d]);
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = xhalf_sum(l_run);
   const float inv_l = 1.0f / l_tot;
   if (q < T_) {
     T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HD;
@@ -796,7 +828,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(AttnArgs a, const 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
@@ -840,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(AttnArgs a, const 
     dma_wait<0>();
     __syncthreads();
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = xhalf_sum(l_run);
   const float inv_l = 1.0f / l_tot;
   if (q < T_) {
     T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * 64;
