@@ -361,9 +361,22 @@ int la_colmean16(const void* src, int ld, int groups, int rows_per_group, int D,
                  void* stream);
 
 /* la_layernorm of x[r] + xg[r / rows_per_group] (xg fp32 [rows / rows_per_group, E]): the pending per-image corrections enter every
- * consumer of the residual stream without being written back. */
+ * consumer of the residual stream without being written back.  colsum_part != NULL (fp32 [rows / rows_per_group * ceil(rows_per_group
+ * / 128), E]): the pass also leaves the column sums of the 16-bit rows it stored, per 128-row chunk of a group - the token means of
+ * the next GEMM's operand without a second pass over it (la_colsum_fold turns the chunks into means). */
 int la_layernorm_g(const float* x, const float* xg, int rows_per_group, int ldx, int rows, int E, const float* gamma, const float* beta,
-                   float eps, float* out32, void* out16, int window, int H, int W, int dt, void* stream);
+                   float eps, float* out32, void* out16, int window, int H, int W, float* colsum_part, int dt, void* stream);
+
+/* la_attn_fwd that also writes the column sums of every 128-query block of its 16-bit output: cspart fp32 [B * ceil(T / 128), E]
+ * (models/image_encoder.py:225-255 - the attention output is the proj operand whose token means the correction needs).
+ * LA_ATTN_RELPOS_WIN16 with csH x csW = the image's token grid: B = images * windows per image, rows of padded window slots are left
+ * out of the sums.  Not available on the G <= 16 LA_ATTN_RELPOS window path. */
+int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh, const void* tabw,
+                   int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, float* cspart, int csH, int csW, int dt,
+                   void* stream);
+
+/* out[g * ldo + c] = inv * sum over the chunks j of part[(g * chunks + j) * D + c], added in index order (fp32). */
+int la_colsum_fold(const float* part, int groups, int chunks, int D, float inv, float* out, int ldo, void* stream);
 
 /* x[r] += v[r / rows_per_group] in place (fp32 [rows, D]). */
 int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D, void* stream);

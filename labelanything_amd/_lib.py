@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold",
 ]
 
 
@@ -493,12 +493,39 @@ def colmean16(src, groups: int, rows_per_group: int, out, scratch, wpart: int = 
                               _ptr(scratch), C.c_int(wpart), C.c_int(h), C.c_int(w), C.c_int(dt_of(src)), _stream()), "la_colmean16")
 
 
-def layernorm_g(x, xg, rows_per_group: int, gamma, beta, eps: float, *, out32=None, out16=None, window=0, H=0, W=0, dt=LA_F16) -> None:
+def layernorm_g(x, xg, rows_per_group: int, gamma, beta, eps: float, *, out32=None, out16=None, window=0, H=0, W=0, colsum_part=None,
+                dt=LA_F16) -> None:
+    """colsum_part: fp32, >= (rows / rows_per_group) * ceil(rows_per_group / 128) * E elements (column sums of the stored 16-bit rows per
+    128-row chunk of a group; colsum_fold makes the means)."""
     _dev(x)
     rows, e = x.shape
+    if colsum_part is not None:
+        need = rows // rows_per_group * ((rows_per_group + 127) // 128) * e
+        if colsum_part.dtype != torch.float32 or colsum_part.numel() < need:
+            raise ValueError(f"layernorm_g colsum_part needs {need} fp32 elements")
     _check(lib().la_layernorm_g(_ptr(x), _ptr(xg), C.c_int(rows_per_group), C.c_int(x.stride(0)), C.c_int(rows), C.c_int(e), _ptr(gamma),
-                                _ptr(beta), C.c_float(eps), _ptr(out32), _ptr(out16), C.c_int(window), C.c_int(H), C.c_int(W), C.c_int(dt),
-                                _stream()), "la_layernorm_g")
+                                _ptr(beta), C.c_float(eps), _ptr(out32), _ptr(out16), C.c_int(window), C.c_int(H), C.c_int(W),
+                                _ptr(colsum_part), C.c_int(dt), _stream()), "la_layernorm_g")
+
+
+def attn_fwd_cs(qkv, vt, out16, relh, relw, b: int, heads: int, t: int, tpad: int, g: int, e: int, scale: float, mode: int, cspart,
+                cs_h: int = 0, cs_w: int = 0, tabh=None, tabw=None) -> None:
+    """attn_fwd + column sums of every 128-query block of the output: cspart fp32 [b * ceil(t / 128), e]."""
+    need = b * ((t + 127) // 128) * e
+    if cspart.dtype != torch.float32 or cspart.numel() < need:
+        raise ValueError(f"attn_fwd_cs cspart needs {need} fp32 elements")
+    _check(lib().la_attn_fwd_cs(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), _ptr(tabh), _ptr(tabw), C.c_int(b), C.c_int(heads),
+                                C.c_int(t), C.c_int(tpad), C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(mode), _ptr(cspart),
+                                C.c_int(cs_h), C.c_int(cs_w), C.c_int(dt_of(qkv)), _stream()), "la_attn_fwd_cs")
+
+
+def colsum_fold(part, groups: int, chunks: int, d: int, inv: float, out) -> None:
+    """out[g, :d] = inv * sum_j part[g * chunks + j, :d] (out: fp32 rows of stride out.stride(0), e.g. a column slice)."""
+    _dev(part)
+    if out.dtype != torch.float32 or out.stride(1) != 1 or out.shape[0] < groups or out.shape[1] < d:
+        raise ValueError("colsum_fold: out must be fp32 [groups, >= d] with unit column stride")
+    _check(lib().la_colsum_fold(_ptr(part), C.c_int(groups), C.c_int(chunks), C.c_int(d), C.c_float(inv), _ptr(out), C.c_int(out.stride(0)),
+                                _stream()), "la_colsum_fold")
 
 
 def add_rowvec(x, v, rows_per_group: int) -> None:

@@ -129,6 +129,8 @@ struct AttnArgs {
   int B, heads, T, Tpad, G, E;
   float scale;
   float* lse;         // optional [B*heads, Tpad] (row stride Tpad): log2-domain log-sum-exp of every query row (la_attn_fwd_lse: the training forward)
+  float* cspart;      // optional [B * ceil(T / 128), E]: column sums of the 16-bit output rows of every 128-query block (the token means of
+  int csH, csW;       // the proj operand, LamEngine mean planes); WIN16 with csH x csW = the image's token grid: padded window rows left out
 };
 
 // MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
@@ -552,6 +554,36 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
       }
   }
+  if (a.cspart != nullptr) {
+    // column sums of the block's stored rows: DPP sums over the 16-lane rows (a lane is a query), the 4 rows x 4 waves of a column
+    // meet in LDS (the K / V^T stages are idle: the key loop ended with a barrier) and are added in a fixed order
+    bool valid = q < T_;
+    if (MODE == 5 && a.csH > 0) {
+      const int nwx = (a.csW + a.G - 1) / a.G, nwy = (a.csH + a.G - 1) / a.G;
+      const int w = b % (nwx * nwy);
+      valid = valid && (w / nwx) * a.G + qc / a.G < a.csH && (w % nwx) * a.G + qc % a.G < a.csW;
+    }
+    float* red = reinterpret_cast<float*>(smem);
+    constexpr int NR = 2 * NH * 16;
+#pragma unroll
+    for (int d = 0; d < 2 * NH; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = valid ? (float)(T)(oacc[d][r] * inv_l) : 0.f;
+        const float sr = row16_sum(v);
+        if ((lane & 15) == 0) red[(wave * NR + d * 16 + r) * 4 + (lane >> 4)] = sr;
+      }
+    __syncthreads();
+    if (tid < HDT) {
+      const int d = tid >> 5, rem = tid & 31, g4 = rem >> 3, ch = (rem >> 2) & 1, k = rem & 3;
+      const int r = g4 * 4 + k;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(w * NR + d * 16 + r) * 4 + 2 * ch] + red[(w * NR + d * 16 + r) * 4 + 2 * ch + 1];
+      const int nq = (T_ + 127) / 128;
+      a.cspart[((size_t)b * nq + qblk) * a.E + h * HDT + tid] = t;
+    }
+  }
 }
 
 
@@ -929,14 +961,24 @@ extern "C" int la_relpos_terms(const void* qkv, int B, int heads, int G, int E, 
   return 0;
 }
 
+extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
+                              const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, float* cspart, int csH,
+                              int csW, int dt, void* stream);
+
 extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
                            const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
+  return la_attn_fwd_cs(qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale, mode, nullptr, 0, 0, dt, stream);
+}
+
+extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
+                              const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, float* cspart, int csH,
+                              int csW, int dt, void* stream) {
   LA_CHECK_ARG(qkv && vt && out16, "la_attn_fwd: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
                "la_attn_fwd: needs head_dim 64 or 128 - pad other widths with zero columns (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd: bad dtype %d", dt);
-  la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale, nullptr};
+  la::AttnArgs a{qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale, nullptr, cspart, csH, csW};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t kv = 0;       // launch_attn adds the K / V^T stages for the head width; the sizes below are the bias tables
   if (mode == LA_ATTN_PLAIN) {

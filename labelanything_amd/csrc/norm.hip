@@ -26,20 +26,40 @@ struct LnArgs {
   int split;          // LA_F16X2: the 16-bit outputs are [hi | lo] plane pairs (row stride 2 E)
   int x2_group;       // > 0: x2 is [rows / x2_group, E] and row r adds x2[r / x2_group] (a per-image vector: the pending token-mean
                       // corrections of single-plane weights, LamEngine mean planes)
+  float* cs_part;     // != nullptr: workgroup (group g, chunk c of ceil(cs_rpg / CM_CHUNK)) handles a fixed 1 / chunks share of the rows of group g
+  int cs_rpg;         // (cs_rpg rows per group) and writes the column sums of what it stored to cs_part[(g * chunks + c) * E ..]: the token means
+                      // of the qkv operand come out of the pass that writes it (la_colsum_fold adds the chunks in a fixed order)
 };
+constexpr int CM_CHUNK = 128;
 
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) { store4v<T>(p, a, b, c, d); }
 
 // NVT = float4 vectors per lane (compile time, so the row loads are issued back to back without per-vector predicates);
 // EXACT = every lane has all NVT vectors (E == 4 * LPR * NVT), otherwise the tail vectors are predicated.
-template <typename T, int LPR, int NVT, bool EXACT>
+// CS = the launch also leaves column sums (LnArgs.cs_part): its own instance, so that the twelve accumulator registers and the 4 NVT KiB
+// of LDS do not cost the plain launches their eighth wave per SIMD (measured: +22 % on every LayerNorm of the step).
+template <typename T, int LPR, int NVT, bool EXACT, bool CS>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int tid = threadIdx.x;
   const int rl = tid / LPR, lane = tid % LPR;
   const int nv = a.E >> 2;
-  for (int row = blockIdx.x * RPB + rl; row < a.rows; row += gridDim.x * RPB) {
+  __shared__ float4 cs_red[CS ? 256 * NVT : 1];
+  float4 cs[CS ? NVT : 1];
+#pragma unroll
+  for (int i = 0; i < (CS ? NVT : 1); ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int row_begin = blockIdx.x * RPB + rl, row_end = a.rows, row_step = gridDim.x * RPB;
+  if (CS) {
+    const int chunks = (a.cs_rpg + CM_CHUNK - 1) / CM_CHUNK;
+    const int g = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    // "chunk" ch = the rows RPB ch + rl + it (RPB chunks) of the group, it = 0, 1, ...: the workgroups of a group sweep it TOGETHER, RPB
+    // rows each per step, like the plain launch does (2048 workgroups each walking its own contiguous 128 rows measured 46 % slower)
+    row_begin = g * a.cs_rpg + ch * RPB + rl;
+    row_end = (g + 1) * a.cs_rpg;
+    row_step = chunks * RPB;
+  }
+  for (int row = row_begin; row < row_end; row += row_step) {
     float4 v[NVT];
     const float4* xp = reinterpret_cast<const float4*>(a.x + (size_t)row * a.ldx);
     const float4* yp = a.x2 ? reinterpret_cast<const float4*>(a.x2 + (a.x2_group > 0 ? (size_t)(row / a.x2_group) * a.E : (size_t)row * a.ldx))
@@ -104,6 +124,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
           if (a.split) store4_split<T>(o16 + (size_t)drow * 2 * a.E, a.E, c * 4, o.x, o.y, o.z, o.w);
           else store4<T>(o16 + (size_t)drow * a.E + c * 4, o.x, o.y, o.z, o.w);
         }
+        // (the fp32 values, not their 16-bit roundings: the mean rounding error of >= 196 tokens is far below what the correction is
+        // accurate to.  Accumulators in registers: thread-private LDS slots updated with ds_add_f32 measured 2.3x the kernel time.)
+        if (CS) { cs[i].x += o.x; cs[i].y += o.y; cs[i].z += o.z; cs[i].w += o.w; }
         if (o16pe) {
           const float4 p = pp[c];
           if (a.split) store4_split<T>(o16pe + (size_t)drow * 2 * a.E, a.E, c * 4, o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w);
@@ -112,12 +135,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
       }
     }
   }
+  if (CS) {                                           // fold the RPB row lanes of a column in index order
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) cs_red[tid * NVT + i] = cs[i];      // (tid == rl * LPR + lane)
+    __syncthreads();
+    if (rl == 0) {
+      float4* dst = reinterpret_cast<float4*>(a.cs_part + (size_t)blockIdx.x * a.E);
+#pragma unroll
+      for (int i = 0; i < NVT; ++i) {
+        const int c = lane + i * LPR;
+        if (EXACT || c < nv) {
+          float4 t = cs_red[lane * NVT + i];
+#pragma unroll 1
+          for (int j = 1; j < RPB; ++j) {         // (rolled: unrolled, its loads set the register count of the whole kernel)
+            const float4 u = cs_red[(j * LPR + lane) * NVT + i];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+          }
+          dst[c] = t;
+        }
+      }
+    }
+  }
 }
 
 template <typename T, int LPR, int NVT>
 static void launch_ln_nv(const LnArgs& a, int blocks, hipStream_t st) {
-  if ((a.E >> 2) == LPR * NVT) hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, true>), dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, false>), dim3(blocks), dim3(256), 0, st, a);
+  const bool exact = (a.E >> 2) == LPR * NVT;
+  if (a.cs_part) {
+    if (exact) hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, true, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, false, true>), dim3(blocks), dim3(256), 0, st, a);
+  } else {
+    if (exact) hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, true, false>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<T, LPR, NVT, false, false>), dim3(blocks), dim3(256), 0, st, a);
+  }
 }
 
 template <typename T>
@@ -128,6 +178,7 @@ static void launch_ln(const LnArgs& a, hipStream_t st) {
   const int rpb = 256 / lpr;
   int blocks = (a.rows + rpb - 1) / rpb;
   if (blocks > 8192) blocks = 8192;
+  if (a.cs_part) blocks = (a.rows / a.cs_rpg) * ((a.cs_rpg + CM_CHUNK - 1) / CM_CHUNK);
   if (lpr == 64) {
     const int nvt = (nv + 63) / 64;
     if (nvt == 1) launch_ln_nv<T, 64, 1>(a, blocks, st);
@@ -152,7 +203,7 @@ static void launch_ln(const LnArgs& a, hipStream_t st) {
 
 static int ln_impl(const char* name, const float* x, const float* x2, int x2_group, int ldx, int rows, int E, const float* gamma,
                    const float* beta, float eps, int gelu, float* out32, void* out16, void* out16_pe, const float* pe, int pe_mod, int window,
-                   int H, int W, int dt, void* stream) {
+                   int H, int W, int dt, void* stream, float* cs_part = nullptr, int cs_rpg = 0) {
   LA_CHECK_ARG(x && gamma && beta, "%s: null pointer", name);
   LA_CHECK_ARG(rows > 0 && E > 0 && (E % 4) == 0 && E <= 4 * 64 * la::LN_MAXV && (ldx % 4) == 0, "%s: bad shape rows=%d E=%d ldx=%d", name, rows, E,
                ldx);
@@ -161,7 +212,9 @@ static int ln_impl(const char* name, const float* x, const float* x2, int x2_gro
   LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "%s: bad window geometry", name);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32 || dt == LA_F16X2, "%s: bad dtype %d", name, dt);
   LA_CHECK_ARG(x2_group >= 0 && (x2_group == 0 || x2), "%s: x2_group needs x2", name);
-  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt == LA_F16X2 ? 1 : 0, x2_group};
+  LA_CHECK_ARG(!cs_part || (cs_rpg > 0 && rows % cs_rpg == 0 && out16 && dt != LA_F16X2), "%s: column sums need rows %% rows_per_group == 0 and a plain 16-bit output", name);
+  la::LnArgs a{x, x2, ldx, rows, E, gamma, beta, eps, gelu, out32, out16, out16_pe, pe, pe_mod, window, H, W, dt == LA_F16X2 ? 1 : 0, x2_group,
+               cs_part, cs_rpg};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dt == LA_F16 || dt == LA_F16X2) la::launch_ln<la::f16_t>(a, st);
   else if (dt == LA_BF16) la::launch_ln<la::bf16_t>(a, st);
@@ -177,9 +230,10 @@ extern "C" int la_layernorm(const float* x, const float* x2, int ldx, int rows, 
 }
 
 extern "C" int la_layernorm_g(const float* x, const float* xg, int rows_per_group, int ldx, int rows, int E, const float* gamma,
-                              const float* beta, float eps, float* out32, void* out16, int window, int H, int W, int dt, void* stream) {
+                              const float* beta, float eps, float* out32, void* out16, int window, int H, int W, float* colsum_part, int dt,
+                              void* stream) {
   return ln_impl("la_layernorm_g", x, xg, rows_per_group, ldx, rows, E, gamma, beta, eps, 0, out32, out16, nullptr, nullptr, 0, window, H, W, dt,
-                 stream);
+                 stream, colsum_part, rows_per_group);
 }
 
 // ---- token means per image of a 16-bit operand, and the in-place add of a per-image vector (LamEngine mean planes) -----------------
@@ -190,7 +244,6 @@ namespace la {
 // of the means from run to run, which the 16-bit roundings downstream turned into 1-ulp flips: 3e-4 between two runs).
 // wpart > 0: group g's rows are the H x W tokens of image g in IMAGE order while src is window-partitioned (ws = wpart,
 // LA_MAP_WINDOW_PART order, pad rows skipped).
-constexpr int CM_CHUNK = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void colmean16_kernel(const T* __restrict__ src, int ld, int rpg, int D, float* __restrict__ part, int wpart,
                                                         int H, int W) {
@@ -230,13 +283,18 @@ __global__ __launch_bounds__(256) void colmean16_kernel(const T* __restrict__ sr
   }
 }
 
-__global__ __launch_bounds__(256) void colmean16_fold_kernel(const float* __restrict__ part, int chunks, int D, float inv, float* __restrict__ out) {
-  const int g = blockIdx.x;
-  for (int c = threadIdx.x; c < D; c += 256) {
-    float s = 0.f;
-    for (int j = 0; j < chunks; ++j) s += part[((size_t)g * chunks + j) * D + c];
-    out[(size_t)g * D + c] = s * inv;
-  }
+// workgroup (column tile of 64, group): chunk lane k adds chunks k, k + 4, ... (independent loads), the four lanes of a column are then
+// added in index order - a fixed tree, whatever the launch
+__global__ __launch_bounds__(256) void colmean16_fold_kernel(const float* __restrict__ part, int chunks, int D, float inv, float* __restrict__ out,
+                                                             int ldo) {
+  __shared__ float red[4][64];
+  const int g = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), k = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < D)
+    for (int j = k; j < chunks; j += 4) s += part[((size_t)g * chunks + j) * D + c];
+  red[k][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (k == 0 && c < D) out[(size_t)g * ldo + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * inv;
 }
 
 __global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, long rows, int rpg, int D) {
@@ -263,8 +321,16 @@ extern "C" int la_colmean16(const void* src, int ld, int groups, int rows_per_gr
   const dim3 grid(groups, chunks), blk(256);
   if (dt == LA_F16) hipLaunchKernelGGL(la::colmean16_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)src, ld, rows_per_group, D, scratch, wpart, H, W);
   else hipLaunchKernelGGL(la::colmean16_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)src, ld, rows_per_group, D, scratch, wpart, H, W);
-  hipLaunchKernelGGL(la::colmean16_fold_kernel, dim3(groups), blk, 0, st, scratch, chunks, D, 1.0f / (float)rows_per_group, out);
+  hipLaunchKernelGGL(la::colmean16_fold_kernel, dim3((D + 63) / 64, groups), blk, 0, st, scratch, chunks, D, 1.0f / (float)rows_per_group, out, D);
   LA_CHECK_LAUNCH("la_colmean16");
+  return 0;
+}
+
+extern "C" int la_colsum_fold(const float* part, int groups, int chunks, int D, float inv, float* out, int ldo, void* stream) {
+  LA_CHECK_ARG(part && out && groups > 0 && chunks > 0 && D > 0 && ldo >= D, "la_colsum_fold: bad arguments");
+  hipLaunchKernelGGL(la::colmean16_fold_kernel, dim3((D + 63) / 64, groups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, chunks, D, inv, out,
+                     ldo);
+  LA_CHECK_LAUNCH("la_colsum_fold");
   return 0;
 }
 

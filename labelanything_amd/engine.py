@@ -143,6 +143,7 @@ class LamEngine:
         if not self.precise <= set(PRECISE_GROUPS):
             raise ValueError(f"unknown precise groups {sorted(self.precise - set(PRECISE_GROUPS))}; known: {PRECISE_GROUPS}")
         self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)
+        self.mean_kx: Dict[str, int] = {}   # block prefix -> columns of its '.mean.w32' that multiply mean(x) (the rest multiply mean(o))
         # the image side of the two-way transformers runs in the fused kernels (one read / one read + write of the stream per
         # attention, csrc/twoway.hip) for the published decoder geometry; LA_FUSE_TWOWAY=0 keeps the GEMM + attention + norm chain
         import os as _os
@@ -210,38 +211,47 @@ class LamEngine:
             self.kmod.pop(key, None)
 
     def _pack_mean(self, pre: str, wv: Tensor, wo: Tensor) -> None:
-        """fp32 operands of the token-mean corrections of one block: what the 16-bit plane of Wv / Wo lost, and Wo itself."""
+        """fp32 operand of the token-mean corrections of one block: rvec += [mean(x) | mean(o)] . [Wo Wv_lo | Wo_lo]^T, where *_lo is what
+        the 16-bit plane of a weight lost (c_v = mean(x) Wv_lo^T belongs on every V row of the image, softmax rows sum to one, so it
+        leaves attention unchanged and goes through proj as c_v Wo^T: one [E, E] product formed here, once)."""
+        cols = []
         if "vmean" in self.precise:
-            wv = wv.contiguous()
-            self.p[pre + ".v.lo32"] = (wv - wv.to(self.dt).float()).contiguous()               # [ea, E]
-            self.p[pre + ".o.w32"] = wo.contiguous().float()                                    # [E, ea]: c_v goes through proj exactly
+            v_lo = (wv - wv.to(self.dt).float()).double()                                       # [ea, E]
+            cols.append((wo.double() @ v_lo).float())                                            # [E, E]
         if "projmean" in self.precise:
-            wo = wo.contiguous()
-            self.p[pre + ".o.lo32"] = (wo - wo.to(self.dt).float()).contiguous()               # [E, ea]
+            cols.append((wo - wo.to(self.dt).float()).float())                                   # [E, ea]
+        if cols:
+            self.p[pre + ".mean.w32"] = torch.cat(cols, dim=1).contiguous()
+            self.mean_kx[pre] = cols[0].shape[1] if "vmean" in self.precise else 0
 
     @property
     def mean_planes(self) -> bool:
         return "vmean" in self.precise or "projmean" in self.precise
 
-    def mean_fix(self, pre: str, xin: Tensor, ao: Tensor, rvec: Tensor, bn: int, rpg: int, wpart_x: int, wpart_o: int, g: int) -> None:
-        """rvec[img] += mean(x) Wv_lo^T Wo^T + mean(o) Wo_lo^T for one attention block (see PRECISE_WIDE).  xin: the 16-bit qkv operand,
-        ao: the attention output, both [rows, *]; wpart_*: window size when that buffer is window-partitioned (rows gathered in
-        image order, pads skipped), 0 when it is in image order."""
-        p = self.p
-        if (pre + ".v.lo32") in p:
-            e = xin.shape[1]
-            xbar = self.f32("mean.xbar", (bn, e))
-            L.colmean16(xin, bn, rpg, xbar, self.f32("mean.scr", (bn * _ceil(rpg, 128) // 128 * e,)), wpart_x, g if wpart_x else 0,
-                        g if wpart_x else 0)
-            cv = self.f32("mean.cv", (bn, p[pre + ".v.lo32"].shape[0]))
-            L.gemm(xbar, p[pre + ".v.lo32"], out32=cv)
-            L.gemm(cv, p[pre + ".o.w32"], res=rvec, out32=rvec)
-        if (pre + ".o.lo32") in p:
-            ea = ao.shape[1]
+    def mean_parts(self, bn: int, rpg: int, e: int, ea: int, o_chunks: int):
+        """Scratch of one block's fused column sums: (LayerNorm partials or None, attention partials or None) - see mean_fix."""
+        xp = self.f32("mean.xpart", (bn * (_ceil(rpg, 128) // 128) * e,)) if "vmean" in self.precise else None
+        op = self.f32("mean.opart", (bn * max(o_chunks, _ceil(rpg, 128) // 128) * ea,)) if "projmean" in self.precise else None
+        return xp, op
+
+    def mean_fix(self, pre: str, xpart, opart, rvec: Tensor, bn: int, rpg: int, o_chunks: int, e: int, ea: int, ao=None, ao_win=(0, 0)) -> None:
+        """rvec[img] += mean(x) (Wo Wv_lo)^T + mean(o) Wo_lo^T for one attention block (see PRECISE_WIDE).  xpart: column sums of the
+        16-bit qkv operand per 128-row chunk, left by the LayerNorm that wrote it (la_layernorm_g); opart: column sums of the attention
+        output per 128-query block (o_chunks per image), left by la_attn_fwd_cs - or, o_chunks == 0, scratch for a separate pass over
+        ao (la_colmean16; ao_win = (ws, g) when ao is window-partitioned).  Chunks are folded in a fixed order: an image's vectors do
+        not depend on the rest of the batch."""
+        wm = self.p[pre + ".mean.w32"]
+        bar = self.f32("mean.bar", (bn, wm.shape[1]))
+        kx = self.mean_kx[pre]
+        if xpart is not None:
+            L.colsum_fold(xpart, bn, _ceil(rpg, 128) // 128, e, 1.0 / rpg, bar[:, :kx])
+        if opart is not None and o_chunks > 0:
+            L.colsum_fold(opart, bn, o_chunks, ea, 1.0 / rpg, bar[:, kx:])
+        elif opart is not None:
             obar = self.f32("mean.obar", (bn, ea))
-            L.colmean16(ao, bn, rpg, obar, self.f32("mean.scr", (bn * _ceil(rpg, 128) // 128 * ea,)), wpart_o, g if wpart_o else 0,
-                        g if wpart_o else 0)
-            L.gemm(obar, p[pre + ".o.lo32"], res=rvec, out32=rvec)
+            L.colmean16(ao, bn, rpg, obar, opart, ao_win[0], ao_win[1], ao_win[1])
+            bar[:, kx:].copy_(obar)
+        L.gemm(bar, wm, res=rvec, out32=rvec)
 
     def _hw_qkv(self, key: str, t: Tensor, bias: Tensor, ea: int) -> None:
         """Pack a fused qkv weight [3 ea, K] + bias.  Group "qkv": planes for all rows; group "v": a one-plane [2 ea, K] q/k weight and
@@ -470,7 +480,7 @@ class LamEngine:
 
     def ln(self, x, name, eps, rvec=None, rpg=0, **kw):
         """LayerNorm of x (+ the pending per-image corrections rvec[row // rpg] of the mean planes, never written back)."""
-        if rvec is not None:
+        if rvec is not None:       # (colsum_part=...: also leave the column sums of the stored rows, mean_fix)
             L.layernorm_g(x, rvec, rpg, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
         else:
             L.layernorm(x, self.w32[name + ".weight"], self.w32[name + ".bias"], eps, dt=self.dti, **kw)
@@ -552,10 +562,15 @@ class LamEngine:
         for i in range(spec.depth):
             bp = f"{pre}.blocks.{i}"
             is_global = i in spec.global_idx
+            xpart = opart = None
+            if rvec is not None:
+                o_chunks = _ceil(hw, 128) // 128 if is_global else nwy * nwy * (_ceil(ws * ws, 128) // 128)
+                xpart, opart = self.mean_parts(bn, hw, e, ea, o_chunks)
+            ckw = dict(colsum_part=xpart) if xpart is not None else {}
             if is_global:
                 nb, t, gg, arows = bn, hw, g, rows
                 xin = x16
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw, **ckw)
             else:
                 nb, t, gg = bn * nwy * nwy, ws * ws, ws
                 arows = nb * t
@@ -571,10 +586,10 @@ class LamEngine:
                 pass
             elif scatter:
                 xin = x16
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw, **ckw)
             else:
                 xin = self.buf("enc.xwin", (arows, e), zero=True)        # padded tokens stay zero
-                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g, **rkw)
+                self.ln(res, bp + ".norm1", 1e-6, out16=xin, window=ws, H=g, W=g, **rkw, **ckw)
             if scatter:
                 qb = p[bp + ".qkv.b"]
 
@@ -595,20 +610,29 @@ class LamEngine:
                 vt = self.buf("enc.vt." + tag, (nb * heads, hdp, tpad), zero=True)
                 self.qkv_gemm(xin, bp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads, vt_ws=gg if win16 else 0)
             ao = self.buf("enc.ao." + tag, (arows, ea))
+            # column sums of the attention output from the attention kernel itself where that is cheaper than a pass over the output:
+            # 260 VALU operations per wave at the end of >= 15 key tiles (global blocks: +2 %), not of a window's 4 (+30 %, measured)
+            fused_o = opart is not None and not win16 and gg > 16
+            okw = dict(cspart=opart) if fused_o else None
+
+            def attn(relh, relw, mode, **tk):
+                if okw is not None:
+                    L.attn_fwd_cs(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, mode, **okw, **tk)
+                else:
+                    L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, mode, **tk)
+
             if win16:
-                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16,
-                           tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
+                attn(None, None, L.ATTN_RELPOS_WIN16, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             elif gg <= 16 or gg == 64:      # rel-pos terms are computed inside the attention kernel
-                L.attn_fwd(qkv, vt, ao, None, None, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS,
-                           tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
+                attn(None, None, L.ATTN_RELPOS, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"])
             else:
                 relh = self.f32("enc.relh." + tag, (nb * heads, t, gg))
                 relw = self.f32("enc.relw." + tag, (nb * heads, t, gg))
                 L.relpos_terms(qkv, nb, heads, gg, ea, p[bp + ".tabh"], p[bp + ".tabw"], relh, relw)
-                L.attn_fwd(qkv, vt, ao, relh, relw, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS)
+                attn(relh, relw, L.ATTN_RELPOS)
             if rvec is not None:
-                xwin = 0 if (is_global or scatter) else ws
-                self.mean_fix(bp, xin, ao, rvec, bn, hw, xwin, 0 if is_global else ws, g)
+                self.mean_fix(bp, xpart, opart, rvec, bn, hw, o_chunks if fused_o else 0, e, ea, ao=ao,
+                              ao_win=(0, 0) if is_global else (ws, g))
             if is_global:
                 self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
             else:       # window_unpartition as a row gather on the A operand: again only the real tokens are computed
@@ -686,18 +710,26 @@ class LamEngine:
             rvec = self.f32("hf.rvec", (bn, e), zero=True)
             rvec.zero_()
         rkw = dict(rvec=rvec, rpg=t) if rvec is not None else {}
+        xpart = opart = None
+        o_chunks = _ceil(t, 128) // 128
+        if rvec is not None:
+            xpart, opart = self.mean_parts(bn, t, e, ea, o_chunks)
+        ckw = dict(colsum_part=xpart) if xpart is not None else {}
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
-            self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, **rkw)
+            self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, **rkw, **ckw)
             self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
+            fused_o = opart is not None and not (self.attn_fp8 and hdp == 64)
             if self.attn_fp8 and hdp == 64:
                 qk8 = self.arena.get("hf.qk8", (rows, 2 * ea), torch.uint8, False)
                 L.qk_fp8(qkv, ea, qk8)
                 L.attn_fwd_fp8(qk8, vt, ao, bn, heads, t, tpad, ea, scale)
+            elif fused_o:
+                L.attn_fwd_cs(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN, opart)
             else:
                 L.attn_fwd(qkv, vt, ao, None, None, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN)
             if rvec is not None:
-                self.mean_fix(lp, x16, ao, rvec, bn, t, 0, 0, g)
+                self.mean_fix(lp, xpart, opart, rvec, bn, t, o_chunks if fused_o else 0, e, ea, ao=ao)
             self.gemm_w(ao, lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
             self.ln(res, lp + ".layernorm_after", 1e-12, out16=x16, **rkw)
             self.gemm_w(x16, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=hbuf, act=L.ACT_GELU)

@@ -729,7 +729,7 @@ def test_fp8_qk_attention_matches_torch_on_e4m3_rounded_operands(L, shape):
 
 @pytest.mark.parametrize("geom", [(3, 901, 768, 0), (2, 4096, 768, 0), (51, 901, 1024, 0), (2, 28 * 28, 128, 14), (1, 64 * 64, 768, 14)])
 def test_token_mean_kernels(L, geom):
-    """la_colmean16 (image order and window-partitioned sources), la_layernorm_g, la_add_rowvec: the pieces of the token-mean
+    """la_colmean16 (image order and window-partitioned sources), la_layernorm_g (+ column sums), la_colsum_fold, la_add_rowvec: the pieces of the token-mean
     correction of single-plane weights.  The means must not depend on the number of groups in the launch (bitwise)."""
     import torch.nn.functional as F
     groups, rpg, d, ws = geom
@@ -764,3 +764,70 @@ def test_token_mean_kernels(L, geom):
     assert float((o32 - F.layer_norm(full, (d,), gamma, beta, 1e-6)).abs().max()) <= 2e-5
     L.add_rowvec(res, rv, rpg)
     assert torch.equal(res, full)
+    # the same LayerNorm leaving the column sums of the 16-bit rows it stores (image order, or window-partitioned output)
+    chunks = (rpg + 127) // 128
+    res2 = torch.randn(groups * rpg, d, generator=gen).cuda()
+    part = torch.full((groups * chunks * d,), float("nan"), device="cuda")
+    arows = groups * ((g + ws - 1) // ws * ws) ** 2 if ws else groups * rpg
+    o16 = torch.zeros(arows, d, device="cuda", dtype=torch.float16)
+    L.layernorm_g(res2, rv, rpg, gamma, beta, 1e-6, out16=o16, colsum_part=part, **(dict(window=ws, H=g, W=g) if ws else {}))
+    plain = torch.zeros_like(o16)
+    L.layernorm_g(res2, rv, rpg, gamma, beta, 1e-6, out16=plain, **(dict(window=ws, H=g, W=g) if ws else {}))
+    assert torch.equal(o16, plain)
+    bar = torch.zeros(groups, d + 8, device="cuda")
+    L.colsum_fold(part, groups, chunks, d, 1.0 / rpg, bar[:, 8:])
+    L.colmean16(o16, groups, rpg, out, scr, ws, g if ws else 0, g if ws else 0)        # the separate pass over the stored rows
+    # (the sums are those of the fp32 values before the 16-bit store: equal to the stored rows' mean up to the mean rounding error)
+    assert float((bar[:, 8:] - out).abs().max()) <= 1e-4 and float(bar[:, :8].abs().max()) == 0.0
+    if groups > 1:                                                    # a group's sums do not depend on the launch
+        part1 = torch.empty(chunks * d, device="cuda")
+        o1 = torch.zeros(arows // groups, d, device="cuda", dtype=torch.float16)
+        L.layernorm_g(res2[rpg:2 * rpg].contiguous(), rv[1:2].contiguous(), rpg, gamma, beta, 1e-6, out16=o1, colsum_part=part1,
+                      **(dict(window=ws, H=g, W=g) if ws else {}))
+        assert torch.equal(part1, part[chunks * d:2 * chunks * d])
+
+
+@pytest.mark.parametrize("shape", [("plain", 3, 901, 0), ("global", 2, 4096, 64), ("win16", 2, 196, 14), ("generic", 2, 400, 20)])
+def test_attention_column_sums(L, shape):
+    """la_attn_fwd_cs: the output equals la_attn_fwd's bit for bit, and the per-block column sums fold to the token means of the stored
+    rows (WIN16: rows of padded window slots left out)."""
+    kind, nimg, t, gg = shape
+    heads, e = 12, 768
+    gen = torch.Generator(device="cuda").manual_seed(t)
+    img_g = 64                                                                     # WIN16: 64 x 64 tokens in 5 x 5 windows of 14 x 14
+    b = nimg * 25 if kind == "win16" else nimg
+    qkv = (torch.randn(b * t, 3 * e, device="cuda", generator=gen) * 0.8).half()
+    mode = {"plain": L.ATTN_PLAIN, "global": L.ATTN_RELPOS, "win16": L.ATTN_RELPOS_WIN16, "generic": L.ATTN_RELPOS}[kind]
+    tpad = (16 * gg + 63) // 64 * 64 if kind == "win16" else (t + 63) // 64 * 64
+    vt = torch.zeros(b * heads, 64, tpad, dtype=torch.float16, device="cuda")
+    if kind == "win16":
+        vt.view(b, heads, 64, tpad)[..., :16 * gg].unflatten(-1, (gg, 16))[..., :gg] = qkv[:, 2 * e:].view(b, gg, gg, heads, 64).permute(0, 3, 4, 1, 2)
+    else:
+        L.head_transpose(qkv, 2 * e, b, heads, t, tpad, vt)
+    tab = dict(tabh=(torch.randn(2 * gg - 1, 64, device="cuda", generator=gen) * 0.3).half(),
+               tabw=(torch.randn(2 * gg - 1, 64, device="cuda", generator=gen) * 0.3).half()) if kind in ("global", "win16") else {}
+    relh = relw = None
+    if kind == "generic":
+        relh = torch.randn(b * heads, t, gg, device="cuda", generator=gen) * 0.3
+        relw = torch.randn(b * heads, t, gg, device="cuda", generator=gen) * 0.3
+    sc = 0.125
+    ref = torch.empty(b * t, e, dtype=torch.float16, device="cuda")
+    L.attn_fwd(qkv, vt, ref, relh, relw, b, heads, t, tpad, gg, e, sc, mode, **tab)
+    out = torch.empty_like(ref)
+    nq = (t + 127) // 128
+    part = torch.full((b * nq * e,), float("nan"), device="cuda")
+    L.attn_fwd_cs(qkv, vt, out, relh, relw, b, heads, t, tpad, gg, e, sc, mode, part, img_g if kind == "win16" else 0,
+                  img_g if kind == "win16" else 0, **tab)
+    assert torch.equal(out, ref)
+    if kind == "win16":
+        o = out.float().view(nimg, 5, 5, gg, gg, e)                                # (image, wy, wx, ty, tx): keep tokens inside the 64 x 64 grid
+        yy = (torch.arange(5, device="cuda")[:, None] * gg + torch.arange(gg, device="cuda")[None]) < img_g
+        keep = (yy[:, None, :, None] & yy[None, :, None, :]).float()               # [wy, wx, ty, tx]
+        want = (o * keep[None, ..., None]).sum((1, 2, 3, 4)) / (img_g * img_g)
+        bar = torch.empty(nimg, e, device="cuda")
+        L.colsum_fold(part, nimg, 25 * nq, e, 1.0 / (img_g * img_g), bar)
+    else:
+        want = out.float().view(b, t, e).mean(1)
+        bar = torch.empty(b, e, device="cuda")
+        L.colsum_fold(part, b, nq, e, 1.0 / t, bar)
+    assert float((bar - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max())), float((bar - want).abs().max())

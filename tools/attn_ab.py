@@ -27,12 +27,12 @@ heads, e = 12, 768
 sc = 1 / math.sqrt(64)
 for name, b, t, mode, gg in (("global_relpos 16x12 T4096", 16, 4096, L.ATTN_RELPOS, 64), ("plain 16x12 T4096", 16, 4096, L.ATTN_PLAIN, 0),
                              ("plain 64x12 T901", 64, 901, L.ATTN_PLAIN, 0), ("window14 400x12 T196", 400, 196, L.ATTN_RELPOS_WIN16, 14)):
-    tpad = (t + 63) // 64 * 64 if mode != L.ATTN_RELPOS_WIN16 else 16 * gg
+    tpad = (t + 63) // 64 * 64 if mode != L.ATTN_RELPOS_WIN16 else (16 * gg + 63) // 64 * 64
     qkv = (torch.randn(b * t, 3 * e, device="cuda", generator=g) * 0.8).half()
     if mode == L.ATTN_RELPOS_WIN16:
         vt = torch.zeros(b * heads, 64, tpad, dtype=torch.float16, device="cuda")
         v = qkv[:, 2 * e:].view(b, gg, gg, heads, 64).permute(0, 3, 4, 1, 2)                   # (b, heads, 64, y, x) -> 16-wide slot rows
-        vt.view(b, heads, 64, gg, 16)[..., :gg] = v
+        vt.view(b, heads, 64, tpad)[..., :16 * gg].unflatten(-1, (gg, 16))[..., :gg] = v
     else:
         vt = torch.empty(b * heads, 64, tpad, dtype=torch.float16, device="cuda")
         L.head_transpose(qkv, 2 * e, b, heads, t, tpad, vt)
