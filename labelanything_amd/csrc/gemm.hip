@@ -1352,15 +1352,31 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
       for (int g4 = 0; g4 < 4; ++g4) {
         if (row < M) {
           const int slot = ws > 0 ? tq * 16 + tw : t;
-          const bool fast = quad_ok && row + 3 < M && (ws == 0 || (ws & 3) == 0 || tw <= ws - 4);
+          // the quad's four tokens sit in consecutive slots of one V^T row: always when T % 4 == 0 (then the slot is 8-byte aligned as
+          // well); with T = 901 (HF ViT + CLS) every image but each fourth starts off the 4-token grid - same row, 2- or 4-byte pieces
+          const bool inside = row + 3 < M && t + 3 < e.vt_T && (ws == 0 || (ws & 3) == 0 || tw <= ws - 4);
+          const bool fast = inside && (quad_ok || (slot & 3) == 0);
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) {
             const float bias = tj ? bias1 : bias0;
             const float v0 = acc[i][tj][g4 * 4] + bias, v1 = acc[i][tj][g4 * 4 + 1] + bias, v2 = acc[i][tj][g4 * 4 + 2] + bias,
                         v3 = acc[i][tj][g4 * 4 + 3] + bias;
             T* rowp = vt + (size_t)b * bstride + (tj ? cb1 : cb0);
-            if (fast) store4v<T>(rowp + slot, v0, v1, v2, v3);
-            else vt_store_slow<T>(vt, (tj ? cb1 : cb0), bstride, e.vt_T, ws, row, M, v0, v1, v2, v3);
+            if (fast) {
+              store4v<T>(rowp + slot, v0, v1, v2, v3);
+            } else if (inside) {
+              T* p = rowp + slot;
+              if (slot & 1) {
+                p[0] = (T)v0;
+                store2<T>(p + 1, v1, v2);
+                p[3] = (T)v3;
+              } else {
+                store2<T>(p, v0, v1);
+                store2<T>(p + 2, v2, v3);
+              }
+            } else {
+              vt_store_slow<T>(vt, (tj ? cb1 : cb0), bstride, e.vt_T, ws, row, M, v0, v1, v2, v3);
+            }
           }
         }
         row += 8;

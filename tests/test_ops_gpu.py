@@ -112,8 +112,9 @@ def test_gemm_conv_transpose_pixel_shuffle(L, dt, cin, cout):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("T", [196, 901])
-def test_gemm_v_transposed_epilogue(L, dt, T):
-    b, heads, e = 2, 2, 128
+@pytest.mark.parametrize("geom", [(2, 2, 128), (5, 12, 768)])           # (5 images x 901 tokens: every alignment of an image start in a 4-row quad)
+def test_gemm_v_transposed_epilogue(L, dt, T, geom):
+    b, heads, e = geom
     tpad = (T + 63) // 64 * 64
     a = rnd(b * T, e, seed=18).to(dt)
     w = (rnd(3 * e, e, seed=19) / math.sqrt(e)).to(dt)
