@@ -33,6 +33,12 @@ timeout 900 python -m pytest tests/test_parity_seeds_gpu.py tests/test_encoder_t
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
 timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>&1
+# per-shape GEMM / attention time inside the model, the attention forms alone, the MFMA / VALU co-issue probe, the gradient diagnostic
+timeout 600 python bench.py --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg2.log > /dev/null
+timeout 600 python bench.py --workload cfg1 --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg1.log > /dev/null
+timeout 300 python tools/attn_ab.py > $OUT/${R}_attn_shapes.log 2>&1
+[ -x tools/probes/coissue ] && timeout 120 ./tools/probes/coissue > $OUT/${R}_coissue_probe.log 2>&1
+timeout 600 python tools/train_grad_diag.py > $OUT/${R}_train_grad_diag.log 2>&1
 # 4. parity report + per-op micro benchmarks
 timeout 900 python tools/parity_report.py > $OUT/${R}_parity.log 2>&1
 timeout 900 python tools/parity_report.py --groups > $OUT/${R}_parity_groups.log 2>&1
