@@ -1397,7 +1397,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
       }
     return;
   }
-  if ((EPI == 1 || EPI == 2) && rtab == nullptr && row0 + 128 <= M) {
+  if ((EPI == 1 || EPI == 2) && row0 + 128 <= M) {
     // 16-bit output of an interior tile, the common case.  Registers 2k, 2k + 1 of an accumulator are rows 2p, 2p + 1 of ONE column:
     // bias (+ GELU) on the pair in packed fp32, one cvt_pk, one 32-bit LDS store - no lane exchange.  Slab = [8 row pairs][64
     // columns] of such words; 16-byte unit u of a row pair sits at u ^ (u >> 3) (conflict-free reads below; on the store side the
@@ -1450,7 +1450,11 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
       od.y = __builtin_amdgcn_perm(u0.w, u0.z, 0x07060302u);
       od.z = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
       od.w = __builtin_amdgcn_perm(u1.w, u1.z, 0x07060302u);
-      if (!nostore) {
+      if (EPI == 1 && rtab != nullptr) {             // output row map: the two rows go where the wave's table says (pad rows: nowhere)
+        const unsigned d0 = rtab[c * 16 + 2 * rp], d1 = rtab[c * 16 + 2 * rp + 1];
+        if (d0 != NOROW) *reinterpret_cast<uint4*>(out + (size_t)d0 * e.ld16 + col0 + rch * 8) = ev;
+        if (d1 != NOROW) *reinterpret_cast<uint4*>(out + (size_t)d1 * e.ld16 + col0 + rch * 8) = od;
+      } else if (!nostore) {
         *reinterpret_cast<uint4*>(op) = ev;
         *reinterpret_cast<uint4*>(op + e.ld16) = od;
       }
@@ -1460,7 +1464,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
     return;
   }
   if (EPI == 1 || EPI == 2) {
-    // 16-bit output, general form (edge tiles, output row maps).
+    // 16-bit output, general form (edge tiles).
     // Slab = [16 rows][128 B], 16-B chunk c of row r at chunk slot c ^ slab_swz(r).  Lane pairs (fr, fr ^ 1) trade one
     // value per register pair over DPP: the even lane ends up with columns (c, c + 1) of row k, the odd lane with the same columns
     // of row k + 1 - one 32-bit LDS store each.

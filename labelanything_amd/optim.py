@@ -24,7 +24,9 @@ def constant_with_warmup(step: int, num_warmup_steps: int) -> float:
 
 class FlatAdamW:
     def __init__(self, params: Iterable[torch.Tensor], lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 num_warmup_steps: int = 0):
+                 num_warmup_steps: int = 0, lrs=None):
+        """lrs: optional per-tensor base learning rates (the reference's ``backbone_lr`` parameter group, models/lam.py:340-346); the
+        warm-up factor multiplies every group's rate alike, as the HF scheduler does."""
         self.params: List[torch.Tensor] = [p for p in params]
         if not self.params:
             raise ValueError("no parameters")
@@ -47,6 +49,9 @@ class FlatAdamW:
             self.grad_views.append(self.grad[off:off + k].view_as(p))
             off += k
         self.base_lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.lrs = [float(lr)] * len(self.params) if lrs is None else [float(v) for v in lrs]
+        if len(self.lrs) != len(self.params):
+            raise ValueError("lrs needs one rate per parameter tensor")
         self.num_warmup_steps = int(num_warmup_steps)
         self.keep_reduced_grad = False  # tests: keep a copy of the all-reduced, world-averaged gradient of the last step
         self.reduced_grad = None
@@ -78,26 +83,27 @@ class FlatAdamW:
         self.steps += 1
         if active is None:
             active = [True] * len(self.params)
-        # contiguous runs of active tensors that share a step count -> one launch each
+        # contiguous runs of active tensors that share a step count (and a learning rate) -> one launch each
         spans, off, cur = [], 0, None
         for i, (p, a) in enumerate(zip(self.params, active)):
             k = p.numel()
             if a:
                 self.tensor_steps[i] += 1
                 t = self.tensor_steps[i]
-                if cur is not None and cur[2] == t:
+                if cur is not None and cur[2] == t and cur[3] == self.lrs[i]:
                     cur[1] = off + k
                 else:
                     if cur is not None:
                         spans.append(tuple(cur))
-                    cur = [off, off + k, t]
+                    cur = [off, off + k, t, self.lrs[i]]
             elif cur is not None:
                 spans.append(tuple(cur))
                 cur = None
             off += k
         if cur is not None:
             spans.append(tuple(cur))
-        for a, b, t in spans:
-            L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], self.lr, self.betas[0], self.betas[1],
+        factor = constant_with_warmup(self.sched_steps, self.num_warmup_steps) if self.num_warmup_steps else 1.0
+        for a, b, t, lr in spans:
+            L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr * factor, self.betas[0], self.betas[1],
                          self.eps, self.weight_decay, t, 1.0 / world)
         self.sched_steps += 1

@@ -321,8 +321,11 @@ class LamTrainer:
     ``Lam.get_learnable_params({'freeze_backbone': True})``."""
 
     def __init__(self, lam: Lam, lr: float = 5e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
-                 num_warmup_steps: int = 0, loss: Optional[FocalLossDevice] = None, train_encoder: bool = False):
-        """train_encoder=False: ``get_learnable_params({'freeze_backbone': True})`` - the image encoder is frozen (and absent from
+                 num_warmup_steps: int = 0, loss: Optional[FocalLossDevice] = None, train_encoder: bool = False,
+                 backbone_lr: Optional[float] = None):
+        """backbone_lr: learning rate of the ``image_encoder.*`` tensors (the reference's ``backbone_lr`` parameter group,
+        models/lam.py:340-346; needs train_encoder=True - with a frozen backbone the reference raises as well).
+        train_encoder=False: ``get_learnable_params({'freeze_backbone': True})`` - the image encoder is frozen (and absent from
         the flat buffer).  train_encoder=True: every parameter trains, as with parameters/trainval/coco20i/mae_noembs.yaml (no
         ``freeze_backbone``: models/lam.py:347 returns ``self.parameters()``); needs an HF ViT encoder (train_encoder.py)."""
         if lam._device().type != "cuda":
@@ -331,6 +334,8 @@ class LamTrainer:
         self.train_encoder = bool(train_encoder)
         if self.train_encoder and lam.cfg.encoder_spec is None:
             raise ValueError("train_encoder=True needs a model with an image encoder")
+        if backbone_lr is not None and not self.train_encoder:
+            raise ValueError("Cannot freeze the backbone and set a learning rate for it at the same time.")
         if self.train_encoder:
             # the saved-activation forward of train_encoder.py runs the plain GEMM sequence: second weight planes instead of the
             # inference engine's token-mean corrections (same accuracy class)
@@ -352,8 +357,9 @@ class LamTrainer:
         self._touched = [False] * len(named)
         for i, (_, p) in enumerate(named):
             p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._touched.__setitem__(_i, True))
+        lrs = None if backbone_lr is None else [backbone_lr if "image_encoder" in k else lr for k, _ in named]
         self.opt = FlatAdamW([p for _, p in named], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
-                             num_warmup_steps=num_warmup_steps)
+                             num_warmup_steps=num_warmup_steps, lrs=lrs)
         for (_, p), gv in zip(named, self.opt.grad_views):
             p.grad = gv                      # autograd accumulates straight into the flat gradient buffer
         self.crit = loss or FocalLossDevice()

@@ -37,3 +37,27 @@ def test_flat_adamw_tracks_torch_adamw_with_warmup():
 def test_flat_adamw_rejects_cpu_parameters():
     with pytest.raises(RuntimeError, match="device parameters"):
         FlatAdamW([torch.zeros(3)])
+
+
+def test_flat_adamw_parameter_groups_like_backbone_lr():
+    """The reference's ``backbone_lr`` branch (models/lam.py:340-346): two torch parameter groups with their own rates under one
+    warm-up schedule == FlatAdamW(lrs=...)."""
+    from transformers import get_scheduler
+    g = torch.Generator().manual_seed(1)
+    shapes = [(64, 16), (16,), (300,), (7, 9)]
+    ref_params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    dev_params = [p.detach().clone().cuda() for p in ref_params]
+    ref_opt = torch.optim.AdamW([{"params": ref_params[:2], "lr": 1e-5}, {"params": ref_params[2:]}], lr=5e-5)
+    sched = get_scheduler("constant_with_warmup", optimizer=ref_opt, num_warmup_steps=2, num_training_steps=100)
+    opt = FlatAdamW(dev_params, lr=5e-5, num_warmup_steps=2, lrs=[1e-5, 1e-5, 5e-5, 5e-5])
+    for step in range(5):
+        for p, gv in zip(ref_params, opt.grad_views):
+            grad = torch.randn(p.shape, generator=g)
+            p.grad = grad.clone()
+            gv.copy_(grad)
+        ref_opt.step()
+        sched.step()
+        opt.step()
+        torch.cuda.synchronize()
+        for p, d in zip(ref_params, dev_params):
+            assert float((d.cpu() - p.detach()).abs().max()) <= 2e-7 * max(1.0, float(p.detach().abs().max())), step
