@@ -350,7 +350,7 @@ def main():
         kernels = {n: {"launches": v[0], "ms": round(v[1] * 1e3, 3)} for n, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
         if g:
             ach = g[2] / g[1] / 1e12
-            roof = {"kernel": "la_gemm (gemm_t256p_kernel on the encoder shapes; gemm_t256_kernel / gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel elsewhere)", "bound": "mfma",
+            roof = {"kernel": "la_gemm (gemm_t256q_kernel on the encoder shapes, gemm_t256p_kernel for two-plane weights; gemm_t256_kernel / gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel elsewhere)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(a.workload, (lam_fwd if train else lam).precise),
                     "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),

@@ -64,20 +64,20 @@ class Arena:
 #        logits 9.5e-4 with only Wq, Wk split = the same as with no plane at all), the V projection is linear all the way to the
 #        block output (7.0e-4 with only Wv split, 6.7e-4 with all three);
 #   "patch", "neck": fp32-class products (fp16 plane pairs on both operands where the shape allows, exact-fp32 MFMA otherwise).
-# Which planes are worth their MFMA passes was measured on the golden cases (profiles/r02_parity_groups.log) AND over other weight /
-# episode seeds (tests/test_parity_seeds_gpu.py, profiles/r02_parity_seeds.log: the max-norm error moves by +-15 % with the seed; worst
-# stage, tolerance 1e-3).  The 768+-wide encoders of the BASELINE configs keep patch / v / proj / neck: 6.6-8.0e-4 over the seeds
-# tried (without proj 7.0-9.4e-4 - inside the tolerance on every seed tried, but with 6 % to spare, for 3 % of the step; lin2's
-# plane would buy another ~1e-4 for 8 %); encoders narrower than 512 keep the full qkv, proj and lin2 planes (cheap there, and
-# their share of the error is larger: sam_tiny 8.3e-4 -> 6.0e-4).
+# Which groups are worth their cost was measured on the golden cases (profiles/r03_parity_groups.log) AND over other weight / episode
+# seeds (tests/test_parity_seeds_gpu.py, profiles/r03_parity_seeds.log: the max-norm error moves by +-15 % with the seed; worst stage,
+# tolerance 1e-3).  The 768+-wide encoders of the BASELINE configs keep patch / V / proj / neck - as second planes in round 2
+# (6.6-8.0e-4 over the seeds tried; without proj 7.0-9.4e-4), as token-mean corrections since round 3 (5.6-8.0e-4); lin2's plane would
+# buy another ~1e-4 for 8 % of the step.  Encoders narrower than 512 keep the full qkv, proj and lin2 planes (cheap there, and their
+# share of the error is larger: sam_tiny 1.02e-3 -> 7.4e-4).
 #   "vmean", "projmean": TOKEN-MEAN correction instead of a second plane (round 3).  With one plane token i errs by a_i . W_lo^T; what
 #        survives attention and pooling is the part every token of an image shares, mean_i(a_i) . W_lo^T - a per-image vector.  It is
-#        formed in fp32 from the column means of the 16-bit A operand (la_colmean16 + a few-row exact-fp32 la_gemm against the fp32
-#        residual W - W_hi) and carried as a pending per-image correction R of the residual stream that every LayerNorm adds on the fly
-#        (la_layernorm_g).  V: softmax rows sum to one, so the vector c_v = mean(x) Wv_lo^T that belongs on every V row of the image
-#        comes out of attention unchanged and goes through proj as c_v Wo^T (exact fp32); proj adds mean(o) Wo_lo^T.  Emulated
-#        (tools/error_budget.py --mean): cfg1 low-res logits 6.4e-4 (two planes 6.0e-4, one plane 9.5e-4), cfg2 6.5e-4 (two planes
-#        7.5e-4) - the second MFMA pass of V and proj (8.7 ms of the 100 ms cfg2 step) for two column means and three few-row GEMMs.
+#        formed in fp32 from the token means of the GEMM operands (left behind by the LayerNorm / attention kernels that write them,
+#        mean_fix) and ONE few-row exact-fp32 la_gemm per block against [Wo Wv_lo | Wo_lo], and carried as a pending per-image correction
+#        R of the residual stream that every LayerNorm adds on the fly (la_layernorm_g).  V: softmax rows sum to one, so the vector
+#        c_v = mean(x) Wv_lo^T that belongs on every V row of the image comes out of attention unchanged and goes through proj as
+#        c_v Wo^T; proj adds mean(o) Wo_lo^T.  Emulated (tools/error_budget.py --mean) and measured: the same error as
+#        the second planes for 3.5 ms instead of 8.7 ms of the cfg2 step.
 PRECISE_FULL = ("patch", "qkv", "proj", "lin2", "neck")
 PRECISE_WIDE = ("patch", "vmean", "projmean", "neck")
 PRECISE_WIDE_PLANES = ("patch", "v", "proj", "neck")          # round 2's default: second weight planes for V and proj
