@@ -330,8 +330,9 @@ int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const vo
 int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float scale, void* stream);
 
 /* dst[c][r] = src[r][c] (fp32 or 16-bit [R, ld] -> 16-bit [C, Rp], zero for R <= r < Rp, Rp % 64 == 0): the token-contiguous operands of
- * a split-K weight-gradient la_gemm (LaGemmEpilogue.ksplit). */
-int la_transpose16(const void* src, int src_dt, int ld, int R, int C, void* dst, int dst_dt, int Rp, void* stream);
+ * a split-K weight-gradient la_gemm (LaGemmEpilogue.ksplit).  colsum != NULL (fp32 [C]): colsum[c] += sum_r dst[c][r] (atomics) - the
+ * bias gradient db = colsum(dY) of an nn.Linear from the same pass over dY that prepares its weight gradient. */
+int la_transpose16(const void* src, int src_dt, int ld, int R, int C, void* dst, int dst_dt, int Rp, float* colsum, void* stream);
 
 /* y += a * x, n contiguous fp32 elements (loss-scaled encoder gradients folded into the flat gradient buffer). */
 int la_axpy(const float* x, float* y, long n, float a, void* stream);

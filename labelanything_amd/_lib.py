@@ -459,14 +459,18 @@ def axpy(x, y, a: float) -> None:
     _check(lib().la_axpy(_ptr(x), _ptr(y), C.c_long(x.numel()), C.c_float(a), _stream()), "la_axpy")
 
 
-def transpose16(src, dst) -> None:
-    """dst[c, r] = src[r, c]; src fp32 / 16-bit [R, C] (row stride src.stride(0)), dst 16-bit [C, Rp] with Rp >= R, Rp % 64 == 0 (zero padded)."""
+def transpose16(src, dst, colsum=None) -> None:
+    """dst[c, r] = src[r, c]; src fp32 / 16-bit [R, C] (row stride src.stride(0)), dst 16-bit [C, Rp] with Rp >= R, Rp % 64 == 0 (zero padded).
+    colsum: optional fp32 [C] that receives += the column sums of the (16-bit) values written - the bias gradient of the layer whose
+    output gradient is being transposed."""
     _dev(src)
     r, c = src.shape
     if src.stride(1) != 1 or not dst.is_contiguous() or dst.shape[0] != c:
         raise ValueError("transpose16: src needs unit column stride, dst contiguous [C, Rp]")
+    if colsum is not None and (colsum.dtype != torch.float32 or colsum.numel() != c or not colsum.is_contiguous()):
+        raise ValueError("transpose16: colsum must be contiguous fp32 [C]")
     _check(lib().la_transpose16(_ptr(src), C.c_int(dt_of(src)), C.c_int(src.stride(0)), C.c_int(r), C.c_int(c), _ptr(dst), C.c_int(dt_of(dst)),
-                                C.c_int(dst.shape[1]), _stream()), "la_transpose16")
+                                C.c_int(dst.shape[1]), _ptr(colsum), _stream()), "la_transpose16")
 
 
 # ---- fp8 QK^T attention (opt-in) --------------------------------------------------------------------------

@@ -616,46 +616,74 @@ __global__ __launch_bounds__(256) void gelu_bwd16_kernel(const T* __restrict__ p
 // dst[c][r] = (T)src[r][c] for r < R, 0 for R <= r < Rp: the token-contiguous 16-bit operands of a split-K weight-gradient GEMM
 // (la_gemm ksplit: dW[N, K] = dY^T X runs as A = dY^T [N, Rp], W = X^T [K, Rp]).  64 x 64 tiles through LDS.
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void transpose16_kernel(const TS* __restrict__ src, int ld, int R, int Cn, TD* __restrict__ dst, int Rp) {
+__global__ __launch_bounds__(256) void transpose16_kernel(const TS* __restrict__ src, int ld, int R, int Cn, TD* __restrict__ dst, int Rp,
+                                                          float* __restrict__ colsum, int rtiles) {
   // 64 x 64 tile as 32-bit words of two adjacent COLUMNS: tile[r][c / 2].  Output row c needs (r, c), (r + 1, c), ...: two words
   // of rows r, r + 1 give the pairs of columns c and c + 1 with one v_perm each - half the LDS instructions of a 16-bit tile.
+  // A workgroup walks `rtiles` row tiles of its column tile (column sums: one atomic per column and workgroup, not per tile - 732
+  // row tiles adding to the same 3072 addresses serialise in L2).
   __shared__ unsigned tile[64][32 + 1];
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int c0 = blockIdx.y * 64;
   const int tid = threadIdx.x;
-  {
-    const int r = tid >> 2, cb = (tid & 3) * 16;
-    const int rr = r0 + r;
-    TD v[16];
-    if (rr < R && c0 + cb + 15 < Cn && (ld % 8) == 0 && sizeof(TS) == 2) {
-      const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb);
-      const uint4 b2 = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb + 8);
-      *reinterpret_cast<uint4*>(&v[0]) = a;
-      *reinterpret_cast<uint4*>(&v[8]) = b2;
-    } else {
+  float sa = 0.f, sb = 0.f;
+  for (int rt = 0; rt < rtiles; ++rt) {
+    const int r0 = (blockIdx.x * rtiles + rt) * 64;
+    if (r0 >= Rp) break;
+    {
+      const int r = tid >> 2, cb = (tid & 3) * 16;
+      const int rr = r0 + r;
+      TD v[16];
+      if (rr < R && c0 + cb + 15 < Cn && (ld % 8) == 0 && sizeof(TS) == 2) {
+        const uint4 a = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb);
+        const uint4 b2 = *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + c0 + cb + 8);
+        *reinterpret_cast<uint4*>(&v[0]) = a;
+        *reinterpret_cast<uint4*>(&v[8]) = b2;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int cc = c0 + cb + i;
-        v[i] = (rr < R && cc < Cn) ? (TD)(float)src[(size_t)rr * ld + cc] : (TD)0.f;
+        for (int i = 0; i < 16; ++i) {
+          const int cc = c0 + cb + i;
+          v[i] = (rr < R && cc < Cn) ? (TD)(float)src[(size_t)rr * ld + cc] : (TD)0.f;
+        }
+      }
+      const unsigned* w = reinterpret_cast<const unsigned*>(v);
+      if (rt > 0) __syncthreads();                   // the previous tile has been read out
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tile[r][cb / 2 + i] = w[i];
+    }
+    __syncthreads();
+    {
+      // thread -> column pair cp (0..31) and 8 consecutive row pairs: writes 16 rows x 2 columns
+      const int cp = tid >> 3, rb = (tid & 7) * 8;
+      unsigned lo[4], hi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned a = tile[rb + 2 * i][cp], b2 = tile[rb + 2 * i + 1][cp];
+        lo[i] = __builtin_amdgcn_perm(b2, a, 0x05040100);     // (row, c) | (row + 1, c) << 16
+        hi[i] = __builtin_amdgcn_perm(b2, a, 0x07060302);     // (row, c + 1) | (row + 1, c + 1) << 16
+      }
+      const int c = c0 + 2 * cp;
+      if (c < Cn) *reinterpret_cast<uint4*>(dst + (size_t)c * Rp + r0 + rb) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      if (c + 1 < Cn) *reinterpret_cast<uint4*>(dst + (size_t)(c + 1) * Rp + r0 + rb) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      if (colsum != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          sa += (float)from_bits16<TD>((uint16_t)(lo[i] & 0xffffu)) + (float)from_bits16<TD>((uint16_t)(lo[i] >> 16));
+          sb += (float)from_bits16<TD>((uint16_t)(hi[i] & 0xffffu)) + (float)from_bits16<TD>((uint16_t)(hi[i] >> 16));
+        }
       }
     }
-    const unsigned* w = reinterpret_cast<const unsigned*>(v);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tile[r][cb / 2 + i] = w[i];
   }
-  __syncthreads();
-  {
-    // thread -> column pair cp (0..31) and 8 consecutive row pairs: writes 16 rows x 2 columns
-    const int cp = tid >> 3, rb = (tid & 7) * 8;
-    unsigned lo[4], hi[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned a = tile[rb + 2 * i][cp], b2 = tile[rb + 2 * i + 1][cp];
-      lo[i] = __builtin_amdgcn_perm(b2, a, 0x05040100);     // (row, c) | (row + 1, c) << 16
-      hi[i] = __builtin_amdgcn_perm(b2, a, 0x07060302);     // (row, c + 1) | (row + 1, c + 1) << 16
+  if (colsum != nullptr) {
+    // colsum[c] += the column sums of what this workgroup wrote (the bias gradient of the layer whose output gradient is being
+    // transposed for its weight gradient: one pass over dY instead of two): the 8 threads of a column pair folded with DPP
+    sa += dpp_mov<0xB1>(sa); sb += dpp_mov<0xB1>(sb);        // lanes ^ 1
+    sa += dpp_mov<0x4E>(sa); sb += dpp_mov<0x4E>(sb);        // lanes ^ 2
+    sa += dpp_mov<0x141>(sa); sb += dpp_mov<0x141>(sb);      // row_half_mirror: lane i <-> 7 - i of its 8-lane group = the other quad
+    const int c = c0 + 2 * (tid >> 3);
+    if ((tid & 7) == 0) {
+      if (c < Cn) atomicAdd(colsum + c, sa);
+      if (c + 1 < Cn) atomicAdd(colsum + c + 1, sb);
     }
-    const int c = c0 + 2 * cp;
-    if (c < Cn) *reinterpret_cast<uint4*>(dst + (size_t)c * Rp + r0 + rb) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    if (c + 1 < Cn) *reinterpret_cast<uint4*>(dst + (size_t)(c + 1) * Rp + r0 + rb) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
   }
 }
 
@@ -880,13 +908,14 @@ extern "C" int la_axpy(const float* x, float* y, long n, float a, void* stream) 
   return 0;
 }
 
-extern "C" int la_transpose16(const void* src, int src_dt, int ld, int R, int Cn, void* dst, int dst_dt, int Rp, void* stream) {
+extern "C" int la_transpose16(const void* src, int src_dt, int ld, int R, int Cn, void* dst, int dst_dt, int Rp, float* colsum, void* stream) {
   LA_CHECK_ARG(src && dst && R > 0 && Cn > 0 && ld >= Cn && Rp >= R && (Rp % 64) == 0, "la_transpose16: bad arguments (R=%d C=%d ld=%d Rp=%d)", R, Cn,
                ld, Rp);
   LA_CHECK_ARG(dst_dt == LA_F16 || dst_dt == LA_BF16, "la_transpose16: 16-bit destination expected");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid(Rp / 64, (Cn + 63) / 64), blk(256);
-#define LA_TR(TS, TD) hipLaunchKernelGGL((la::transpose16_kernel<TS, TD>), grid, blk, 0, st, (const TS*)src, ld, R, Cn, (TD*)dst, Rp)
+  const int rtiles = colsum ? 8 : 1;
+  const dim3 grid((Rp / 64 + rtiles - 1) / rtiles, (Cn + 63) / 64), blk(256);
+#define LA_TR(TS, TD) hipLaunchKernelGGL((la::transpose16_kernel<TS, TD>), grid, blk, 0, st, (const TS*)src, ld, R, Cn, (TD*)dst, Rp, colsum, rtiles)
   if (src_dt == LA_F32 && dst_dt == LA_F16) LA_TR(float, la::f16_t);
   else if (src_dt == LA_F32 && dst_dt == LA_BF16) LA_TR(float, la::bf16_t);
   else if (src_dt == LA_F16 && dst_dt == LA_F16) LA_TR(la::f16_t, la::f16_t);

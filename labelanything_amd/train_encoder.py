@@ -23,7 +23,7 @@ relative positions) has no backward here; its trainings in the reference freeze 
 from __future__ import annotations
 
 import math
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -65,6 +65,7 @@ class HfEncoderGraph:
         self.last_scale = 1.0
         self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
         self._tbufs: Dict[tuple, Tensor] = {}
+        self._xt_key = None                   # which activation the transposed-operand scratch of _wgrad currently holds
         self._b_ready: Dict[tuple, bool] = {}
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
@@ -138,9 +139,10 @@ class HfEncoderGraph:
         L.nchw_to_nhwc(wt.detach().contiguous(), 1, n, k, out16=out, dt=L._DT[dt])
         return out
 
-    def _wgrad(self, dy16, dy32, x, dw: Tensor) -> None:
+    def _wgrad(self, dy16, dy32, x, dw: Tensor, db: Optional[Tensor] = None) -> bool:
         """dw[N, K] += dy[R, N]^T x[R, K].  dy16 / dy32: the same gradient in 16 bit and fp32 (either may be None; column slices
-        allowed); x: fp32 or 16-bit."""
+        allowed); x: fp32 or 16-bit.  db: the layer's bias gradient [N]; returns True when db += colsum(dy) was done on the way (the
+        transpose of dy for the split-K product reads every element anyway)."""
         dy = dy16 if dy16 is not None else dy32
         r, n = dy.shape
         k = x.shape[1]
@@ -149,9 +151,14 @@ class HfEncoderGraph:
             dt = self.ctx["dt"]
             dyt = self._tbuf("dyt", n, rp, dt)
             xt = self._tbuf("xt", k, rp, dt)
-            L.transpose16(dy, dyt)
-            L.transpose16(x, xt)
+            fused = db is not None and db.is_contiguous()
+            L.transpose16(dy, dyt, colsum=db if fused else None)
+            xkey = (x.data_ptr(), tuple(x.shape), x.dtype)
+            if self._xt_key != xkey:                 # q, k and v share their input: one transposed copy serves the three products
+                L.transpose16(x, xt)
+                self._xt_key = xkey
             L.gemm(dyt, xt, out32=dw.view(n, k), ksplit=1)
+            return fused
         else:
             x32 = x
             if x.dtype != torch.float32:
@@ -161,6 +168,7 @@ class HfEncoderGraph:
                 dy32 = self._tbuf("dy32", r, n, torch.float32)
                 L.cast(dy16.contiguous(), dy32)
             L.gemm_tn(dy32, x32, dw.view(n, k))
+            return False
 
     def _tbuf(self, name: str, a: int, b: int, dtype) -> Tensor:
         key = (name, a, b, dtype)
@@ -173,8 +181,8 @@ class HfEncoderGraph:
     def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x, wname: str, bname: str, dx32=None, dx16=None) -> None:
         """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K]); x: the layer's input, any dtype."""
         wt = self.w[wname]
-        self._wgrad(dy16, dy32, x, self.sviews[wname])
-        L.colsum_acc(dy32, self.sviews[bname])
+        if not self._wgrad(dy16, dy32, x, self.sviews[wname], db=self.sviews[bname]):
+            L.colsum_acc(dy32, self.sviews[bname])
         L.gemm(dy16, self._wt16(wt, dy16.dtype), out32=dx32, out16=dx16)
 
     @torch.no_grad()
@@ -206,6 +214,7 @@ class HfEncoderGraph:
         c = self.ctx
         if c is None:
             raise RuntimeError("HfEncoderGraph.backward without a forward")
+        self._xt_key = None
         spec, w, sv = self.spec, self.w, self.sviews
         pre = "image_encoder"
         bn, t, hw, rows, tpad, e, heads, dt = c["bn"], c["t"], c["hw"], c["rows"], c["tpad"], c["e"], c["heads"], c["dt"]
@@ -246,11 +255,14 @@ class HfEncoderGraph:
             L.head_transpose(a["qkv"], 0, bn, heads, t, tpad, qt)
             L.head_transpose(dao, 0, bn, heads, t, tpad, dot)
             L.attn_bwd(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
-            L.cast(dqkv16, dqkv32)
             att = lp + ".attention.attention."
+            have32 = False
             for j, nm in enumerate(("query", "key", "value")):
-                self._wgrad(dqkv16[:, j * e:(j + 1) * e], dqkv32[:, j * e:(j + 1) * e], a["xn"], sv[att + nm + ".weight"])
-                L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
+                if not self._wgrad(dqkv16[:, j * e:(j + 1) * e], None, a["xn"], sv[att + nm + ".weight"], db=sv[att + nm + ".bias"]):
+                    if not have32:                    # (exact-fp32 fallback of the weight gradient: it needs the fp32 copy)
+                        L.cast(dqkv16, dqkv32)
+                        have32 = True
+                    L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
             wqkv = torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]])       # [3E, E]
             L.gemm(dqkv16, self._wt16(wqkv, dt), out32=dxn)
             L.layernorm_bwd(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, False, dx,

@@ -222,9 +222,13 @@ def test_split_k_weight_gradient_gemm_matches_torch(shape):
     rp = (r + 63) // 64 * 64
     dyt = torch.empty(n, rp, dtype=torch.float16, device="cuda")
     xt = torch.empty(k, rp, dtype=torch.float16, device="cuda")
-    L.transpose16(dy, dyt)
+    db0 = torch.randn(n, generator=g).cuda()
+    db = db0.clone()
+    L.transpose16(dy, dyt, colsum=db)                 # the bias gradient db += colsum(dY) from the same pass
     L.transpose16(x, xt)
     assert torch.equal(dyt[:, :r], dy.half().t()) and torch.equal(xt[:, :r], x.t())
+    want = db0.double() + dy.half().double().sum(0)
+    assert float((db.double() - want).abs().max()) <= 2e-5 * float(dy.half().double().abs().sum(0).max()), "fused column sums"
     assert rp == r or (float(dyt[:, r:].abs().max()) == 0.0 and float(xt[:, r:].abs().max()) == 0.0)
     dw0 = torch.randn(n, k, generator=g).cuda()
     dw = dw0.clone()

@@ -279,7 +279,7 @@ def test_bias_gradient_colsum_matches_torch(mn):
 
 
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("rows_e", [(70000, 4), (70000, 16), (66000, 32), (5000, 16), (3000, 64), (2000, 256), (901, 768), (300, 1280)])
+@pytest.mark.parametrize("rows_e", [(70000, 4), (70000, 16), (66000, 32), (5000, 16), (3000, 64), (2000, 256), (700, 512), (901, 768), (500, 1024), (300, 1280)])
 def test_layernorm_backward_matches_torch_autograd(rows_e, gelu):
     """la_layernorm_bwd on every dispatch branch: one thread per row for the 4 / 16 / 32-channel LayerNorm2d stacks over >= 65536
     pixels (mask_downscaling, output_upscaling), a wave per row otherwise (decoder 256, encoder 768 / 1280)."""
