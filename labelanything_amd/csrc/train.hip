@@ -919,7 +919,7 @@ extern "C" int la_transpose16(const void* src, int src_dt, int ld, int R, int Cn
                ld, Rp);
   LA_CHECK_ARG(dst_dt == LA_F16 || dst_dt == LA_BF16, "la_transpose16: 16-bit destination expected");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int rtiles = colsum ? 8 : 1;
+  const int rtiles = 8;                             // (also without column sums: 8 tiles per workgroup measured faster than one)
   const dim3 grid((Rp / 64 + rtiles - 1) / rtiles, (Cn + 63) / 64), blk(256);
 #define LA_TR(TS, TD) hipLaunchKernelGGL((la::transpose16_kernel<TS, TD>), grid, blk, 0, st, (const TS*)src, ld, R, Cn, (TD*)dst, Rp, colsum, rtiles)
   if (src_dt == LA_F32 && dst_dt == LA_F16) LA_TR(float, la::f16_t);

@@ -66,6 +66,7 @@ class HfEncoderGraph:
         self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
         self._tbufs: Dict[tuple, Tensor] = {}
         self._xt_key = None                   # which activation the transposed-operand scratch of _wgrad currently holds
+        self._runs = None
         self._b_ready: Dict[tuple, bool] = {}
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
@@ -182,6 +183,9 @@ class HfEncoderGraph:
         """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K]); x: the layer's input, any dtype."""
         wt = self.w[wname]
         if not self._wgrad(dy16, dy32, x, self.sviews[wname], db=self.sviews[bname]):
+            if dy32 is None:
+                dy32 = self._tbuf("dy32b", dy16.shape[0], dy16.shape[1], torch.float32)
+                L.cast(dy16.contiguous(), dy32)
             L.colsum_acc(dy32, self.sviews[bname])
         L.gemm(dy16, self._wt16(wt, dy16.dtype), out32=dx32, out16=dx16)
 
@@ -203,12 +207,25 @@ class HfEncoderGraph:
         else:
             raise FloatingPointError("encoder backward overflowed at every loss scale tried")
         self.last_scale = scale
-        off = 0
-        for k, gslot in self.grads.items():
-            m = gslot.numel()
-            L.axpy(self.scratch[off:off + m], gslot.view(-1), 1.0 / scale)
-            off += m
+        for off, m, dst in self._unscale_runs():
+            L.axpy(self.scratch[off:off + m], dst, 1.0 / scale)
         self.ctx = None
+
+    def _unscale_runs(self):
+        """(scratch offset, length, destination view) per run of gradient slots that are adjacent in memory, in scratch order - the
+        optimizer's flat buffer keeps the encoder tensors together, so the un-scaling is one launch, not one per tensor."""
+        if self._runs is None:
+            runs, off = [], 0
+            for gslot in self.grads.values():
+                m, flat = gslot.numel(), gslot.view(-1)
+                if runs and flat.data_ptr() == runs[-1][2].data_ptr() + 4 * runs[-1][1] and flat.untyped_storage().data_ptr() == \
+                        runs[-1][2].untyped_storage().data_ptr():
+                    runs[-1][1] += m
+                else:
+                    runs.append([off, m, flat])
+                off += m
+            self._runs = [(o, m, torch.as_strided(f, (m,), (1,))) for o, m, f in runs]
+        return self._runs
 
     def _backward_scaled(self, d_out: Tensor, s: float) -> None:
         c = self.ctx
@@ -244,8 +261,11 @@ class HfEncoderGraph:
             # ---- MLP: res = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------------------------------------
             L.cast(dres, d16)
             self._linear_bwd(dres, d16, a["post"], lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
-            L.gelu_bwd16(a["pre"], dh, dpre32, dpre16)
-            self._linear_bwd(dpre32, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias", dx32=dxn)
+            # (the fp32 copy of d pre-activation only feeds the exact-fp32 fallbacks of the weight / bias gradient)
+            need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
+            L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
+            self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias",
+                             dx32=dxn)
             L.layernorm_bwd(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, False, dx,
                             sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
             L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])

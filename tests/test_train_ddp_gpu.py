@@ -97,7 +97,9 @@ def test_two_rank_trainer_keeps_replicas_identical_with_rank_local_prompt_types(
     assert tr.opt.tensor_steps == r0["steps"]
     assert torch.equal(r0["grad0"], r1["grad0"])
     gs = float(g_single.abs().max())
-    assert float((g_single - r0["grad0"]).abs().max()) <= 2e-6 * gs, float((g_single - r0["grad0"]).abs().max()) / gs
+    # (the same fp32 sums in a different grouping: two half-batches added by the all-reduce vs one batch through the atomics of the
+    # weight / LayerNorm gradient kernels - measured 1.6 - 2.1e-6 of the largest entry)
+    assert float((g_single - r0["grad0"]).abs().max()) <= 5e-6 * gs, float((g_single - r0["grad0"]).abs().max()) / gs
     # parameters after two AdamW steps: lr * m / (sqrt(v) + eps) turns a rounding-level difference of a near-zero gradient entry into
     # a difference of up to ~lr per step; every entry stays within that, and all but a sliver agree to rounding
     diff = (single - r0["flat"]).abs()
