@@ -124,8 +124,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   dma(0, 0);
   dma_wait<0>();
   __syncthreads();
+  // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
+  const bool idle_wave = qblk * 128 + wave * 32 >= T_;
   for (int j = 0; j < ntiles; ++j) {
     if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+    if (idle_wave) {
+      dma_wait<0>();
+      __syncthreads();
+      continue;
+    }
     const char* sk = smem + (j & 1) * STAGE;
     const char* sv = sk + TILE_B;
     const char* skt = sk + 2 * TILE_B;
@@ -230,8 +237,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   dma(0, 0);
   dma_wait<0>();
   __syncthreads();
+  const bool idle_wave = kblk * 128 + wave * 32 >= T_;       // (as in the dQ kernel: key rows beyond T)
   for (int i = 0; i < ntiles; ++i) {
     if (i + 1 < ntiles) dma(i + 1, (i + 1) & 1);
+    if (idle_wave) {
+      dma_wait<0>();
+      __syncthreads();
+      continue;
+    }
     const char* sq = smem + (i & 1) * STAGE;
     const char* sdo = sq + TILE_B;
     const char* sqt = sq + 2 * TILE_B;
