@@ -14,6 +14,8 @@ the reference too, which therefore needs ``find_unused_parameters``) keep the ze
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Any, Dict, Optional, Tuple
 
@@ -337,10 +339,10 @@ class LamTrainer:
         if backbone_lr is not None and not self.train_encoder:
             raise ValueError("Cannot freeze the backbone and set a learning rate for it at the same time.")
         if self.train_encoder:
-            # the saved-activation forward of train_encoder.py runs the plain GEMM sequence: second weight planes instead of the
-            # inference engine's token-mean corrections (same accuracy class)
-            swap = {"vmean": "v", "projmean": "proj"}
-            lam.precise = tuple(dict.fromkeys(swap.get(gname, gname) for gname in lam.precise))
+            # the saved-activation forward of train_encoder.py runs the plain GEMM sequence, without the inference engine's
+            # token-mean corrections of V / proj: what those recover (logits 9.5e-4 -> 6e-4) is far below the 16-bit backward's own
+            # error (1e-3 ... 1e-2 on the gradients), and second weight planes in their place cost 2.5 ms of the step
+            lam.precise = tuple(gname for gname in lam.precise if gname not in ("vmean", "projmean"))
             lam.invalidate()
         named = [(k, p) for k, p in lam.named_parameters() if self.train_encoder or "image_encoder" not in k]
         # tensors the forward never reaches (dead in the reference too, prompt_encoder.py:683) go to the tail of the flat buffer so
