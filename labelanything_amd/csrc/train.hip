@@ -10,6 +10,7 @@
 //   la_row_broadcast    backward of the mean over the hw axis
 // Reference: the autograd graph of label_anything/models/{common,transformer,prompt_encoder,mask_decoder,lam}.py under
 // experiment/utils.py:266-303 (WrapperModule) + loss/__init__.py:67-89.
+#include <cstdlib>
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
@@ -721,8 +722,10 @@ extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, flo
     return 0;
   }
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
-  // M-chunks: every chunk ends in one atomic per output element: ~1024 workgroups, at least 128 rows each (multiple of 16)
-  int chunks = 1024 / (tiles_n * tiles_k);
+  // M-chunks: every chunk ends in one atomic per output element: ~2048 workgroups (256 / 512 / 1024 / 2048 measured 10.4 / 7.2 / 7.2 /
+  // 6.9 ms over the decoder's 85 launches: the row loads are latency-bound), at least 128 rows each (multiple of 16)
+  static const char* wgenv = getenv("LA_TN_WGS");       // debugging: target number of workgroups
+  int chunks = (wgenv ? atoi(wgenv) : 2048) / (tiles_n * tiles_k);
   if (chunks < 1) chunks = 1;
   int mchunk = (M + chunks - 1) / chunks;
   if (mchunk < 128) mchunk = 128;
