@@ -363,7 +363,7 @@ int la_colmean16(const void* src, int ld, int groups, int rows_per_group, int D,
 
 /* la_layernorm of x[r] + xg[r / rows_per_group] (xg fp32 [rows / rows_per_group, E]): the pending per-image corrections enter every
  * consumer of the residual stream without being written back.  colsum_part != NULL (fp32 [rows / rows_per_group * ceil(rows_per_group
- * / 128), E]): the pass also leaves the column sums of the 16-bit rows it stored, per 128-row chunk of a group - the token means of
+ * / 32), E]): the pass also leaves the column sums of the rows it stored, per fixed 1 / ceil(rows_per_group / 32) share of a group - the token means of
  * the next GEMM's operand without a second pass over it (la_colsum_fold turns the chunks into means). */
 int la_layernorm_g(const float* x, const float* xg, int rows_per_group, int ldx, int rows, int E, const float* gamma, const float* beta,
                    float eps, float* out32, void* out16, int window, int H, int W, float* colsum_part, int dt, void* stream);

@@ -497,14 +497,21 @@ def colmean16(src, groups: int, rows_per_group: int, out, scratch, wpart: int = 
                               _ptr(scratch), C.c_int(wpart), C.c_int(h), C.c_int(w), C.c_int(dt_of(src)), _stream()), "la_colmean16")
 
 
+LN_CS_ROWS = 32        # rows per column-sum partial of la_layernorm_g (norm.hip)
+
+
+def ln_cs_chunks(rows_per_group: int) -> int:
+    return (rows_per_group + LN_CS_ROWS - 1) // LN_CS_ROWS
+
+
 def layernorm_g(x, xg, rows_per_group: int, gamma, beta, eps: float, *, out32=None, out16=None, window=0, H=0, W=0, colsum_part=None,
                 dt=LA_F16) -> None:
-    """colsum_part: fp32, >= (rows / rows_per_group) * ceil(rows_per_group / 128) * E elements (column sums of the stored 16-bit rows per
-    128-row chunk of a group; colsum_fold makes the means)."""
+    """colsum_part: fp32, >= (rows / rows_per_group) * ln_cs_chunks(rows_per_group) * E elements (column sums of the stored rows per
+    fixed share of a group; colsum_fold makes the means)."""
     _dev(x)
     rows, e = x.shape
     if colsum_part is not None:
-        need = rows // rows_per_group * ((rows_per_group + 127) // 128) * e
+        need = rows // rows_per_group * ln_cs_chunks(rows_per_group) * e
         if colsum_part.dtype != torch.float32 or colsum_part.numel() < need:
             raise ValueError(f"layernorm_g colsum_part needs {need} fp32 elements")
     _check(lib().la_layernorm_g(_ptr(x), _ptr(xg), C.c_int(rows_per_group), C.c_int(x.stride(0)), C.c_int(rows), C.c_int(e), _ptr(gamma),

@@ -1313,7 +1313,10 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
       for (int g4 = 0; g4 < 4; ++g4) {
         const int rb = i * 32 + 8 * g4 + 4 * fh;
         const unsigned p0 = rtab[rb], p1 = rtab[rb + 1], p2 = rtab[rb + 2], p3 = rtab[rb + 3];
-        const bool fast = p0 != NOROW && p3 == p0 + 3 && (p0 & 3) == 0 && (e.vt_Tpad & 3) == 0;   // 4 tokens in consecutive, 8-byte aligned slots
+        // 4 tokens in consecutive slots: one 8-byte store when the run is aligned, 2- / 4-byte pieces when it is not (14-wide windows:
+        // every window of an odd column starts 2 slots off the token quads of the 64-wide image row)
+        const bool run = p0 != NOROW && p1 == p0 + 1 && p2 == p0 + 2 && p3 == p0 + 3 && (e.vt_Tpad & 1) == 0;
+        const bool fast = run && (p0 & 3) == 0 && (e.vt_Tpad & 3) == 0;
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
           const float bias = tj ? bias1 : bias0;
@@ -1322,6 +1325,16 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
           T* cp = vt + (tj ? cb1 : cb0);
           if (fast) {
             store4v<T>(cp + p0, v0, v1, v2, v3);
+          } else if (run) {
+            T* pp = cp + p0;
+            if (p0 & 1) {
+              pp[0] = (T)v0;
+              store2<T>(pp + 1, v1, v2);
+              pp[3] = (T)v3;
+            } else {
+              store2<T>(pp, v0, v1);
+              store2<T>(pp + 2, v2, v3);
+            }
           } else {
             if (p0 != NOROW) cp[p0] = (T)v0;
             if (p1 != NOROW) cp[p1] = (T)v1;

@@ -26,11 +26,13 @@ struct LnArgs {
   int split;          // LA_F16X2: the 16-bit outputs are [hi | lo] plane pairs (row stride 2 E)
   int x2_group;       // > 0: x2 is [rows / x2_group, E] and row r adds x2[r / x2_group] (a per-image vector: the pending token-mean
                       // corrections of single-plane weights, LamEngine mean planes)
-  float* cs_part;     // != nullptr: workgroup (group g, chunk c of ceil(cs_rpg / CM_CHUNK)) handles a fixed 1 / chunks share of the rows of group g
+  float* cs_part;     // != nullptr: workgroup (group g, chunk c of ceil(cs_rpg / LN_CS_ROWS)) handles a fixed 1 / chunks share of the rows of group g
   int cs_rpg;         // (cs_rpg rows per group) and writes the column sums of what it stored to cs_part[(g * chunks + c) * E ..]: the token means
                       // of the qkv operand come out of the pass that writes it (la_colsum_fold adds the chunks in a fixed order)
 };
-constexpr int CM_CHUNK = 128;
+constexpr int CM_CHUNK = 128;      // rows per partial of la_colmean16 / la_attn_fwd_cs
+constexpr int LN_CS_ROWS = 32;     // rows per partial of the LayerNorm's column sums (la_layernorm_g): 64 images x 901 rows in 128-row shares
+                                   // were 512 workgroups on 256 CUs - 2.7 TB/s instead of 4.6
 
 template <typename T>
 __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) { store4v<T>(p, a, b, c, d); }
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   for (int i = 0; i < (CS ? NVT : 1); ++i) cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int row_begin = blockIdx.x * RPB + rl, row_end = a.rows, row_step = gridDim.x * RPB;
   if (CS) {
-    const int chunks = (a.cs_rpg + CM_CHUNK - 1) / CM_CHUNK;
+    const int chunks = (a.cs_rpg + LN_CS_ROWS - 1) / LN_CS_ROWS;
     const int g = blockIdx.x / chunks, ch = blockIdx.x % chunks;
     // "chunk" ch = the rows RPB ch + rl + it (RPB chunks) of the group, it = 0, 1, ...: the workgroups of a group sweep it TOGETHER, RPB
     // rows each per step, like the plain launch does (2048 workgroups each walking its own contiguous 128 rows measured 46 % slower)
@@ -178,7 +180,7 @@ static void launch_ln(const LnArgs& a, hipStream_t st) {
   const int rpb = 256 / lpr;
   int blocks = (a.rows + rpb - 1) / rpb;
   if (blocks > 8192) blocks = 8192;
-  if (a.cs_part) blocks = (a.rows / a.cs_rpg) * ((a.cs_rpg + CM_CHUNK - 1) / CM_CHUNK);
+  if (a.cs_part) blocks = (a.rows / a.cs_rpg) * ((a.cs_rpg + LN_CS_ROWS - 1) / LN_CS_ROWS);
   if (lpr == 64) {
     const int nvt = (nv + 63) / 64;
     if (nvt == 1) launch_ln_nv<T, 64, 1>(a, blocks, st);

@@ -230,7 +230,7 @@ class LamEngine:
 
     def mean_parts(self, bn: int, rpg: int, e: int, ea: int, o_chunks: int):
         """Scratch of one block's fused column sums: (LayerNorm partials or None, attention partials or None) - see mean_fix."""
-        xp = self.f32("mean.xpart", (bn * (_ceil(rpg, 128) // 128) * e,)) if "vmean" in self.precise else None
+        xp = self.f32("mean.xpart", (bn * L.ln_cs_chunks(rpg) * e,)) if "vmean" in self.precise else None
         op = self.f32("mean.opart", (bn * max(o_chunks, _ceil(rpg, 128) // 128) * ea,)) if "projmean" in self.precise else None
         return xp, op
 
@@ -244,7 +244,7 @@ class LamEngine:
         bar = self.f32("mean.bar", (bn, wm.shape[1]))
         kx = self.mean_kx[pre]
         if xpart is not None:
-            L.colsum_fold(xpart, bn, _ceil(rpg, 128) // 128, e, 1.0 / rpg, bar[:, :kx])
+            L.colsum_fold(xpart, bn, L.ln_cs_chunks(rpg), e, 1.0 / rpg, bar[:, :kx])
         if opart is not None and o_chunks > 0:
             L.colsum_fold(opart, bn, o_chunks, ea, 1.0 / rpg, bar[:, kx:])
         elif opart is not None:

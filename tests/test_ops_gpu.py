@@ -766,7 +766,7 @@ def test_token_mean_kernels(L, geom):
     L.add_rowvec(res, rv, rpg)
     assert torch.equal(res, full)
     # the same LayerNorm leaving the column sums of the 16-bit rows it stores (image order, or window-partitioned output)
-    chunks = (rpg + 127) // 128
+    chunks = L.ln_cs_chunks(rpg)
     res2 = torch.randn(groups * rpg, d, generator=gen).cuda()
     part = torch.full((groups * chunks * d,), float("nan"), device="cuda")
     arows = groups * ((g + ws - 1) // ws * ws) ** 2 if ws else groups * rpg
