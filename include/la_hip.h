@@ -337,6 +337,10 @@ int la_transpose16(const void* src, int src_dt, int ld, int R, int C, void* dst,
 /* y += a * x, n contiguous fp32 elements (loss-scaled encoder gradients folded into the flat gradient buffer). */
 int la_axpy(const float* x, float* y, long n, float a, void* stream);
 
+/* post = GELU(pre) (erf form) on n contiguous 16-bit values, n % 8 == 0: the training forward derives the MLP activation from the saved
+ * pre-activation (transformers ViTIntermediate; models/common.py:36-37). */
+int la_gelu_fwd16(const void* pre16, void* post16, long n, int dt, void* stream);
+
 /* dpre = dh * gelu'(pre) (erf form, transformers ViTIntermediate): pre 16-bit, dh fp32, outputs fp32 and / or 16-bit (either may be NULL). */
 int la_gelu_bwd16(const void* pre16, const float* dh, float* d32, void* d16, long n, int dt, void* stream);
 

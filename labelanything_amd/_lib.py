@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16",
 ]
 
 
@@ -445,6 +445,14 @@ def cast(src, dst, scale: float = 1.0) -> None:
         raise ValueError("la_cast needs contiguous tensors of equal size")
     _check(lib().la_cast(_ptr(src), C.c_int(dt_of(src)), _ptr(dst), C.c_int(dt_of(dst)), C.c_long(src.numel()), C.c_float(scale), _stream()),
            "la_cast")
+
+
+def gelu_fwd16(pre16, post16) -> None:
+    """post16 = GELU(pre16), contiguous 16-bit tensors of equal size (numel % 8 == 0)."""
+    _dev(pre16)
+    if not (pre16.is_contiguous() and post16.is_contiguous() and pre16.numel() == post16.numel() and pre16.dtype == post16.dtype):
+        raise ValueError("gelu_fwd16 needs contiguous 16-bit tensors of equal size and dtype")
+    _check(lib().la_gelu_fwd16(_ptr(pre16), _ptr(post16), C.c_long(pre16.numel()), C.c_int(dt_of(pre16)), _stream()), "la_gelu_fwd16")
 
 
 def gelu_bwd16(pre16, dh, d32=None, d16=None) -> None:

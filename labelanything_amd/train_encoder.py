@@ -103,27 +103,28 @@ class HfEncoderGraph:
         vt = torch.zeros(bn * heads, 64, tpad, device=dev, dtype=dt)
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
-            sv = {"x_in": res.clone()}
-            x16 = torch.empty(rows, e, device=dev, dtype=dt)
-            sv["xn"] = torch.empty(rows, e, device=dev)
-            eng.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, out32=sv["xn"])
+            sv = {"x_in": res}                       # (the stream is never updated in place: every residual GEMM writes a new buffer,
+            x16 = torch.empty(rows, e, device=dev, dtype=dt)      # which is also the activation the backward keeps)
+            sv["xn"] = x16                           # the weight gradients take the 16-bit LayerNorm output the GEMMs saw
+            eng.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
             sv["qkv"] = torch.empty(rows, 3 * e, device=dev, dtype=dt)
             self._qkv_plain(eng, x16, lp + ".qkv.w", sv["qkv"], e)
             L.head_transpose(sv["qkv"], 2 * e, bn, heads, t, tpad, vt)
             sv["ao"] = torch.empty(rows, e, device=dev, dtype=dt)
             sv["lse"] = torch.full((bn * heads, tpad), 1e30, device=dev)
             L.attn_fwd_lse(sv["qkv"], vt, sv["ao"], sv["lse"], bn, heads, t, tpad, e, scale)
-            eng.gemm_w(sv["ao"], lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res)
-            sv["x_mid"] = res.clone()
+            x_mid = torch.empty(rows, e, device=dev)
+            eng.gemm_w(sv["ao"], lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=x_mid)
+            sv["x_mid"] = x_mid
             x16b = torch.empty(rows, e, device=dev, dtype=dt)
-            sv["xnb"] = torch.empty(rows, e, device=dev)
-            eng.ln(res, lp + ".layernorm_after", 1e-12, out16=x16b, out32=sv["xnb"])
+            sv["xnb"] = x16b
+            eng.ln(x_mid, lp + ".layernorm_after", 1e-12, out16=x16b)
             sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
-            b1 = w[lp + ".intermediate.dense.bias"]
-            eng.gemm_w(x16b, lp + ".fc1.w", bias=b1, out16=sv["post"], act=L.ACT_GELU)      # exactly the inference epilogue ...
-            eng.gemm_w(x16b, lp + ".fc1.w", bias=b1, out16=sv["pre"])                       # ... and the pre-activation gelu' needs
-            eng.gemm_w(sv["post"], lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=res, out32=res)
+            eng.gemm_w(x16b, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=sv["pre"])    # the pre-activation gelu' needs;
+            L.gelu_fwd16(sv["pre"], sv["post"])                                                             # the activation from it
+            res = torch.empty(rows, e, device=dev)
+            eng.gemm_w(sv["post"], lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=x_mid, out32=res)
             layers.append(sv)
         fin = torch.empty(rows, e, device=dev)
         eng.ln(res, pre + ".layernorm", 1e-12, out32=fin)
