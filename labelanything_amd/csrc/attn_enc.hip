@@ -181,6 +181,48 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
   }
 
+  // ---- K / V^T tile staging by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per wave instruction) ----------
+  // The DMA destination is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk (row = lane/8, slot = lane%8
+  // holds logical chunk slot ^ ((row>>1)&7)).  No staging registers: hipcc parked the register-staged variant in
+  // scratch and exposed the whole load latency every tile.
+  const T* ksrc[2];
+  const T* vsrc[2];
+  int krow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);        // tile row 0..63
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    krow[i] = row;
+    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HDT + chunk * 8;
+    vsrc[i] = vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  auto dma = [&](int j, int stage) {
+    const unsigned sk = lds0 + stage * KVS;
+    const unsigned sv = sk + NH * SUB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key;
+      if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
+        const int slot = j * 64 + krow[i];
+        key = min(slot >> 4, a.G - 1) * a.G + min(slot & 15, a.G - 1);
+      } else {
+        key = min(j * 64 + krow[i], T_ - 1);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {            // dims 64 hh .. of K, rows 64 hh .. of V^T
+        dma16(ksrc[i] + (size_t)key * E3 + hh * 64, sk + hh * SUB + (i * 4 + wave) * 1024);
+        dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
+      }
+    }
+  };
+
+  // the first K / V^T tile goes on its way BEFORE the bias tables are built: a window's key loop is four tiles long, and two thirds of
+  // that kernel's time were the per-workgroup prologue chain (loads -> table MFMAs -> LDS -> first tile) - the stages and the bias
+  // tables do not overlap in LDS
+  const int ntiles = (MODE == 5) ? ((16 * a.G + 63) >> 6) : ((T_ + 63) >> 6);
+  dma(0, 0);
+
   // ---- bias staging ---------------------------------------------------------------------------------
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * KVS);
   f32x16 rw[2];
@@ -314,42 +356,6 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     keyinfo = ki;
   }
 
-  // ---- K / V^T tile staging by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 tile rows per wave instruction) ----------
-  // The DMA destination is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk (row = lane/8, slot = lane%8
-  // holds logical chunk slot ^ ((row>>1)&7)).  No staging registers: hipcc parked the register-staged variant in
-  // scratch and exposed the whole load latency every tile.
-  const T* ksrc[2];
-  const T* vsrc[2];
-  int krow[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);        // tile row 0..63
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    krow[i] = row;
-    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HDT + chunk * 8;
-    vsrc[i] = vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
-  }
-  const unsigned lds0 = lds_addr_of(smem);
-  auto dma = [&](int j, int stage) {
-    const unsigned sk = lds0 + stage * KVS;
-    const unsigned sv = sk + NH * SUB;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key;
-      if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
-        const int slot = j * 64 + krow[i];
-        key = min(slot >> 4, a.G - 1) * a.G + min(slot & 15, a.G - 1);
-      } else {
-        key = min(j * 64 + krow[i], T_ - 1);
-      }
-#pragma unroll
-      for (int hh = 0; hh < NH; ++hh) {            // dims 64 hh .. of K, rows 64 hh .. of V^T
-        dma16(ksrc[i] + (size_t)key * E3 + hh * 64, sk + hh * SUB + (i * 4 + wave) * 1024);
-        dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
-      }
-    }
-  };
-
   f32x16 oacc[2 * NH];
 #pragma unroll
   for (int d = 0; d < 2 * NH; ++d)
@@ -357,8 +363,6 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
 
-  const int ntiles = (MODE == 5) ? ((16 * a.G + 63) >> 6) : ((T_ + 63) >> 6);
-  dma(0, 0);
   dma_wait<0>();
   // MODE 4: relh[q][j] = Uh[63 - j][q], Uh[i][q] = Rh[y + i] . q; half hf covers tiles j in [32 hf, 32 hf + 32) = rows
   // i in [32 (1 - hf), +32): my_bh[q][j & 31]
