@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    s = wave_sum(s, LPR);
+    s = LPR == 64 ? wave_sum_dpp(s) : wave_sum(s, LPR);       // (DPP row sums + 4 readlanes: no ds_bpermute round trips in the row's chain)
     const float mean = s / (float)a.E;
     float q = 0.f;
 #pragma unroll
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
     }
-    q = wave_sum(q, LPR);
+    q = LPR == 64 ? wave_sum_dpp(q) : wave_sum(q, LPR);
     const float rstd = 1.0f / sqrtf(q / (float)a.E + a.eps);
 
     int drow = row;
