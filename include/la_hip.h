@@ -250,6 +250,9 @@ int la_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 /* dW[N,K] += dY[M,N]^T . X[M,K]: weight gradient of nn.Linear / 1x1 conv / k = s conv(-transpose) (exact-fp32 MFMA, split over M with
  * atomic accumulation: the caller zero-fills or pre-loads dW). */
 int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream);
+/* la_gemm_tn that also accumulates the bias gradient db[n] += sum_m dy[m][n] from the dY operands it loads (db fp32 [N]; NULL = la_gemm_tn):
+ * the weight and bias gradient of an nn.Linear / 1x1 conv in one pass over dY (autograd of models/common.py:19-37, transformer.py). */
+int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, float* db, void* stream);
 
 /* out[N] += column sums of dY[M,N] (fp32): the bias gradient of nn.Linear / the conv layers (autograd of the `+ bias` in
  * models/common.py, transformer.py, mask_decoder.py). */

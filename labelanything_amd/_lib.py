@@ -60,7 +60,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
 ]
 
 
@@ -335,13 +335,18 @@ def _f32rows(t: torch.Tensor) -> None:
         raise ValueError("fp32 device matrices with unit column stride expected")
 
 
-def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> None:
-    """dw[N,K] += dy[M,N]^T @ x[M,K].  dy / x may be column slices of wider matrices (row stride = the parent's width)."""
+def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None) -> None:
+    """dw[N,K] += dy[M,N]^T @ x[M,K] (and db[N] += dy.sum(0) when db is given).  dy / x may be column slices of wider matrices (row
+    stride = the parent's width)."""
     _f32rows(dy), _f32rows(x), _f32c(dw)
     m, n = dy.shape
     k = x.shape[1]
-    _check(lib().la_gemm_tn(_ptr(dy), C.c_int(dy.stride(0)), _ptr(x), C.c_int(x.stride(0)), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n),
-                            C.c_int(k), _stream()), "la_gemm_tn")
+    if db is not None:
+        _f32c(db)
+        if db.numel() != n:
+            raise ValueError("gemm_tn: db must hold N elements")
+    _check(lib().la_gemm_tn_db(_ptr(dy), C.c_int(dy.stride(0)), _ptr(x), C.c_int(x.stride(0)), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n),
+                               C.c_int(k), _ptr(db), _stream()), "la_gemm_tn")
 
 
 def colsum_acc(dy: torch.Tensor, out: torch.Tensor) -> None:

@@ -23,7 +23,8 @@ namespace la {
 // M-chunk; chunks are folded with fp32 atomics (the summation order is therefore not fixed; 1e-7-level run-to-run noise).
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                      float* __restrict__ dw, int ldw, int M, int N, int K, int mchunk, int tiles_k) {
+                                                      float* __restrict__ dw, int ldw, int M, int N, int K, int mchunk, int tiles_k,
+                                                      float* __restrict__ db) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
@@ -62,13 +63,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       }
     }
   };
+  // db != nullptr: the bias gradient db[n] += sum_m dY[m][n] on the way - the waves of the first k-tile column that own a dY column
+  // block (wave & 1 == 0) add up the operands they load anyway
+  const bool do_db = db != nullptr && tk == 0 && (wave & 1) == 0;
+  float bsum[2] = {0.f, 0.f};
   auto mma = [&](const float (&a)[4][2], const float (&b)[4][2]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        if (do_db) bsum[i] += a[u][i];
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+      }
   };
   float a0[4][2], b0[4][2], a1[4][2], b1[4][2];
   fetch(mbeg, a0, b0);
@@ -90,6 +97,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         if (n < N) atomicAdd(&dw[(size_t)n * ldw + k], acc[i][j][r]);
       }
     }
+  if (do_db) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = n0 + i * 32 + fr;                // (both half waves hold partial sums of column n: rows m + 2 u + fh)
+      if (n < N) atomicAdd(&db[n], bsum[i]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -724,7 +738,13 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, 
 
 }  // namespace la
 
+extern "C" int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, float* db, void* stream);
+
 extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, void* stream) {
+  return la_gemm_tn_db(dy, ldy, x, ldx, dw, ldw, M, N, K, nullptr, stream);
+}
+
+extern "C" int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, float* db, void* stream) {
   LA_CHECK_ARG(dy && x && dw, "la_gemm_tn: null pointer");
   LA_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && ldw >= K, "la_gemm_tn: bad shape M=%d N=%d K=%d", M, N, K);
   hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
@@ -733,6 +753,7 @@ extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, flo
     if (N <= 4 && K <= 4) hipLaunchKernelGGL((la::gemm_tn_tiny_kernel<4, 4>), dim3(blocks), dim3(256), 0, st0, dy, ldy, x, ldx, dw, ldw, (long)M, N, K);
     else hipLaunchKernelGGL((la::gemm_tn_tiny_kernel<8, 8>), dim3(blocks), dim3(256), 0, st0, dy, ldy, x, ldx, dw, ldw, (long)M, N, K);
     LA_CHECK_LAUNCH("la_gemm_tn");
+    if (db) return la_colsum_acc(dy, ldy, (long)M, N, db, stream);      // (tiny outputs: the separate column-sum pass)
     return 0;
   }
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
@@ -746,7 +767,7 @@ extern "C" int la_gemm_tn(const float* dy, int ldy, const float* x, int ldx, flo
   mchunk = (mchunk + 15) / 16 * 16;
   chunks = (M + mchunk - 1) / mchunk;
   hipLaunchKernelGGL(la::gemm_tn_kernel, dim3(tiles_n * tiles_k, chunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, ldy, x, ldx,
-                     dw, ldw, M, N, K, mchunk, tiles_k);
+                     dw, ldw, M, N, K, mchunk, tiles_k, db);
   LA_CHECK_LAUNCH("la_gemm_tn");
   return 0;
 }
