@@ -158,6 +158,34 @@ def test_training_step_with_trainable_encoder_matches_oracle_autograd():
     assert not torch.equal(before, qw.detach())
 
 
+def test_backbone_lr_is_its_own_parameter_group():
+    """The reference's ``backbone_lr`` branch (models/lam.py:340-346): the image encoder steps with its own rate, everything else with
+    ``lr``; a frozen backbone with a backbone rate raises as in the reference."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from tests.cases import CASES
+    from tests.test_train_gpu import make_gt
+    case = CASES["hf_tiny_1w1s_masks"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    with pytest.raises(ValueError, match="freeze the backbone"):
+        LamTrainer(Lam(case["cfg"], seed=3).cuda(), backbone_lr=1e-5)
+    moved = {}
+    for blr in (None, 1e-6):
+        lam = Lam(case["cfg"], seed=3).cuda()
+        tr = LamTrainer(lam, lr=1e-3, weight_decay=0.0, train_encoder=True, backbone_lr=blr)
+        params = dict(lam.named_parameters())
+        before = {k: params[k].detach().clone() for k in ("image_encoder.encoder.layer.0.attention.attention.query.weight",
+                                                           "mask_decoder.output_upscaling.0.weight")}
+        tr.step(batch, gt)
+        moved[blr] = {k: float((params[k].detach() - v).abs().max()) for k, v in before.items()}
+    enc, dec = "image_encoder.encoder.layer.0.attention.attention.query.weight", "mask_decoder.output_upscaling.0.weight"
+    # the first AdamW step moves an entry with a gradient by ~ its learning rate
+    assert 0.5e-3 <= moved[None][enc] <= 1.01e-3 and 0.5e-3 <= moved[None][dec] <= 1.01e-3, moved
+    assert 0.5e-6 <= moved[1e-6][enc] <= 1.01e-6 and 0.5e-3 <= moved[1e-6][dec] <= 1.01e-3, moved
+
+
 def test_steps_with_trainable_encoder_match_the_reference_fixture():
     """tests/golden/train_step_encoder.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up with
     NO frozen parameters (tools/make_golden_train.py, hf_tiny at 240 px): losses, per-tensor gradient norms of the first step, the
