@@ -38,7 +38,7 @@ PEAK_MFMA_TFLOPS = 2500.0      # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16
 WORKLOADS = {
     "cfg2": dict(desc="BASELINE cfg2: SAM ViT-B 1024px encoder + LabelAnything decoder, 1-way 1-shot episodes (2 images each)",
                  model=dict(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False),
-                 episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=32),
+                 episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=48),
     "cfg1": dict(desc="BASELINE cfg1 geometry on the GPU: ViT-MAE-B 480px encoder + decoder, 1-way 1-shot episodes (2 images each)",
                  model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                             example_class_attention=False, custom_preprocess=False),
@@ -162,7 +162,7 @@ class KernelTimer:
         return agg
 
 
-def pmc_traffic(workload: str, precise):
+def pmc_traffic(workload: str, precise, episodes=None):
     """HBM-side bytes per la_gemm launch from the committed PMC passes (profiles/r*_traffic.json, written by tools/collect_profiles.sh
     with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE).  A file only applies to the workload AND the numerics configuration it was
     collected on (it records both); anything else reports null instead of a stale number."""
@@ -170,7 +170,8 @@ def pmc_traffic(workload: str, precise):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
-        if d.get("workload", "cfg2") == workload and d.get("encoder_split_precision") == list(precise):
+        if d.get("workload", "cfg2") == workload and d.get("encoder_split_precision") == list(precise) and \
+                (episodes is None or d.get("episodes_per_step", 32) == episodes)        # (files of rounds 1 - 2: 32 episodes per step):
             return d.get("bytes_per_launch")
     return None
 
@@ -257,8 +258,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 32 = 64 images, 30 GB of the 288 GB; round 1 used 16; same box, round 2: "
-                    "302 / 309 / 312 / 316 episodes/s at 16 / 24 / 32 / 48)")
+    ap.add_argument("--episodes", type=int, default=None, help="episodes per step per GPU (cfg2 default 48 = 96 images, 45 GB of the 288 GB; rounds 1 / 2 used 16 / 32; same box, round 3: "
+                    "335 / 341 / 340 episodes/s at 32 / 48 / 64)")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS), help="cfg2 = the BASELINE metric (default); the others are "
                     "extra data points with the geometry of the other BASELINE configs")
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
@@ -352,7 +353,7 @@ def main():
             ach = g[2] / g[1] / 1e12
             roof = {"kernel": "la_gemm (gemm_t256q_kernel on the encoder shapes, gemm_t256p_kernel for two-plane weights; gemm_t256_kernel / gemm_dma4_kernel / gemm_pp_kernel / gemm_dma_kernel / gemm_f32_kernel / gemm_skinny_kernel elsewhere)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(a.workload, (lam_fwd if train else lam).precise),
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": pmc_traffic(a.workload, (lam_fwd if train else lam).precise, a.episodes),
                     "flop_per_launch": round(g[2] / g[0]), "algorithmic_bytes_per_launch": round(g[3] / g[0]), "launches_per_step": g[0], "avg_launch_us": round(g[1] / g[0] * 1e6, 2),
                     "share_of_kernel_time": round(g[1] / tot, 3),
                     # split-precision weights ([W_hi | W_lo]) issue two MFMA passes for one algorithmic product

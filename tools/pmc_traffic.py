@@ -38,10 +38,14 @@ def main():
     wkib = sum(write.get(n, 0.0) for n in names)
     from labelanything_amd.engine import PRECISE_WIDE
     workload = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    episodes = bench.WORKLOADS[workload]["default_episodes"]          # the passes run `bench.py` with its default batch
     precise = list(PRECISE_WIDE) if len(sys.argv) <= 5 or sys.argv[5] == "default" else [g for g in sys.argv[5].split(",") if g and g != "none"]
     tw = sorted(n for n in fetch if "twoway_" in n and "merge" not in n)
     out = {
         "workload": workload, "encoder_split_precision": precise,      # bench.py only attaches this file to a matching run
+        "episodes_per_step": episodes,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --no-graphs --no-cpu-baseline`",
         "kernels": names,
         "launches_counted": launches,
