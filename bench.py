@@ -171,7 +171,7 @@ def pmc_traffic(workload: str, precise, episodes=None):
         with open(path) as f:
             d = json.load(f)
         if d.get("workload", "cfg2") == workload and d.get("encoder_split_precision") == list(precise) and \
-                (episodes is None or d.get("episodes_per_step", 32) == episodes)        # (files of rounds 1 - 2: 32 episodes per step):
+                (episodes is None or d.get("episodes_per_step", 32) == episodes):       # (files of rounds 1 - 2: 32 episodes per step)
             return d.get("bytes_per_launch")
     return None
 
