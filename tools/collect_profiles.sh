@@ -7,17 +7,20 @@ R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
-# 1. the official bench line (with roofline + cpu_baseline)
+# 1. HBM-side traffic of the GEMM kernels FIRST (one counter per pass, no other trace domains): the bench line below attaches the
+#    bytes per launch of a traffic file that matches its workload, numerics and batch
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
+python tools/pmc_traffic.py $(find $OUT/pmc -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic.json > /dev/null 2> $OUT/traffic.stderr
+cp $OUT/${R}_traffic.json profiles/${R}_traffic.json 2>/dev/null      # (on the box: bench.py reads profiles/)
+# 2. the official bench line (with roofline + cpu_baseline)
 timeout 900 python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.stderr
-# 2. rocprofv3 kernel stats of the same command (eager launches so that every kernel is a separate dispatch record too)
+# 3. rocprofv3 kernel stats of the same command (eager launches so that every kernel is a separate dispatch record too)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --no-cpu-baseline --no-eager-baseline > $OUT/prof_graph.log 2>&1
 cp $(find $OUT/prof -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv 2>/dev/null
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eager -o bench -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs > $OUT/prof_eager.log 2>&1
 cp $(find $OUT/prof_eager -name 'bench_kernel_stats.csv' | head -1) $OUT/${R}_bench_eager_kernel_stats.csv 2>/dev/null
-# 3. HBM-side traffic of the GEMM kernels: one counter per pass, no other trace domains
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc -o f -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc -o w -- python bench.py --no-cpu-baseline --no-eager-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
-python tools/pmc_traffic.py $(find $OUT/pmc -name 'f_counter_collection.csv' | head -1) $(find $OUT/pmc -name 'w_counter_collection.csv' | head -1) $OUT/${R}_traffic.json > /dev/null 2> $OUT/traffic.stderr
+if [ -n "${ONLY_HEAD:-}" ]; then rm -rf $OUT/prof $OUT/prof_eager $OUT/pmc; ls -la $OUT; exit 0; fi
 # 3b. the same two passes on cfg4 (decoder-dominated: the fused two-way kernels' stream traffic)
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc4 -o f -- python bench.py --workload cfg4 --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o w -- python bench.py --workload cfg4 --no-cpu-baseline --no-graphs --steps 2 --warmup 1 > /dev/null 2>&1
