@@ -42,6 +42,7 @@ timeout 600 python bench.py --workload cfg1 --gemm-shapes --no-cpu-baseline --no
 timeout 300 python tools/attn_ab.py > $OUT/${R}_attn_shapes.log 2>&1
 [ -x tools/probes/coissue ] && timeout 120 ./tools/probes/coissue > $OUT/${R}_coissue_probe.log 2>&1
 timeout 600 python tools/train_grad_diag.py > $OUT/${R}_train_grad_diag.log 2>&1
+timeout 900 python tools/race_screen.py 40 > $OUT/${R}_race_screen.log 2>&1
 # 4. parity report + per-op micro benchmarks
 timeout 900 python tools/parity_report.py > $OUT/${R}_parity.log 2>&1
 timeout 900 python tools/parity_report.py --groups > $OUT/${R}_parity_groups.log 2>&1
