@@ -8,7 +8,7 @@ OUT=gpurun_out/pmc_$R
 mkdir -p $OUT
 SUM=gpurun_out/${R}_pmc_summary.txt
 : > $SUM
-for w in lin1 lin2 qk v2 attn; do
+for w in ${PMC_SHAPES:-lin1 lin2 qk v2 attn}; do
   i=0
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
              "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
