@@ -1413,17 +1413,25 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
   if ((EPI == 1 || EPI == 2) && row0 + 128 <= M) {
     // 16-bit output of an interior tile, the common case.  Registers 2k, 2k + 1 of an accumulator are rows 2p, 2p + 1 of ONE column:
     // bias (+ GELU) on the pair in packed fp32, one cvt_pk, one 32-bit LDS store - no lane exchange.  Slab = [8 row pairs][64
-    // columns] of such words; 16-byte unit u of a row pair sits at u ^ (u >> 3) (conflict-free reads below; on the store side the
-    // flip is the compile-time tj).  Read side: lane (pair p, 8-column group ch) fetches the pair's 8 columns as two 16-byte units
+    // columns] of such words (256 B = one pass over the 64 LDS banks); 16-byte unit u of row pair p sits at u ^ (p & 1) ^ 8 ((p >> 1) & 1):
+    //   a ds_write_b32 stores pairs kp + 4 q + 2 fh - its two half waves land in different 128-byte halves of the bank row;
+    //   a ds_read_b128 pass serves 16 lanes = two pairs p, p + 1 reading the units 2 ch - the odd pair's sit on the odd units.
+    // Read side: lane (pair p, 8-column group ch) fetches the pair's 8 columns as two 16-byte units
     // and unzips them with v_perm into the two 16-byte row segments it stores: whole 128-byte lines per 8 lanes.
     // The LDS queue of a wave is in order: chunk c + 1 is written right behind the READ INSTRUCTIONS of chunk c, and the read data is
     // waited for (counted) only after those writes have been issued - no round trip is exposed between chunks.
     T* out = reinterpret_cast<T*>(e.out16);
-    const int rp = lane >> 3, rch = lane & 7, rs = rch >> 2;
-    char* wb0 = slab + (2 * fh) * 256 + (fr >> 2) * 16 + (fr & 3) * 4;                   // pair 2 fh (+ kp + 4 q), logical unit fr >> 2
-    char* wb1 = wb0 + 128 + (((fr >> 2) & 1) ? -16 : 16);                                // logical unit 8 + (fr >> 2) -> physical ^ 1
-    const char* rb0 = slab + rp * 256 + (2 * rch + rs) * 16;
-    const char* rb1 = slab + rp * 256 + (2 * rch + 1 - rs) * 16;
+    const int rp = lane >> 3, rch = lane & 7;
+    // write bases [tj][kp]: pair 2 fh (+ kp + 4 q added below), logical unit 8 tj + (fr >> 2), physical ^ kp ^ 8 fh
+    char* wb[2][2];
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp)
+        wb[tj][kp] = slab + (2 * fh + kp) * 256 + ((((fr >> 2) + 8 * tj) ^ kp ^ (8 * fh)) << 4) + (fr & 3) * 4;
+    const int rx = (rp & 1) ^ (8 * ((rp >> 1) & 1));
+    const char* rb0 = slab + rp * 256 + (((2 * rch) ^ rx) << 4);
+    const char* rb1 = slab + rp * 256 + (((2 * rch + 1) ^ rx) << 4);
     T* op = out + (size_t)(row0 + 2 * rp) * e.ld16 + col0 + rch * 8;
     const size_t cstride = (size_t)16 * e.ld16;
     const f32x2 b0 = {bias0, bias0}, b1 = {bias1, bias1};
@@ -1438,7 +1446,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
             const int r = h * 8 + q * 4 + 2 * kp;
             f32x2 v = f32x2{acc[i][tj][r], acc[i][tj][r + 1]} + (tj ? b1 : b0);
             if (EPI == 2) v = gelu_erf_pk(v);
-            *reinterpret_cast<uint32_t*>((tj ? wb1 : wb0) + (kp + 4 * q) * 256) = pack2<T>(v.x, v.y);
+            *reinterpret_cast<uint32_t*>(wb[tj][kp] + (4 * q) * 256) = pack2<T>(v.x, v.y);
           }
     };
     uint4 u0, u1;
