@@ -52,7 +52,8 @@ WORKLOADS = {
                             custom_preprocess=False),
                  episode=dict(n_ways=2, k_shots=5, image_size=1024, embeddings_channels=256, grid=64), default_episodes=8),
     "cfg5": dict(desc="BASELINE cfg5 geometry, forward: ViT-MAE-L 480px (parameters/trainval/coco/mael.yaml), 10-way 5-shot episodes "
-                      "(51 images, 550 prompt pairs each), 16-bit MFMA attention (the fp8 attention of BASELINE cfg5 is not built)",
+                      "(51 images, 550 prompt pairs each); 16-bit MFMA attention by default, --attn-fp8 runs QK^T on the fp8 MFMA as BASELINE "
+                      "configs[4] words it (3e-3 on the logits: outside the 1e-3 tolerance, hence opt-in)",
                  model=dict(encoder="vit_l_mae", image_size=480, image_embed_dim=1024, embed_dim=256, spatial_convs=3,
                             class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
                  episode=dict(n_ways=10, k_shots=5, image_size=480), default_episodes=1),
@@ -270,6 +271,8 @@ def main():
                     "or a comma list of groups")
     ap.add_argument("--train-encoder", action="store_true", help="cfg3_train only: train the ViT backbone too (mae_noembs.yaml has no "
                     "freeze_backbone): forward with saved activations + encoder backward + 96 M-parameter gradient all-reduce")
+    ap.add_argument("--attn-fp8", action="store_true", help="HF encoders (cfg1/3/5): QK^T of the attention on the fp8 (e4m3) MFMA, as BASELINE "
+                    "configs[4] words cfg5; 3e-3 on the logits, i.e. outside the 1e-3 tolerance - never the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the torch-eager-on-GPU comparator that fills vs_baseline (cfg2, 1 GPU)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -300,6 +303,7 @@ def main():
     lam, cfg = build_model(dtype, {"f32": torch.float32, "f16x2": "f16x2", "same": None}[a.decoder], a.workload, precise)
     lam = lam.to(dev)
     train = bool(WORKLOADS[a.workload].get("train"))
+    lam.attn_fp8 = bool(a.attn_fp8)
     lam.use_graphs = not a.no_graphs and not train
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
     if train:
@@ -384,7 +388,13 @@ def main():
                       (f"episodes/sec (training steps{', trainable encoder' if a.train_encoder else ''}) {a.workload}" if train else f"episodes/sec (forward) {a.workload}"),
             "value": round(eps, 3), "unit": "episodes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "dtype_note": ("BASELINE configs[1] says bf16, north_star's tolerance says 'fp16/bf16': the path is served with fp16 MFMA operands because "
+                           "bf16 operands (8 mantissa bits on every activation) measure 4.4e-3 on the cfg2 logits against the 1e-3 tolerance "
+                           "(fp16: 7e-4) and run 15 % slower with the full weight-plane set they need (profiles/r03_bench_cfg2_bf16.json); "
+                           "--dtype bf16 runs that configuration") if a.dtype == "f16" else
+                          "bf16 operands: outside the 1e-3 logit tolerance (4.4e-3 measured on cfg2); the parity configuration is --dtype f16",
+            "attn_fp8": bool(a.attn_fp8), "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes, "global_episodes_per_step": a.episodes * world,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),

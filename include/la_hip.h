@@ -38,8 +38,10 @@ enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1, LA_ATTN_RELPOS_WIN16 = 2 };
 const char* la_last_error(void);
 int la_version(void);
 
-/* Tuning hook of la_gemm (measurement A/B only, results are identical): 1 = 64-deep quadrant-phase main loop where it
- * applies (default), 0 = the 32-deep persistent kernel everywhere; v < 0 only queries.  Returns the previous value. */
+/* Tuning hook of la_gemm (measurement A/B only, results are bit-identical): 1 = 64-deep quadrant-phase main loop where it
+ * applies (default), 0 = the 32-deep persistent kernel everywhere; v < 0 only queries.  Returns the previous value.
+ * Only bit 0 is honoured by the product library; the timing ablations behind the higher bits and every environment
+ * override of kernel selection are compiled into the -DLA_DEBUG library alone (`make -C labelanything_amd/csrc DEBUG=1`). */
 int la_gemm_variant(int v);
 
 /* Epilogue of la_gemm: out = map( act(A.W^T + bias) + residual ).
@@ -314,7 +316,7 @@ int la_twoway_i2t(float* img, const void* wq_hi, const void* wq_lo, const float*
  * freeze_backbone, so models/lam.py:321-347 hands every ViT parameter to the optimizer).  Plain HF ViT attention, head_dim 64. ---- */
 
 /* la_attn_fwd in LA_ATTN_PLAIN mode that also writes the log2-domain log-sum-exp of every query row: lse fp32 [B*heads, Tpad]
- * (entries t >= T are not touched: the caller pre-fills them with +1e30 so that those rows carry zero probability in la_attn_bwd). */
+ * (entries t >= T are not touched here; la_attn_bwd overwrites them with +1e30 itself, so that those rows carry zero probability). */
 int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, float* lse, int B, int heads, int T, int Tpad, int E, float scale,
                     int dt, void* stream);
 
@@ -324,7 +326,8 @@ int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T
 
 /* Gradient of O = softmax(Q K^T scale) V per (image, head) (transformers ViTSelfAttention.forward under build_encoder.py:83-100):
  * qkv [B*T, 3E] (q | k | v), out16 = O, dout16 = dO [B*T, E]; kt / qt / dot = la_head_transpose of K, Q, dO; lse from la_attn_fwd_lse;
- * dvec fp32 [B*heads, Tpad] workspace (zero beyond T, receives rowsum(dO * O)); dqkv [B*T, 3E] receives dq | dk | dv.  All 16-bit
+ * dvec fp32 [B*heads, Tpad] workspace (need not be initialised: receives rowsum(dO * O), and 0 in [T, Tpad), where lse is set to
+ * +1e30 as well); dqkv [B*T, 3E] receives dq | dk | dv.  All 16-bit
  * tensors share dt; dO may be pre-scaled (loss scaling), dq / dk / dv then carry the same factor. */
 int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
                 float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream);

@@ -112,17 +112,13 @@ def preprocess_images_to_embeddings(encoder_name, checkpoint, use_sam_checkpoint
     """SAM-style encoders (preprocess.py:78-139).  ``num_workers`` / ``compile`` are accepted for CLI compatibility."""
     if encoder_name not in ENCODER_SPECS or ENCODER_SPECS[encoder_name].kind != "sam":
         raise KeyError(f"{encoder_name!r} is not a SAM-style encoder; use --huggingface for plain ViTs")
+    from label_anything.models import model_registry
     spec = ENCODER_SPECS[encoder_name]
-    lam = Lam(LamConfig(encoder=encoder_name, image_size=spec.img_size), compute_dtype=compute_dtype)
-    if checkpoint is not None:
-        sd = _load_checkpoint(checkpoint)
-        if use_sam_checkpoint:   # SAM checkpoints prefix the encoder with "image_encoder." (build_encoder.py:71-77)
-            sd = {k[len("image_encoder."):]: v for k, v in sd.items() if k.startswith("image_encoder.")}
-        enc = {"image_encoder." + k: v for k, v in sd.items()}
-        missing, unexpected = torch.nn.Module.load_state_dict(lam, enc, strict=False)
-        missing = [k for k in missing if k.startswith("image_encoder.")]
-        if missing or unexpected:
-            raise RuntimeError(f"checkpoint does not match encoder {encoder_name}: missing {missing[:5]}, unexpected {unexpected[:5]}")
+    # preprocess.py:105-107: the encoder-only entry of the registry, built from the checkpoint
+    from labelanything_amd.models import build_encoder
+    build = model_registry.get(encoder_name) or (lambda **kw: build_encoder(encoder_name, **kw))      # (registered test geometries)
+    model = build(checkpoint=checkpoint, use_sam_checkpoint=use_sam_checkpoint, compute_dtype=compute_dtype)
+    lam = model.lam
     lam = lam.to(device)
     mean, std = IMAGENET_DEFAULT
     return _run(lam, directory, outfolder, last_block_dir, batch_size, spec.img_size, custom_preprocess, mean, std, square=False)

@@ -50,6 +50,8 @@ ENCODER_SPECS: Dict[str, EncoderSpec] = {
     "vit_l_mae": EncoderSpec("hf", 1024, 24, 16, 4096, img_size=224),
     # facebook/dino-vitb8 (models/build_encoder.py:115-117): HF ViT-B with 8x8 patches (use vit_patch_size=8)
     "vit_dino_b8": EncoderSpec("hf", 768, 12, 12, 3072, patch=8, img_size=224),
+    # google/vit-base-patch16-224-in21k (models/build_encoder.py:108-112): the plain HF ViT-B geometry
+    "vit_b_imagenet_i21k": EncoderSpec("hf", 768, 12, 12, 3072, img_size=224),
 }
 
 

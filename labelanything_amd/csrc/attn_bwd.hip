@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   }
   dsum += __shfl_xor(dsum, 32, 64);               // D of this lane pair's query
   const float lse2 = a.lse[(size_t)bh * a.Tpad + qc];
-  if (q < T_ && fh == 0) a.dvec[(size_t)bh * a.Tpad + q] = dsum;
+  // rows in [T, Tpad) are written here too (D = 0, LSE = +BIG: p = 0 in the dK / dV kernel) - the C entry point does not depend on
+  // how the caller initialised its buffers (an uninitialised D there would give 0 * NaN in dK)
+  if (fh == 0 && q < a.Tpad) {
+    a.dvec[(size_t)bh * a.Tpad + q] = q < T_ ? dsum : 0.f;
+    if (q >= T_) a.lse[(size_t)bh * a.Tpad + q] = 1e30f;
+  }
 
   const unsigned lds0 = lds_addr_of(smem);
   const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * 64;

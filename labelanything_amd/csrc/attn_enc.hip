@@ -997,7 +997,7 @@ extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, cons
   } else if (mode == LA_ATTN_RELPOS) {
     LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
     if (tabh && tabw && G <= 16) {        // windows: bias terms computed in-kernel from the tables
-      static const char* wforce = getenv("LA_WINDOW_PATH");     // debugging: "lds" selects the LDS-staged MODE 3 kernel
+      static const char* wforce = la_dbg_env("LA_WINDOW_PATH");     // debugging: "lds" selects the LDS-staged MODE 3 kernel
       if (!(wforce && wforce[0] == 'l') && E == heads * 64) {   // (the no-LDS window kernel is 64-wide only)
         if (dt == LA_F16) la::launch_window<la::f16_t>(a, st);
         else la::launch_window<la::bf16_t>(a, st);

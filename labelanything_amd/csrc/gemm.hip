@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
 static int tile_group_m(int dflt = 8) {
   static int forced = -2;
   if (forced == -2) {
-    const char* v = getenv("LA_GEMM_GROUP_M");
+    const char* v = la_dbg_env("LA_GEMM_GROUP_M");
     forced = v ? atoi(v) : -1;
   }
   return forced >= 0 ? forced : dflt;
@@ -1766,8 +1766,12 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
   constexpr int BUFB = 2 * OPB;                      // 64 KiB per k-tile
   constexpr int SDECL = (EPI == 3) ? 32 : 16;        // stores per wave of an interior, non-V^T tile (never more than are issued)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bool nostore = (gm >> 8) & 1;                // measurement ablations (la_gemm_variant bits 8 / 23: results wrong by construction)
-  const bool noepi = (gm >> 23) & 1;
+#ifdef LA_DEBUG
+  const bool nostore = (gm >> 8) & 1;                // measurement ablations (la_gemm_variant bits 8 / 23: results wrong by construction);
+  const bool noepi = (gm >> 23) & 1;                 // they exist in the -DLA_DEBUG library only
+#else
+  constexpr bool nostore = false, noepi = false;
+#endif
   gm &= 0xff;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wi = wave & 3;
@@ -1969,7 +1973,7 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
     // 16 / 28 / 32 / 64 / 114 chunks measured 97 / - / 131 / 155 / 210 us (more than one round also pays the tile quantisation)
     const int tmn = ((M + 255) / 256) * (N / 256), nkt = K / 64;
     int want = ncu / tmn;
-    static const char* wenv = getenv("LA_KSPLIT_WANT");      // debugging: force the number of K chunks
+    static const char* wenv = la_dbg_env("LA_KSPLIT_WANT");      // debugging: force the number of K chunks
     if (wenv) want = atoi(wenv);
     if (want > nkt / 2) want = nkt / 2;
     if (want < 1) want = 1;
@@ -1982,7 +1986,7 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
   }
   const int ntiles = ((M + 255) / 256) * (N / 256) * ksplit;
   int grid = ntiles < ncu ? ntiles : ncu;
-  static const char* genv = getenv("LA_KSPLIT_GRID");      // debugging: workgroups launched (0 = one per tile)
+  static const char* genv = la_dbg_env("LA_KSPLIT_GRID");      // debugging: workgroups launched (0 = one per tile)
   if (EPI == 4 && genv) grid = atoi(genv) > 0 ? atoi(genv) : ntiles;
   hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800100), ksplit, kchunk);
@@ -2022,7 +2026,7 @@ static void launch_t256_epi(const void* A, int lda, const void* W, int ldw, int 
 template <typename T, int NPL>
 static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   const bool plain = e.map == LA_MAP_NONE && e.res_mod == 0;
-  static const char* nop = getenv("LA_GEMM_NO_PERSISTENT");
+  static const char* nop = la_dbg_env("LA_GEMM_NO_PERSISTENT");
   const bool al = (N % 256) == 0 && K / 32 >= 8 && !nop && (e.ld16 % 8) == 0;
   if (al && plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   // qkv of a SAM window block from image-order tokens: rows scattered into window order by the epilogue (no padded rows multiplied)
@@ -2351,7 +2355,11 @@ static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, in
 
 extern "C" int la_gemm_variant(int v) {
   const int prev = la::g_gemm_variant;
+#ifdef LA_DEBUG
   if (v >= 0) la::g_gemm_variant = v;
+#else
+  if (v >= 0) la::g_gemm_variant = v & 1;       // the product library only knows the two bit-identical main loops
+#endif
   return prev;
 }
 
@@ -2402,7 +2410,7 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     LA_CHECK_LAUNCH("la_gemm");
     return 0;
   }
-  static const char* force = getenv("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128), "6" (256x256)
+  static const char* force = la_dbg_env("LA_GEMM_PATH");   // debugging: "v1" (register staged), "2" (128x128), "4" (256x128), "6" (256x256)
   bool fast = la::fast_ok(A, lda, W, ldw, M, N, K, *epi) && !(force && force[0] == 'v');
   if (fast) {
     // measured on MI355X (profiles/r01_gemm_variants.log): the 256x128 / 128x64-per-wave kernel wins by ~5 % on the short-K

@@ -4,6 +4,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Measurement / debugging switches (environment overrides of kernel selection, ablation bits of la_gemm_variant) exist only in a
+// -DLA_DEBUG build (`make DEBUG=1` -> libla_hip_dbg.so, loaded by tools/ through LA_HIP_LIB): the product library never reads the
+// environment and its kernels carry no "results wrong by construction" paths.
+#ifdef LA_DEBUG
+#include <cstdlib>
+static inline const char* la_dbg_env(const char* name) { return getenv(name); }
+#else
+static inline constexpr const char* la_dbg_env(const char*) { return nullptr; }
+#endif
+
 namespace la {
 
 typedef _Float16 f16_t;

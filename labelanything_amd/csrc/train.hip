@@ -759,7 +759,7 @@ extern "C" int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, 
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
   // M-chunks: every chunk ends in one atomic per output element: ~2048 workgroups (256 / 512 / 1024 / 2048 measured 10.4 / 7.2 / 7.2 /
   // 6.9 ms over the decoder's 85 launches: the row loads are latency-bound), at least 128 rows each (multiple of 16)
-  static const char* wgenv = getenv("LA_TN_WGS");       // debugging: target number of workgroups
+  static const char* wgenv = la_dbg_env("LA_TN_WGS");       // debugging: target number of workgroups
   int chunks = (wgenv ? atoi(wgenv) : 2048) / (tiles_n * tiles_k);
   if (chunks < 1) chunks = 1;
   int mchunk = (M + chunks - 1) / chunks;

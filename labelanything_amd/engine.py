@@ -12,7 +12,6 @@ PyTorch is used for device memory, views/copies and the host-side prompt bookkee
 """
 from __future__ import annotations
 
-import os
 
 import math
 from typing import Dict, Optional, Tuple
@@ -117,11 +116,19 @@ def resolve_precise(cfg: LamConfig, precise, dtype: torch.dtype = torch.float16)
 
 class LamEngine:
     def __init__(self, cfg: LamConfig, weights: Dict[str, Tensor], device: torch.device, dtype: torch.dtype = torch.float16,
-                 decoder_dtype: Optional[torch.dtype] = torch.float32, precise=PRECISE_DEFAULT):
+                 decoder_dtype: Optional[torch.dtype] = torch.float32, precise=PRECISE_DEFAULT, fuse_twoway: bool = True,
+                 window_scatter: bool = True, scope: str = "all"):
         """dtype: MFMA operand type of the image encoder and necks (>99% of the FLOPs).  decoder_dtype: operand type of the
         prompt encoder / mask decoder GEMMs - fp32 by default (exact-fp32 MFMA; ~1% of the FLOPs but the stage where
         16-bit operand rounding would dominate the logit error), or None to follow ``dtype``.  precise: encoder GEMM groups
-        that run in split precision (see PRECISE_DEFAULT); () = every encoder GEMM with plain 16-bit operands."""
+        that run in split precision (see PRECISE_DEFAULT); () = every encoder GEMM with plain 16-bit operands.
+        fuse_twoway / window_scatter: explicit constructor switches for A/B measurements (tools/) of the fused two-way kernels and of
+        the window-order scatter epilogue; the product never reads the environment.  scope="encoder": only the image encoder's weights
+        are packed (the trainer-private engine of train_encoder.HfEncoderGraph, re-packed after every optimizer step by
+        ``repack_encoder``)."""
+        if scope not in ("all", "encoder"):
+            raise ValueError("scope must be 'all' or 'encoder'")
+        self.scope = scope
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float16 or torch.bfloat16")
         self.precise = frozenset(resolve_precise(cfg, precise, dtype))
@@ -145,10 +152,9 @@ class LamEngine:
         self.kmod: Dict[str, int] = {}      # packed-weight key -> a_kmod of its GEMM (split-precision planes)
         self.mean_kx: Dict[str, int] = {}   # block prefix -> columns of its '.mean.w32' that multiply mean(x) (the rest multiply mean(o))
         # the image side of the two-way transformers runs in the fused kernels (one read / one read + write of the stream per
-        # attention, csrc/twoway.hip) for the published decoder geometry; LA_FUSE_TWOWAY=0 keeps the GEMM + attention + norm chain
-        import os as _os
-        self.fuse_twoway = (cfg.embed_dim == 256 and cfg.dec_heads == 8 and decoder_dtype == torch.float32
-                            and _os.environ.get("LA_FUSE_TWOWAY", "1") != "0")
+        # attention, csrc/twoway.hip) for the published decoder geometry; fuse_twoway=False keeps the GEMM + attention + norm chain
+        self.fuse_twoway = bool(fuse_twoway) and cfg.embed_dim == 256 and cfg.dec_heads == 8 and decoder_dtype == torch.float32
+        self.window_scatter = bool(window_scatter)
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
         L.lib()  # fail loudly if the HIP extension is missing
@@ -417,6 +423,8 @@ class LamEngine:
                                 self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp))
                 self._hw(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], "lin1")
                 self._hw(lp + ".fc2.w", w[lp + ".output.dense.weight"], "lin2")
+        if self.scope == "encoder":
+            return
         if cfg.lam_neck:
             self._pack_conv_neck("neck")
         pe = "prompt_encoder"
@@ -445,6 +453,17 @@ class LamEngine:
         if cfg.spatial_convs:
             for i in range(cfg.spatial_convs):
                 p[f"{md}.sc{i}.w"] = self._hd(w[f"{md}.spatial_convs.{3 * i}.weight"].permute(0, 2, 3, 1).flatten(1))
+
+    def repack_encoder(self, weights: Dict[str, Tensor]) -> None:
+        """Refresh the packed image-encoder weights from ``weights`` (live parameters after an optimizer step); the arena, the cached
+        positional tables that do not depend on parameters and everything outside the encoder stay.  Only for scope="encoder" engines."""
+        if self.scope != "encoder":
+            raise RuntimeError("repack_encoder is for scope='encoder' engines; full engines are rebuilt by Lam.engine()")
+        for k, v in weights.items():
+            if k.startswith("image_encoder."):
+                self.w32[k] = v.detach().to(device=self.dev, dtype=torch.float32).contiguous()
+        self._hfpos_cache.clear()          # resampled position embeddings are functions of a parameter
+        self._pack()
 
     # ------------------------------------------------------------------------------------------------
     # small helpers
@@ -581,7 +600,7 @@ class LamEngine:
             # image order and their epilogue scatters q / k rows and V^T slots into window order (LA_MAP_WINDOW_PART) - the padded
             # tokens (16 % of the rows at 64 x 64 / 14) are never multiplied.  Their q / k / v are the bias (pad-after-norm), constant
             # per block: every window block owns its buffers, filled once when they are created.
-            scatter = win16 and "qkv" not in self.precise and arows > rows and not os.environ.get("LA_NO_WINDOW_SCATTER")
+            scatter = win16 and "qkv" not in self.precise and arows > rows and self.window_scatter
             if is_global:
                 pass
             elif scatter:

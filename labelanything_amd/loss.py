@@ -1,7 +1,8 @@
 """Training objective on the device, first link of SURVEY 8f row 1: the focal term of ``LabelAnythingLoss`` with per-batch
 class weighting (reference ``loss/__init__.py:67-89``, ``loss/focal.py:17-26``, ``loss/utils.py:17-43``; the training config
 ``parameters/trainval/coco20i/mae_noembs.yaml:24-28`` uses exactly ``{focal: {weight: 1.0}}`` with ``class_weighting: True``),
-fused with its gradient with respect to the logits.  The backward pass through the network is not built yet."""
+fused with its gradient with respect to the logits (``la_focal_loss``): ``train.LamTrainer`` feeds that gradient into the backward of
+the decoder (and, with ``train_encoder=True``, of the image encoder)."""
 from __future__ import annotations
 
 from typing import Dict

@@ -7,7 +7,8 @@
 
 Same constructor kwargs, same ``state_dict()`` key layout (``model.image_encoder.*``, ``model.neck.*``,
 ``model.prompt_encoder.*``, ``model.mask_decoder.*``), same batch dictionary in, same result dictionary out.
-Inference only: parameters are plain tensors held in a module tree; all arithmetic runs in libla_hip.so.
+Parameters are plain tensors held in a module tree; all arithmetic runs in libla_hip.so.  ``forward`` / ``predict`` are the
+inference path; training (forward + backward + AdamW on the same kernels) goes through ``labelanything_amd.train.LamTrainer``.
 """
 from __future__ import annotations
 
@@ -126,7 +127,9 @@ class Lam(nn.Module):
             self._graphs = {}
             self._engine = LamEngine(self.cfg, self.state_dict(), dev, self.compute_dtype, self.decoder_dtype, self.precise)
             self._engine_key = key
-        self._engine.attn_fp8 = bool(self.attn_fp8)
+        if self._engine.attn_fp8 != bool(self.attn_fp8):
+            self._engine.attn_fp8 = bool(self.attn_fp8)
+            self._graphs = {}                # a captured launch sequence holds the kernel choice it was recorded with
         return self._engine
 
     def invalidate(self) -> None:
@@ -394,7 +397,7 @@ class Lam(nn.Module):
         return out
 
     def get_learnable_params(self, training_params: dict) -> list:
-        """lam.py:321-347 (parameter grouping only; this build is inference-only)."""
+        """lam.py:321-347: the parameter groups the optimizer receives (LamTrainer / FlatAdamW consume them)."""
         def not_enc(kv):
             return "image_encoder" not in kv[0]
         freeze = training_params.get("freeze_backbone", False)
@@ -534,6 +537,129 @@ def build_lam_vit_l(**kw) -> Lam:
 
 def build_lam_vit_mae_b(**kw) -> Lam:
     return build_lam(encoder="vit_b_mae", **kw)
+
+
+def build_lam_vit_h(**kw) -> Lam:
+    """build_lam.py:46-50."""
+    return build_lam(encoder="vit_h", **kw)
+
+
+def build_lam_vit_b_imagenet_i21k(**kw) -> Lam:
+    """build_lam.py:74-78 (google/vit-base-patch16-224-in21k geometry; weights come from the checkpoint - no hub access here)."""
+    return build_lam(encoder="vit_b_imagenet_i21k", **kw)
+
+
+def build_lam_dino_b8(**kw) -> Lam:
+    """build_lam.py:90-94 (facebook/dino-vitb8: 8 x 8 patches)."""
+    kw.setdefault("vit_patch_size", 8)
+    return build_lam(encoder="vit_dino_b8", **kw)
+
+
+class ImageEncoder(nn.Module):
+    """Encoder-only model, what ``model_registry[encoder_name](...)`` returns in the reference (``ENCODERS``,
+    models/build_encoder.py:143-151; consumer: preprocess.py:105-107): ``enc(images)`` -> (Bn, C, g, g) fp32,
+    ``enc(images, return_last_block_state=True)`` -> {"last_hidden_state", "last_block_state"} (image_encoder.py:110-131).
+    ``state_dict`` / ``load_state_dict`` use the encoder's own key names (no ``image_encoder.`` prefix), like the reference's modules.
+    project_last_hidden=False returns the last block state instead of the SAM neck output (image_encoder.py:123-124)."""
+
+    def __init__(self, encoder: str, image_size: Optional[int] = None, project_last_hidden: bool = True, seed: Optional[int] = None,
+                 compute_dtype=torch.float16, vit_patch_size: Optional[int] = None):
+        super().__init__()
+        spec = ENCODER_SPECS[encoder]
+        side = image_size or (spec.img_size if spec.kind == "sam" else 480)
+        kw = dict(encoder=encoder, image_size=side, vit_patch_size=vit_patch_size or spec.patch)
+        if spec.kind == "hf":
+            kw.update(image_embed_dim=spec.dim)
+        self.lam = Lam(LamConfig(**kw), seed=seed, compute_dtype=compute_dtype)
+        self.project_last_hidden = bool(project_last_hidden) or spec.kind == "hf"
+        self.kind = spec.kind
+
+    def forward(self, x, return_last_block_state: bool = False):
+        if self.kind == "sam" and not self.project_last_hidden:
+            return self.lam.encode_images_nchw(x, return_last_block_state=True)["last_block_state"]
+        return self.lam.encode_images_nchw(x, return_last_block_state=return_last_block_state)
+
+    def state_dict(self, *a, **kw):
+        pre = "image_encoder."
+        return {k[len(pre):]: v for k, v in self.lam.state_dict(*a, **kw).items() if k.startswith(pre)}
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = _hf5_to_hf4({"image_encoder." + k: v for k, v in state_dict.items()})
+        res = nn.Module.load_state_dict(self.lam, sd, strict=False)
+        missing = [k[len("image_encoder."):] for k in res.missing_keys if k.startswith("image_encoder.")]
+        unexpected = [k[len("image_encoder."):] for k in res.unexpected_keys]
+        self.lam._engine = None
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for ImageEncoder: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        return res
+
+
+def _build_sam_encoder(name: str, checkpoint=None, use_sam_checkpoint=False, project_last_hidden=True, **kw) -> ImageEncoder:
+    """``_build_vit`` (models/build_encoder.py:43-80): a SAM checkpoint prefixes the encoder's tensors with ``image_encoder.``."""
+    enc = ImageEncoder(name, project_last_hidden=project_last_hidden, **kw)
+    if checkpoint is not None:
+        weights = _load_any(checkpoint)
+        if use_sam_checkpoint:
+            weights = {k[len("image_encoder."):]: v for k, v in weights.items() if k.startswith("image_encoder.")}
+        enc.load_state_dict(weights)
+    return enc
+
+
+def build_vit_h(**kw) -> ImageEncoder:
+    return _build_sam_encoder("vit_h", **kw)
+
+
+def build_vit_l(**kw) -> ImageEncoder:
+    return _build_sam_encoder("vit_l", **kw)
+
+
+def build_vit_b(**kw) -> ImageEncoder:
+    return _build_sam_encoder("vit_b", **kw)
+
+
+def _build_hf_encoder(name: str, project_last_hidden=False, pretrained: Optional[str] = None, **kw) -> ImageEncoder:
+    """``ViTModelWrapper.from_pretrained(<hub id>)`` (models/build_encoder.py:103-118).  There is no hub access in this build:
+    ``pretrained`` names a LOCAL HuggingFace model directory (model.safetensors | pytorch_model.bin); without it the encoder keeps its
+    seeded random initialisation."""
+    enc = ImageEncoder(name, **kw)
+    if pretrained is not None:
+        wpath = os.path.join(pretrained, "model.safetensors")
+        sd = _load_any(wpath if os.path.exists(wpath) else os.path.join(pretrained, "pytorch_model.bin"))
+        sd = {(k[len("vit."):] if k.startswith("vit.") else k): v for k, v in sd.items()
+              if not k.startswith("decoder.") and "mask_token" not in k}
+        enc.load_state_dict(sd)
+    return enc
+
+
+def build_vit_b_mae(**kw) -> ImageEncoder:
+    return _build_hf_encoder("vit_b_mae", **kw)
+
+
+def build_vit_b_imagenet_i21k(**kw) -> ImageEncoder:
+    return _build_hf_encoder("vit_b_imagenet_i21k", **kw)
+
+
+def build_vit_dino_b8(**kw) -> ImageEncoder:
+    return _build_hf_encoder("vit_dino_b8", **kw)
+
+
+def build_encoder(name: str, **kw) -> ImageEncoder:
+    """models/build_encoder.py:138-141; geometries added with ``config.register_encoder`` build through the same two paths."""
+    if name in ENCODERS:
+        return ENCODERS[name](**kw)
+    if name not in ENCODER_SPECS:
+        raise KeyError(f"unknown encoder {name!r}; available: {sorted(ENCODER_SPECS)}")
+    return (_build_sam_encoder if ENCODER_SPECS[name].kind == "sam" else _build_hf_encoder)(name, **kw)
+
+
+# models/build_encoder.py:143-151, on-path entries (resnet50 / swin_b feed the out-of-scope pyramid variants)
+ENCODERS: Dict[str, Any] = {
+    "vit_h": build_vit_h,
+    "vit_l": build_vit_l,
+    "vit_b": build_vit_b,
+    "vit_b_mae": build_vit_b_mae,
+    "vit_dino_b8": build_vit_dino_b8,
+}
 
 
 def _load_any(path: str) -> Dict[str, torch.Tensor]:

@@ -338,12 +338,12 @@ class LamTrainer:
             raise ValueError("train_encoder=True needs a model with an image encoder")
         if backbone_lr is not None and not self.train_encoder:
             raise ValueError("Cannot freeze the backbone and set a learning rate for it at the same time.")
-        if self.train_encoder:
-            # the saved-activation forward of train_encoder.py runs the plain GEMM sequence, without the inference engine's
-            # token-mean corrections of V / proj: what those recover (logits 9.5e-4 -> 6e-4) is far below the 16-bit backward's own
-            # error (1e-3 ... 1e-2 on the gradients), and second weight planes in their place cost 2.5 ms of the step
-            lam.precise = tuple(gname for gname in lam.precise if gname not in ("vmean", "projmean"))
-            lam.invalidate()
+        # the saved-activation forward of train_encoder.py runs the plain GEMM sequence, without the inference engine's token-mean
+        # corrections of V / proj: what those recover (logits 9.5e-4 -> 6e-4) is far below the 16-bit backward's own error (1e-3 ... 1e-2
+        # on the gradients), and second weight planes in their place cost 2.5 ms of the step.  That choice lives in the
+        # trainer's PRIVATE encoder engine (HfEncoderGraph): ``lam.precise`` - what validation / inference on the same model use - is
+        # left alone.
+        self.train_precise = tuple(gname for gname in lam.precise if gname not in ("vmean", "projmean"))
         named = [(k, p) for k, p in lam.named_parameters() if self.train_encoder or "image_encoder" not in k]
         # tensors the forward never reaches (dead in the reference too, prompt_encoder.py:683) go to the tail of the flat buffer so
         # that the per-step "received a gradient" spans of FlatAdamW.step stay one contiguous run
@@ -370,7 +370,8 @@ class LamTrainer:
         self.enc_graph = None
         if self.train_encoder:
             from .train_encoder import HfEncoderGraph
-            self.enc_graph = HfEncoderGraph(lam, {k: gv for k, gv in zip(self.names, self.opt.grad_views) if k.startswith("image_encoder.")})
+            self.enc_graph = HfEncoderGraph(lam, {k: gv for k, gv in zip(self.names, self.opt.grad_views) if k.startswith("image_encoder.")},
+                                            precise=self.train_precise)
             self._anchor = torch.zeros(1, device=lam._device(), requires_grad=True)
             self._enc_idx = [i for i, k in enumerate(self.names) if k.startswith("image_encoder.")]
 
@@ -422,8 +423,11 @@ class LamTrainer:
         self.opt.step(active=active)
         self._touched = [False] * len(self.names)
         # packed / converted weight copies of the inference engine are stale now; the trainer's own engine only serves the frozen
-        # encoder and host-side helpers, so nothing is re-packed until the model is next used for inference
+        # encoder and host-side helpers, so nothing of it is re-packed until the model is next used for inference; a trainable
+        # encoder's private engine re-packs its encoder weights (and only those) before the next forward
         self.lam.invalidate()
+        if self.enc_graph is not None:
+            self.enc_graph.weights_changed()
 
     def step(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
         self.zero_grad()

@@ -41,13 +41,18 @@ class HfEncoderGraph:
 
     TARGET_MAX = 64.0
 
-    def __init__(self, lam, grads: Dict[str, Tensor]):
+    def __init__(self, lam, grads: Dict[str, Tensor], precise=None):
         spec = lam.cfg.encoder_spec
         if spec is None or spec.kind != "hf":
             raise NotImplementedError("the encoder backward covers the HF ViT stack (ViT-MAE / DINO / IN21k); the SAM ViTDet stack is forward only")
         if spec.head_dim != 64:
             raise NotImplementedError(f"encoder backward needs 64-wide heads (got {spec.head_dim})")
         self.lam, self.spec, self.grads = lam, spec, grads
+        # private engine: the encoder's packed weights under the TRAINING numerics (precise), re-packed after every optimizer step;
+        # the caller's ``lam.precise`` / inference engine are not touched
+        self.precise = tuple(lam.precise) if precise is None else tuple(precise)
+        self._eng = None
+        self._eng_stale = True
         self.w: Dict[str, Tensor] = {k: v for k, v in lam.state_dict(keep_vars=True).items() if k.startswith("image_encoder.")}
         missing = [k for k, v in self.w.items() if v.is_floating_point() and k not in grads]
         if missing:
@@ -68,6 +73,22 @@ class HfEncoderGraph:
         self._xt_key = None                   # which activation the transposed-operand scratch of _wgrad currently holds
         self._runs = None
         self._b_ready: Dict[tuple, bool] = {}
+        self._wt_cache: Dict[str, Tensor] = {}      # 16-bit W^T copies of the data-gradient GEMMs, per optimizer step
+
+    def weights_changed(self) -> None:
+        """The optimizer wrote the parameters (through raw pointers): re-pack before the next forward."""
+        self._eng_stale = True
+        self._wt_cache.clear()
+
+    def engine(self):
+        from .engine import LamEngine
+        lam = self.lam
+        if self._eng is None:
+            self._eng = LamEngine(lam.cfg, lam.state_dict(), lam._device(), lam.compute_dtype, lam.decoder_dtype, self.precise, scope="encoder")
+        elif self._eng_stale:
+            self._eng.repack_encoder(lam.state_dict())
+        self._eng_stale = False
+        return self._eng
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
     def _qkv_plain(self, eng, x16: Tensor, key: str, qkv: Tensor, ea: int) -> None:
@@ -82,7 +103,7 @@ class HfEncoderGraph:
     @torch.no_grad()
     def forward(self, images: Tensor) -> Tensor:
         """(Bn, 3, S, S) fp32 on the device -> [Bn * hw, E] fp32 NHWC rows (CLS dropped), activations kept for ``backward``."""
-        eng = self.lam.engine()            # re-packed from the live parameters (LamTrainer.apply_update invalidated the last one)
+        eng = self.engine()
         spec, w, p = self.spec, eng.w32, eng.p
         pre = "image_encoder"
         images = images.contiguous()
@@ -134,11 +155,16 @@ class HfEncoderGraph:
         return out
 
     # ---- backward --------------------------------------------------------------------------------------------------------------
-    def _wt16(self, wt: Tensor, dt) -> Tensor:
-        """nn.Linear weight [N, K] fp32 -> W^T [K, N] 16-bit: the 'weight' of the data-gradient GEMM dX = dY . W."""
-        n, k = wt.shape
-        out = torch.empty(k, n, device=wt.device, dtype=dt)
-        L.nchw_to_nhwc(wt.detach().contiguous(), 1, n, k, out16=out, dt=L._DT[dt])
+    def _wt16(self, key: str, wt_fn, dt) -> Tensor:
+        """nn.Linear weight [N, K] fp32 -> W^T [K, N] 16-bit: the 'weight' of the data-gradient GEMM dX = dY . W.  One copy per
+        optimizer step (``weights_changed`` drops them): a loss-scale retry or a gradient-accumulation micro-step re-uses it."""
+        out = self._wt_cache.get(key)
+        if out is None or out.dtype != dt:
+            wt = wt_fn()
+            n, k = wt.shape
+            out = torch.empty(k, n, device=wt.device, dtype=dt)
+            L.nchw_to_nhwc(wt.detach().contiguous(), 1, n, k, out16=out, dt=L._DT[dt])
+            self._wt_cache[key] = out
         return out
 
     def _wgrad(self, dy16, dy32, x, dw: Tensor, db: Optional[Tensor] = None) -> bool:
@@ -188,7 +214,7 @@ class HfEncoderGraph:
                 dy32 = self._tbuf("dy32b", dy16.shape[0], dy16.shape[1], torch.float32)
                 L.cast(dy16.contiguous(), dy32)
             L.colsum_acc(dy32, self.sviews[bname])
-        L.gemm(dy16, self._wt16(wt, dy16.dtype), out32=dx32, out16=dx16)
+        L.gemm(dy16, self._wt16(wname, lambda: wt, dy16.dtype), out32=dx32, out16=dx16)
 
     @torch.no_grad()
     def backward(self, d_out: Tensor) -> None:
@@ -202,7 +228,7 @@ class HfEncoderGraph:
         for _ in range(4):
             self.scratch.zero_()
             self._backward_scaled(d_out, scale)
-            if bool(torch.isfinite(self.scratch.sum())):
+            if bool(torch.isfinite(self.scratch).all()):          # (a sum can overflow or cancel to a finite value)
                 break
             scale /= 256.0                 # a 16-bit intermediate overflowed: repeat with more head-room
         else:
@@ -284,8 +310,8 @@ class HfEncoderGraph:
                         L.cast(dqkv16, dqkv32)
                         have32 = True
                     L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
-            wqkv = torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]])       # [3E, E]
-            L.gemm(dqkv16, self._wt16(wqkv, dt), out32=dxn)
+            wqkv_t = self._wt16(att + "qkv", lambda: torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]]), dt)
+            L.gemm(dqkv16, wqkv_t, out32=dxn)                                                                  # [3E, E]^T
             L.layernorm_bwd(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, False, dx,
                             sv[lp + ".layernorm_before.weight"], sv[lp + ".layernorm_before.bias"])
             L.add_cast(dres, dx, rows, out32=dres, dt=L._DT[dt])

@@ -46,7 +46,9 @@ def test_attention_forward_lse_and_backward_match_torch(shape):
     o_rows.backward(dout.double().cpu())
     gref = x.grad.permute(1, 3, 0, 2, 4).reshape(b * t, 3 * e)                                          # rows (b, t), cols (q|k|v, head, d)
     kt, qt, dot = heads_t(qkv, e), heads_t(qkv, 0), heads_t(dout, 0)
-    dvec = torch.zeros(b * heads, tpad, device="cuda")
+    # the C entry point is self-contained: an uninitialised workspace (NaN) and garbage in the padded LSE entries must not reach dK
+    dvec = torch.full((b * heads, tpad), float("nan"), device="cuda")
+    lse[:, t:] = float("nan")
     dqkv = torch.zeros(b * t, 3 * e, dtype=torch.float16, device="cuda")
     L.attn_bwd(qkv, out, dout, kt, qt, dot, lse, dvec, dqkv, b, heads, t, tpad, e, scale)
     torch.cuda.synchronize()
@@ -57,6 +59,7 @@ def test_attention_forward_lse_and_backward_match_torch(shape):
         assert err <= 4e-3, (name, err)                      # P, dS and the outputs are rounded to fp16 (2^-11) once each
     dref = (dout.double().cpu() * o_rows.detach()).view(b, t, heads, 64).sum(-1).permute(0, 2, 1).reshape(b * heads, t)
     assert float((dvec[:, :t].double().cpu() - dref).abs().max()) <= 3e-3 * float(dref.abs().max())
+    assert bool((dvec[:, t:] == 0).all()) and bool((lse[:, t:] == 1e30).all()) and bool(torch.isfinite(dqkv).all())
 
 
 def _hf_cfg(size=240):
@@ -264,3 +267,32 @@ def test_split_k_weight_gradient_gemm_matches_torch(shape):
     torch.cuda.synchronize()
     ref = dw0.double() + dy.half().double().t() @ x.double()
     assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 1e-5      # fp32 accumulation of exactly representable products
+
+
+def test_trainer_leaves_the_models_inference_numerics_alone():
+    """``LamTrainer(train_encoder=True)`` must not strip the token-mean correction groups from ``lam.precise`` - validation
+    between training steps runs the SAME inference configuration as before; the training forward's own numerics live in the trainer's
+    private encoder engine, which re-packs after every optimizer step (the second step must see the updated weights)."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from tests.cases import CASES
+    from tests.test_train_gpu import make_gt
+    case = CASES["hf_tiny_1w1s_masks"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    lam = Lam(case["cfg"], seed=3, precise=("patch", "vmean", "projmean", "neck")).cuda()
+    before = tuple(lam.precise)
+    ref = lam(batch)["logits"].clone()
+    tr = LamTrainer(lam, lr=0.0, weight_decay=0.0, train_encoder=True)          # lr 0: the weights do not move
+    assert tuple(lam.precise) == before and "vmean" not in tr.train_precise and "vmean" not in tr.enc_graph.precise
+    l1 = float(tr.step(batch, gt)["loss"])
+    assert tuple(lam.precise) == before
+    assert torch.equal(lam(batch)["logits"], ref)                               # inference between steps: unchanged configuration
+    eng1 = tr.enc_graph.engine()
+    l2 = float(tr.step(batch, gt)["loss"])
+    assert tr.enc_graph.engine() is eng1 and l1 == l2                           # same engine object, re-packed; same weights -> same loss
+    tr2 = LamTrainer(Lam(case["cfg"], seed=3).cuda(), lr=1e-2, weight_decay=0.0, train_encoder=True)
+    a = float(tr2.step(batch, gt)["loss"])
+    b = float(tr2.step(batch, gt)["loss"])
+    assert a != b                                                               # the second forward ran on re-packed (moved) weights

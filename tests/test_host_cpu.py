@@ -168,3 +168,33 @@ def test_has_config_records_arguments():
     assert m.config["embed_dim"] == 64 and m.config["use_vit"] is False and m.config["class_attention"] is False
     m2 = LabelAnything(config=dict(m.config))
     assert m2.config == m.config
+
+
+def test_model_registry_has_every_on_path_reference_name(tmp_path):
+    """label_anything/models/__init__.py:33-60 of the reference: the LabelAnything entries and the encoder-only ``**ENCODERS`` entries
+    (``model_registry[encoder_name](checkpoint=..., use_sam_checkpoint=...)``, preprocess.py:105-107)."""
+    import label_anything.models as M
+    from safetensors.torch import save_file
+    for name in ("lam", "lam_no_vit", "lam_h", "lam_l", "lam_b", "lam_mae_b", "lam_dino_b8", "lam_b_imagenet_i21k",
+                 "vit_h", "vit_l", "vit_b", "vit_b_mae", "vit_dino_b8"):
+        assert callable(M.model_registry[name]), name
+    for fn in ("build_lam_vit_h", "build_lam_dino_b8", "build_lam_vit_b_imagenet_i21k", "build_vit_b", "build_vit_h", "build_vit_l",
+               "build_vit_b_mae", "build_vit_dino_b8", "build_vit_b_imagenet_i21k", "build_encoder", "ENCODERS"):
+        assert hasattr(M, fn), fn
+    # geometry of the builders that were missing (shapes only: meta-free but cheap - the dino / i21k encoders are ViT-B sized)
+    from labelanything_amd.config import ENCODER_SPECS
+    assert ENCODER_SPECS["vit_b_imagenet_i21k"].kind == "hf" and ENCODER_SPECS["vit_b_imagenet_i21k"].patch == 16
+    assert ENCODER_SPECS["vit_dino_b8"].patch == 8 and ENCODER_SPECS["vit_h"].dim == 1280
+    # encoder-only builder: SAM-checkpoint key handling and strict loading, on a reduced geometry
+    from tests.cases import CASES  # noqa: F401  (registers sam_tiny)
+    enc = M.build_encoder("sam_tiny", seed=3)
+    sd = enc.state_dict()
+    assert "patch_embed.proj.weight" in sd and not any(k.startswith("image_encoder.") for k in sd)
+    ck = str(tmp_path / "sam.safetensors")
+    donor = {("image_encoder." + k): (v + 1).contiguous() for k, v in sd.items()}
+    donor["mask_decoder.foo"] = torch.zeros(1)
+    save_file(donor, ck)
+    enc2 = M.build_encoder("sam_tiny", checkpoint=ck, use_sam_checkpoint=True)
+    assert torch.equal(enc2.state_dict()["pos_embed"], sd["pos_embed"] + 1)
+    with pytest.raises(RuntimeError):
+        M.build_encoder("sam_tiny", checkpoint=ck)                   # prefixed keys without use_sam_checkpoint: strict load fails

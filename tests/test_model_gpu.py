@@ -7,8 +7,11 @@ is held to 1e-3 on EVERY stage below (measured 4.7e-4 .. 7.0e-4 on the worst sta
 
 Argmax: the fused argmax must equal torch.argmax of the logits the same launch wrote, bit for bit, and it must equal the
 REFERENCE's argmax at every pixel whose reference top-2 margin exceeds 2 x the logit tolerance (two logits that each move
-by <= tol can only swap when they were closer than 2 tol).  Random-weight models put 0.02-0.2 % of the pixels inside that
-band; those are reported, not asserted.
+by <= tol can only swap when they were closer than 2 tol).  Random-weight models put 0.02-0.3 % of the pixels inside that
+band; their number is printed and held, per case, to 4 x the count measured on MI355X (profiles/r03_parity.log).  Context:
+"bit-exact" against the reference is unreachable for ANY re-ordered arithmetic on these random-weight fixtures - the fp32 CPU
+oracle itself differs from the reference on 27 of the 1 048 576 pixels of cfg2 (tests/golden/cfg2_sam_b_1024_1w1s.json,
+"argmax_ties") - so the assertion is: zero flips outside the band, and no more flips inside it than the measured error explains.
 
 bf16 operands (8 mantissa bits) are a supported switch, NOT the parity configuration: their activation roundings alone
 cost 3-6e-3 on the logits, so they are held to their own measured bound (x1.5) and documented as such.
@@ -27,7 +30,16 @@ TOL = {
     torch.float16: dict(emb=1e-3, cls=1e-3, low=1e-3, logits=1e-3),
     torch.bfloat16: dict(emb=6.5e-3, cls=1.5e-3, low=9e-3, logits=8e-3),
 }
-ARGMAX_FLIPS = {torch.float16: 0.005, torch.bfloat16: 0.02}      # largest share of near-tie pixels that may flip
+# share of the pixels measured to flip inside the near-tie band, per case (profiles/r03_parity.log, default numerics); the test allows
+# 4 x that count (box-to-box the last bits of the token-mean sums are identical, so the spread is what a kernel change may move),
+# and at least ARGMAX_FLOOR pixels for the decoder-only cases that measure zero
+ARGMAX_MEASURED = {
+    torch.float16: {"sam_tiny_2w2s_all_prompts": 8.7e-4, "hf_tiny_1w1s_masks": 2.1e-4, "novit_d256_2w3s": 0.0, "novit_d512_neck_1w2s": 0.0,
+                    "cfg2_sam_b_1024_1w1s": 1.29e-3, "cfg1_mae_b_480_1w1s": 2.66e-3},
+    torch.bfloat16: {"sam_tiny_2w2s_all_prompts": 4.6e-3, "hf_tiny_1w1s_masks": 2.5e-3, "novit_d256_2w3s": 0.0, "novit_d512_neck_1w2s": 0.0,
+                     "cfg2_sam_b_1024_1w1s": 1.23e-2, "cfg1_mae_b_480_1w1s": 6.2e-3},
+}
+ARGMAX_FLOOR = 4
 ARGMAX_MARGIN = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # 2 x the logit tolerance
 
 
@@ -61,8 +73,9 @@ def test_episode_matches_reference_fixture(name, dt):
     # and equals the reference's argmax wherever the reference's top-2 margin is outside the tolerance band
     n_diff, n_real = argmax_disagreement(out["logits"], gold["argmax"].long(), ref_logits, margin_rel=ARGMAX_MARGIN[dt])
     assert n_real == 0, f"{n_real} of {n_diff} differing pixels have a reference margin above the tolerance band"
-    # measured: fp16 0.03 - 0.3 % of the pixels sit inside the band and flip, bf16 (8x wider band) up to 1 %
-    assert n_diff <= ARGMAX_FLIPS[dt] * am.numel(), f"{n_diff} of {am.numel()} pixels flip inside the near-tie band"
+    allowed = max(ARGMAX_FLOOR, int(4 * ARGMAX_MEASURED[dt][name] * am.numel()))
+    print(f"[argmax {name} {dt}] {n_diff} of {am.numel()} pixels flip inside the near-tie band (allowed {allowed}), {n_real} outside it")
+    assert n_diff <= allowed, f"{n_diff} of {am.numel()} pixels flip inside the near-tie band (allowed {allowed} = 4 x measured)"
     assert out["logits"].shape == (b, gold["class_embeddings"].shape[1], *gold["argmax"].shape[-2:])
 
 
@@ -371,3 +384,48 @@ def test_cfg3_decoder_at_full_size_matches_the_oracle_on_device_embeddings():
         ref = O.postprocess(geo, low, batch["dims"], batch.get("flag_gts"))
     assert rel_err(out["class_examples_embeddings"], pe["class_examples_embeddings"]) <= 2e-5
     assert rel_err(out["logits"], ref) <= 5e-5
+
+
+# ---- BASELINE configs[4] as worded: "fp8 MFMA attention" ------------------------------------------------------------------------------
+FP8_BOUND = 3.5e-3      # stated bound of the opt-in switch (measured 3.1e-3 on the cfg1 fixture, 2.7e-3 on a cfg5 episode: profiles/r03_attn_fp8.log)
+
+
+def test_attn_fp8_on_the_cfg1_reference_fixture_holds_its_stated_bound():
+    """``Lam.attn_fp8 = True`` (QK^T on v_mfma_scale_f32_32x32x64_f8f6f4 from an e4m3 copy of q | k) against the REFERENCE's logits
+    of the cfg1 fixture: 3 mantissa bits on q and k cost 3e-3 - outside north_star's 1e-3, which is why the switch is opt-in - and must
+    stay inside the bound the switch is documented with; the 16-bit path of the same model stays <= 1e-3; toggling the switch on a
+    live model (graphs captured) takes effect and toggling it back restores the 16-bit result bit for bit."""
+    name = "cfg1_mae_b_480_1w1s"
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    ref = reference_logits(case, gold, batch)
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    lam.use_graphs = True
+    base = lam(batch)["logits"].clone()
+    lam.attn_fp8 = True
+    out8 = lam(batch)["logits"].clone()
+    lam.attn_fp8 = False
+    again = lam(batch)["logits"]
+    e16, e8 = rel_err(base, ref), rel_err(out8, ref)
+    n_diff, n_real = argmax_disagreement(out8, gold["argmax"].long(), ref, margin_rel=2 * FP8_BOUND)
+    print(f"[attn_fp8 cfg1] logits vs reference: 16-bit {e16:.3e}, fp8 QK^T {e8:.3e} (bound {FP8_BOUND}); argmax flips {n_diff}, outside the band {n_real}")
+    assert e16 <= 1e-3
+    assert e16 < e8 <= FP8_BOUND, (e16, e8)
+    assert n_real == 0
+    assert torch.equal(again, base)
+
+
+def test_attn_fp8_on_a_cfg5_episode_at_full_geometry():
+    """BASELINE configs[4]: ViT-MAE-L 480, 10-way 5-shot (51 images, 550 pairs) with the fp8 attention, at its own size.  The CPU oracle
+    needs minutes here, so the fp8 run is held against the 16-bit run of the same model (itself pinned to <= 1e-3 on the fixtures and
+    on the reduced cfg5-shaped episode above): <= the stated bound, finite, right shape."""
+    lam, batch = _bench_model("cfg5")
+    lam.selected_rows = torch.arange(batch["flag_examples"].shape[2])
+    base = lam(batch)["logits"].clone()
+    lam.attn_fp8 = True
+    out8 = lam(batch)["logits"]
+    assert out8.shape == base.shape == (1, 11, 480, 480) and bool(torch.isfinite(out8).all())
+    e = rel_err(out8, base)
+    print(f"[attn_fp8 cfg5] logits vs the 16-bit path: {e:.3e} (bound {FP8_BOUND})")
+    assert 0 < e <= FP8_BOUND, e

@@ -6,9 +6,11 @@ import sys
 
 import torch
 
-if "--no-persistent" in sys.argv:
-    os.environ["LA_GEMM_NO_PERSISTENT"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--no-persistent" in sys.argv:      # an environment override of kernel selection: the -DLA_DEBUG library only
+    from tools._dbglib import use_debug_library
+    use_debug_library()
+    os.environ["LA_GEMM_NO_PERSISTENT"] = "1"
 from labelanything_amd import _lib as L  # noqa: E402
 
 

@@ -11,6 +11,9 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools._dbglib import use_debug_library  # noqa: E402
+
+use_debug_library()      # LA_GEMM_PATH is honoured by the -DLA_DEBUG library only
 
 SHAPES = [(131072, 3072, 768, "lin1", 1), (131072, 768, 3072, "lin2", 2), (131072, 2304, 768, "qkv g", 2),
           (156800, 2304, 768, "qkv w", 2), (131072, 768, 768, "proj", 2), (131072, 768, 3072, "lin2", 1),
