@@ -3,19 +3,24 @@
 with the model's epilogues: interleaved rounds, median / min microseconds, TFLOP/s, and a bitwise comparison of the results."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from labelanything_amd import _lib as L
 
-dt = torch.float16
 M = int(os.environ.get("M", 131072))
 SHAPES = [("lin1", M, 3072, 768), ("lin2", M, 768, 3072), ("qk", M, 1536, 768), ("proj1", M, 768, 768), ("sq8192", 8192, 8192, 8192),
           ("lin1_L", 46886, 4096, 1024), ("edge", 23426, 3072, 768)]
 if os.environ.get("SHAPES"):       # "name:m:n:k,..." - names starting with lin1 get the GELU epilogue, lin2 / proj1 the residual one
     SHAPES = [(t.split(":")[0], *(int(x) for x in t.split(":")[1:])) for t in os.environ["SHAPES"].split(",")]
 rounds = int(os.environ.get("ROUNDS", 7))
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,1").split(",")]
+
+variants = [int(v, 0) for v in os.environ.get("VARIANTS", "0,1").split(",")]      # (0x201: 64-deep loop without the atomic residual epilogue - debug library)
+if any(v > 1 for v in variants):
+    from tools._dbglib import use_debug_library
+    use_debug_library()
 
 
+import torch  # noqa: E402
+from labelanything_amd import _lib as L  # noqa: E402
+
+dt = torch.float16
 LDA = None if not os.environ.get("A_HOT") else 0      # A_HOT=1: row stride 0 - every A row is the same (cache-hot) line set
 
 
