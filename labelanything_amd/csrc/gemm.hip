@@ -1758,17 +1758,6 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
 // from the accumulator layout (a register is 32 consecutive columns of one row per half wave: 128-byte segments).  ksplit > 1 cuts the
 // K range into chunks of kchunk (a multiple of 64) that run as independent tiles: dW[N, K] = dY^T X over 10^4 - 10^5 tokens has
 // 9 - 36 output tiles only, the chunks are what fills the chip.
-// M-side LDS-DMA issue (gemm_t256q_kernel, MSIDE): the issue point behind MFMA number SLOT of a quadrant phase.  The wave whose index
-// within its group equals SLOT & 3 issues its piece here, the others fall through: one scalar compare + branch, inside the asm so that
-// the compiler neither predicates nor moves it.  (M0 is saved / restored once around the phase's MFMA block by the caller.)
-template <int SLOT>
-__device__ __forceinline__ void dma_slot(int wi, const void* src, unsigned voff, unsigned lds_dst) {
-  asm volatile("s_cmp_eq_u32 %[wi], %[k]\n\ts_cbranch_scc0 .Ldslot_%=\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[src]\n.Ldslot_%=:"
-               :
-               : [wi] "s"(wi), [k] "n"(SLOT & 3), [d] "s"(lds_dst), [v] "v"(voff), [src] "s"(src)
-               : "memory", "scc");
-}
-
 static int g_gemm_variant = 1;       // 1: BK = 64 quadrant-phase kernel where it applies, 0: the BK = 32 persistent kernel everywhere
 
 #ifdef LA_DEBUG
@@ -1776,15 +1765,13 @@ constexpr int LA_DBG_NSTAMP = 64;
 __device__ unsigned long long g_dbg_stamps[8 * LA_DBG_NSTAMP];      // [wave][i] = s_memtime << 8 | tag (workgroup 0 of the last stamped launch)
 #endif
 
-template <typename T, int EPI, int MSIDE = 0>
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw,
                                                              int M, int N, int K, LaGemmEpilogue e, int gm, int ksplit, int kchunk) {
   constexpr int BK_ = 64;
   constexpr int OPB = 256 * BK_ * 2;                 // 32 KiB per operand k-tile
   constexpr int BUFB = 2 * OPB;                      // 64 KiB per k-tile
-  // stores per wave of an interior, non-V^T tile (never more than are issued).  EPI 5 issues 128 atomics per wave, more than the 6-bit
-  // counter holds: once they are all issued at most 63 operations are outstanding, i.e. everything older has completed - 4 + 59 = 63
-  constexpr int SDECL = (EPI == 5) ? 59 : (EPI == 3) ? 32 : 16;
+  constexpr int SDECL = (EPI == 3) ? 32 : 16;        // stores per wave of an interior, non-V^T tile (never more than are issued)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef LA_DEBUG
   const bool stamps = ((gm >> 10) & 1) && blockIdx.x == 0;      // seam timeline of workgroup 0 (la_dbg_gemm_stamps)
@@ -1844,14 +1831,11 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
       }
   };
   const unsigned lds0 = lds_addr_of(smem);
-  auto dma_piece = [&](int q, int i, int kt, int buf) {
+  auto dma_q = [&](int q, int kt, int buf) {
     const bool isw = (q == 1 || q == 2);
     const T* src = isw ? Wt + kb_issue + kt * BK_ : A + a_koff(e, kb_issue + kt * BK_);
-    dma16s(src, soff[q][i], lds0 + buf * BUFB + (isw ? OPB : 0) + piece_row0(q, i) * 128);
-  };
-  auto dma_q = [&](int q, int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma_piece(q, i, kt, buf);
+    for (int i = 0; i < 2; ++i) dma16s(src, soff[q][i], lds0 + buf * BUFB + (isw ? OPB : 0) + piece_row0(q, i) * 128);
   };
 
   f32x16 acc[4][2];
@@ -1898,26 +1882,17 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
       const bool last = kt + 1 == nk;
       const bool feed = !last || more;               // a k-tile follows in the stream
       if (last && more) plan(next, m0n, n0n, kbn, nkn);        // every piece of this tile is on its way: the offsets now describe the next tile
-      const int ktn_ = last ? 0 : kt + 1;                      // (M-side issue: the k-tile this one's pieces belong to, its two source bases)
-      const T* srcA = A + a_koff(e, kb_issue + ktn_ * BK_);
-      const T* srcW = Wt + kb_issue + ktn_ * BK_;
       // counted wait at the end of phase q (q = 3, 0, 1); see the header
-      // (M-side issue, MSIDE: group 1 retires in its L interval, i.e. BEFORE it issues the phase's two pieces - two fewer outstanding)
       auto retire = [&](int q) {
         if (q == 3) {
-          if (feed) {
-            if (MSIDE && grp == 1) dma_wait<2>();
-            else dma_wait<4>();
-          }
+          if (feed) dma_wait<4>();
         } else if (!feed) {
           if (q == 0) dma_wait<2>();
           else dma_wait<0>();
         } else if (seam_slack && kt == 0) {
-          if (MSIDE && grp == 1) dma_wait<2 + SDECL>();
-          else dma_wait<4 + SDECL>();
+          dma_wait<4 + SDECL>();
         } else {
-          if (MSIDE && grp == 1) dma_wait<2>();
-          else dma_wait<4>();
+          dma_wait<4>();
         }
       };
       auto phase = [&](auto qc) {
@@ -1934,7 +1909,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
           read_w(buf, 0);                            // W_j0 again: 4 reads in the otherwise empty L(q3) instead of 16 registers held
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!MSIDE && feed) dma_q(q, last ? 0 : kt + 1, buf ^ 1);
+        if (feed) dma_q(q, last ? 0 : kt + 1, buf ^ 1);
         if (grp == 1 && q != 2) retire(q);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1942,46 +1917,10 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
         // ---- M ----------------------------------------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
         constexpr int ib = (q >= 2) ? 2 : 0, jb = (q == 1 || q == 2) ? 1 : 0;
-        if (!MSIDE) {
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[ib + i][jb] = Half16<T>::mfma32(af[i][ks], wf[ks], acc[ib + i][jb]);
-        } else if (!feed) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[ib + i][jb] = Half16<T>::mfma32(af[i][ks], wf[ks], acc[ib + i][jb]);
-        } else {
-          // M-side issue: the vector-memory front end takes one 1 KiB piece per ~33 cycles CU-wide (tools/micro/dma_bw.hip) and a
-          // wave stalls at issue until its piece is accepted.  Eight pieces at the head of an L interval therefore hold the barrier
-          // for ~264 cycles whatever the reads do.  Here the wave that MULTIPLIES issues its two pieces, one behind its MFMA number
-          // wi and one behind number wi + 4: the four waves of the group (one per SIMD) take turns, a piece reaches the front end
-          // every 32 cycles, and its issue sits in the shadow of the 32-cycle MFMA just started.
-          const T* srcq = (q == 1 || q == 2) ? srcW : srcA;
-          const unsigned ldsq = lds0 + (buf ^ 1) * BUFB + ((q == 1 || q == 2) ? OPB : 0);
-          const unsigned d0 = __builtin_amdgcn_readfirstlane(ldsq + piece_row0(q, 0) * 128), d1 = __builtin_amdgcn_readfirstlane(ldsq + piece_row0(q, 1) * 128);
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
-          auto step = [&](auto sc) {
-            constexpr int SL = decltype(sc)::value, ks = SL >> 1, i = SL & 1;
-            acc[ib + i][jb] = Half16<T>::mfma32(af[i][ks], wf[ks], acc[ib + i][jb]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (MSIDE == 1) dma_slot<SL>(wi, srcq, soff[q][SL >> 2], SL < 4 ? d0 : d1);
-            else if (SL == 1 || SL == 5)           // MSIDE 2: every wave at the same two issue points, no branch (isolates the stagger)
-              asm volatile("s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[src]" ::[d] "s"(SL < 4 ? d0 : d1), [v] "v"(soff[q][SL >> 2]), [src] "s"(srcq) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-          };
-          step(std::integral_constant<int, 0>{});
-          step(std::integral_constant<int, 1>{});
-          step(std::integral_constant<int, 2>{});
-          step(std::integral_constant<int, 3>{});
-          step(std::integral_constant<int, 4>{});
-          step(std::integral_constant<int, 5>{});
-          step(std::integral_constant<int, 6>{});
-          step(std::integral_constant<int, 7>{});
-          asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
-        }
+          for (int i = 0; i < 2; ++i) acc[ib + i][jb] = Half16<T>::mfma32(af[i][ks], wf[ks], acc[ib + i][jb]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (grp == 0 && q != 2) retire(q);
@@ -2014,39 +1953,6 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
             unsafeAtomicAdd(op + 32, acc[i][1][r]);
           }
         }
-    } else if (EPI == 5) {
-      // (measurement library only - see launch_t256) in-place residual (out32 == res): x += A.W^T + bias as fp32 atomics straight from the accumulator layout (a register is 32
-      // consecutive columns of one row per half wave: 128-byte segments).  Every element is touched by exactly one atomic, so the
-      // result is res + (acc + bias) - bit-identical to the read-modify-write form - but no wave waits for the residual to come
-      // back from HBM, nothing goes through the slab, and the L2 does the read-modify-write behind the next tile's main loop.
-      const int fr_ = lane & 31, fh_ = lane >> 5;
-      const float b0 = e.bias ? e.bias[n0 + wi * 64 + fr_] : 0.f, b1 = e.bias ? e.bias[n0 + wi * 64 + 32 + fr_] : 0.f;
-      asm volatile("" ::"v"(b0), "v"(b1));           // (consumed here: see epilogue_wave)
-      const int rbase = m0 + grp * 128;
-      const unsigned loff = (unsigned)(4 * fh_) * (unsigned)e.ld32 + (unsigned)fr_;
-      float* tbase = e.out32 + (size_t)rbase * e.ld32 + n0 + wi * 64;          // wave-uniform
-      if (rbase + 128 <= M) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float* op = tbase + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * e.ld32 + loff;
-            unsafeAtomicAdd(op, acc[i][0][r] + b0);
-            unsafeAtomicAdd(op + 32, acc[i][1][r] + b1);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-            if (rbase + rr + 4 * fh_ < M) {
-              float* op = tbase + (size_t)rr * e.ld32 + loff;
-              unsafeAtomicAdd(op, acc[i][0][r] + b0);
-              unsafeAtomicAdd(op + 32, acc[i][1][r] + b1);
-            }
-          }
-      }
     } else {
       epilogue_wave<T, (EPI >= 4 ? 1 : EPI)>(slab, rtab, acc, m0 + grp * 128, n0 + wi * 64, n0, M, e, lane, nostore);
     }
@@ -2070,17 +1976,11 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
 }
 
 
-constexpr int LA_GEMM_MSIDE = 0;      // product default of the LDS-DMA issue placement (0: L side; 1 / 2: M-side experiments, see the kernel)
-
-template <typename T, int EPI, int MSIDE = LA_GEMM_MSIDE>
+template <typename T, int EPI>
 static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-#ifdef LA_DEBUG
-  if (MSIDE == 0 && EPI == 1 && (g_gemm_variant & 0x800)) return launch_t256q<T, EPI, 1>(A, lda, W, ldw, M, N, K, e, st);    // A/B: bits 11 / 12,
-  if (MSIDE == 0 && EPI == 1 && (g_gemm_variant & 0x1000)) return launch_t256q<T, EPI, 2>(A, lda, W, ldw, M, N, K, e, st);   // 16-bit epilogue only
-#endif
   constexpr int LDS = 2 * 65536 + 8 * 2048 + 8 * 512;       // two k-tile buffers + 2 KiB slab per wave + row tables: 148 KiB
   static unsigned long long attr_mask = 0;
-  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256q_kernel<T, EPI, MSIDE>), LDS, attr_mask);
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256q_kernel<T, EPI>), LDS, attr_mask);
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
@@ -2110,7 +2010,7 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
   int grid = ntiles < ncu ? ntiles : ncu;
   static const char* genv = la_dbg_env("LA_KSPLIT_GRID");      // debugging: workgroups launched (0 = one per tile)
   if (EPI == 4 && genv) grid = atoi(genv) > 0 ? atoi(genv) : ntiles;
-  hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI, MSIDE>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
+  hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
                      reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800500), ksplit, kchunk);
 }
 
@@ -2158,17 +2058,8 @@ static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, i
   if (al && scatter) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) return launch_t256p<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_NONE && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (!e.res || (e.ldr % 4) == 0)) {
-    // experiment: residual added IN PLACE (the encoder's proj / lin2: res == out32) with fp32 atomics from the accumulator layout
-    // (EPI 5 of the 64-deep kernel) instead of the read-modify-write through the slab
-#ifdef LA_DEBUG
-    // measured and rejected (profiles/r04_notes.md 1): proj 263 -> 367 us, lin2 671 -> 720 us - the L2's atomic units take ~150 cycles
-    // per 256-byte atomic instruction and the next tile's operand stream queues behind them.  Kept in the measurement library only
-    // (la_gemm_variant bit 9).
-    const bool inplace = NPL == 1 && e.res != nullptr && static_cast<const void*>(e.res) == static_cast<const void*>(e.out32) &&
-                         e.ldr == e.ld32 && !e.out16 && (g_gemm_variant & 0xff) == 1 && (g_gemm_variant & 0x200) && (K % 64) == 0 &&
-                         K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0);
-    if (inplace) return launch_t256q<T, 5>(A, lda, W, ldw, M, N, K, e, st);
-#endif
+    // (fp32 atomics from the accumulator layout instead of the read-modify-write through the slab were measured in round 4 and are
+    // slower: profiles/r04_notes.md 1)
     return launch_t256p<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);
   }
   if (plain && e.act == LA_ACT_NONE && !e.res && !e.out32 && e.out16) launch_t256_epi<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
@@ -2490,7 +2381,7 @@ static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, in
 extern "C" int la_gemm_variant(int v) {
   const int prev = la::g_gemm_variant;
 #ifdef LA_DEBUG
-  if (v >= 0) la::g_gemm_variant = v;       // bit 8 no stores, bit 9 atomic residual epilogue, bit 10 seam stamps, bit 11 other DMA placement, bit 23 no epilogue
+  if (v >= 0) la::g_gemm_variant = v;       // bit 8 no stores, bit 10 seam stamps (la_dbg_gemm_stamps), bit 23 no epilogue
 #else
   if (v >= 0) la::g_gemm_variant = v & 1;       // the product library only knows the two bit-identical main loops
 #endif
