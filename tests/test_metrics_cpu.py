@@ -70,3 +70,24 @@ def test_out_of_range_labels_raise():
         metrics_from_state(torch.zeros(3, 3, dtype=torch.int64), torch.zeros(2, 2, dtype=torch.int64), invalid=2)
     with pytest.raises(RuntimeError):
         MO.confusion_matrix(np.array([0, 5]), np.array([0, 1]), 3)
+
+
+def test_iou_fixture_from_the_reference_metric_classes():
+    """tests/golden/metrics_iou.* (tools/make_golden_metrics_iou.py): the REFERENCE's StrictMeanIoU / MeanIoU /
+    DistributedBinaryJaccardIndex (utils/metrics.py:28-53, imported and executed) on seeded label maps over several ``update`` calls.
+    Their torchmetrics base classes are a stand-in that follows the published confusion-matrix / ``_jaccard_index_reduce`` algorithm
+    (torchmetrics is not installable here), so this pins the reference-specific arithmetic - the background-IoU correction, the
+    ``> 0 -> 1`` clamp, ignore_index = -100, the constructor arguments of run.py:654-669 - on reference-produced numbers."""
+    t = load_file(os.path.join(GOLD, "metrics_iou.safetensors"))
+    meta = json.load(open(os.path.join(GOLD, "metrics_iou.json")))
+    for ci, case in enumerate(meta["cases"]):
+        k = case["num_classes"]
+        cm = sum(MO.confusion_matrix(t[f"c{ci}_preds{u}"].numpy(), t[f"c{ci}_gt{u}"].numpy(), k) for u in range(case["updates"]))
+        cb = sum(MO.binary_confusion_matrix(t[f"c{ci}_preds{u}"].numpy(), t[f"c{ci}_gt{u}"].numpy()) for u in range(case["updates"]))
+        assert np.array_equal(cm, t[f"c{ci}_confmat"].numpy()) and np.array_equal(cb, t[f"c{ci}_confbin"].numpy())
+        got = metrics_from_state(t[f"c{ci}_confmat"], t[f"c{ci}_confbin"])
+        for name in ("mIoU", "BmIoU", "FBIoU"):
+            assert abs(got[name] - case[name]) < 1e-6, (ci, name, got[name], case[name])
+        assert abs(MO.strict_mean_iou(cm) - case["mIoU"]) < 1e-6 and abs(MO.binary_jaccard(cb) - case["FBIoU"]) < 1e-6
+        for c in case["absent"]:
+            assert cm[c].sum() == 0 and cm[:, c].sum() == 0

@@ -109,3 +109,21 @@ def test_full_resolution_properties_and_fused_argmax_feed():
     assert np.array_equal(cm.sum(1), np.bincount(gt[keep].numpy(), minlength=k))
     assert np.array_equal(cm.sum(0), np.bincount(pred[keep].numpy(), minlength=k))
     assert np.array_equal(cm, MO.confusion_matrix(pred.numpy(), gt.numpy(), k))
+
+
+def test_meter_reproduces_the_reference_metric_classes():
+    """SegmentationMeter (la_confmat_update + metrics_from_state) on the label maps of tests/golden/metrics_iou.* must give the confusion
+    matrices and the mIoU / BmIoU / FBIoU values the REFERENCE's metric classes produced (tools/make_golden_metrics_iou.py)."""
+    import json
+    from safetensors.torch import load_file
+    t = load_file(os.path.join(GOLD, "metrics_iou.safetensors"))
+    meta = json.load(open(os.path.join(GOLD, "metrics_iou.json")))
+    for ci, case in enumerate(meta["cases"]):
+        m = SegmentationMeter(case["num_classes"])
+        for u in range(case["updates"]):
+            m.update(t[f"c{ci}_preds{u}"].long().cuda(), t[f"c{ci}_gt{u}"].long().cuda())
+        k = case["num_classes"]
+        assert torch.equal(m.confmat.view(k, k).cpu(), t[f"c{ci}_confmat"]) and torch.equal(m.confbin.view(2, 2).cpu(), t[f"c{ci}_confbin"])
+        got = m.compute()
+        for name in ("mIoU", "BmIoU", "FBIoU"):
+            assert abs(got[name] - case[name]) < 1e-6, (ci, name, got[name], case[name])
