@@ -67,18 +67,30 @@ class FlatAdamW:
     def zero_grad(self) -> None:
         self.grad.zero_()
 
-    def step(self, all_reduce: bool = True, active=None) -> None:
+    def step(self, all_reduce: bool = True, active=None, reducer=None) -> None:
         """Average ``self.grad`` over the data-parallel ranks (if a process group is up) and apply one AdamW update.
 
         active: optional per-parameter flags "this tensor received a gradient in this step".  torch.optim.AdamW skips tensors whose
         ``.grad`` is None - no moment update and NO weight decay - which is what happens to the parameters the reference's forward
         never reaches (DDP ``find_unused_parameters``, experiment/run.py:123); contiguous runs of active tensors are updated with
-        one launch each (one launch in the usual case: never-used tensors are kept at the tail by LamTrainer)."""
+        one launch each (one launch in the usual case: never-used tensors are kept at the tail by LamTrainer).
+
+        reducer: a ``parallel.BucketedGradReducer`` over ``self.grad`` - buckets that were launched during / right after the backward
+        pass are waited for one at a time, each followed by the AdamW launches of ITS tensors, so the collective of the next bucket
+        overlaps the optimizer kernel of this one; without it the whole buffer is reduced by one collective here."""
         world = 1
         if all_reduce and torch.distributed.is_available() and torch.distributed.is_initialized():
             world = torch.distributed.get_world_size()
-            sum_over_ranks(self.grad)
+            if reducer is None:
+                sum_over_ranks(self.grad)
+        if reducer is None or not all_reduce:
+            bucket_bounds = [(0, self.grad.numel())]
+            reducer = None
+        else:
+            bucket_bounds = reducer.bounds
         if self.keep_reduced_grad:
+            if reducer is not None:
+                reducer.finish_all()
             self.reduced_grad = self.grad / float(world)
         self.steps += 1
         if active is None:
@@ -103,7 +115,12 @@ class FlatAdamW:
         if cur is not None:
             spans.append(tuple(cur))
         factor = constant_with_warmup(self.sched_steps, self.num_warmup_steps) if self.num_warmup_steps else 1.0
-        for a, b, t, lr in spans:
-            L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr * factor, self.betas[0], self.betas[1],
-                         self.eps, self.weight_decay, t, 1.0 / world)
+        for bi, (ba, bb) in enumerate(bucket_bounds):
+            if reducer is not None:
+                reducer.finish(bi)                   # this stream waits for bucket bi only; later buckets keep travelling
+            for a, b, t, lr in spans:
+                a, b = max(a, ba), min(b, bb)        # (the update is element-wise: a span cut at a bucket boundary is the same update)
+                if a < b:
+                    L.adamw_step(self.flat[a:b], self.grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], lr * factor, self.betas[0],
+                                 self.betas[1], self.eps, self.weight_decay, t, 1.0 / world)
         self.sched_steps += 1

@@ -62,3 +62,104 @@ def any_over_ranks(flags: Sequence[bool], device=None) -> List[bool]:
     t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32, device=device)
     _all_reduce(t, dist.ReduceOp.MAX)
     return [bool(v) for v in t.cpu().tolist()]
+
+
+class BucketedGradReducer:
+    """SUM all-reduce of one flat gradient buffer in BUCKETS (contiguous element ranges) that are launched as soon as their gradients
+    are final and waited for one by one, so that the collective of bucket i + 1 runs while the optimizer kernel of bucket i does
+    (SURVEY 8e "overlapped with the tail of backward"; the reference gets the same from DDP's gradient buckets,
+    experiment/run.py:122-131,172).
+
+    * RCCL ("nccl" backend): ``launch`` enqueues the collective from a side stream that first waits for the caller's stream, and
+      returns at once; ``finish`` makes the caller's stream wait for it.  No host synchronisation anywhere.
+    * ``staged=True`` reduces a COPY of the bucket: used for the bucket launched from INSIDE the backward pass (the decoder-side
+      gradients, final before the encoder backward starts).  If a gradient of that bucket is written after the launch
+      (``invalidate``), ``finish`` drops the copy and reduces the bucket in place instead - the result is always the sum of the final
+      gradients.
+    * gloo (CPU tests, two processes on one GPU) has no device path: buckets are reduced synchronously in ``finish``.
+    Every element is reduced exactly once per ``begin`` / ``finish_all`` cycle; with two ranks the result is bit-identical to one
+    collective over the whole buffer (a + b either way)."""
+
+    def __init__(self, grad: torch.Tensor, bounds: Sequence[Sequence[int]], single_rank_collectives: bool = False):
+        """single_rank_collectives: issue the collectives also in a process group of ONE rank (they are identities there) - lets a
+        one-GPU box run the RCCL side-stream choreography (tests)."""
+        self.single_rank_collectives = bool(single_rank_collectives)
+        if grad.dim() != 1:
+            raise ValueError("flat 1-D gradient buffer expected")
+        self.grad = grad
+        self.bounds = [(int(a), int(b)) for a, b in bounds]
+        pos = 0
+        for a, b in self.bounds:
+            if a != pos or b <= a:
+                raise ValueError("buckets must tile the buffer in order")
+            pos = b
+        if pos != grad.numel():
+            raise ValueError("buckets must cover the whole buffer")
+        self.side = torch.cuda.Stream(grad.device) if grad.is_cuda else None
+        self._work = {}          # bucket -> (work handle | None, staging tensor | None)
+        self._stale = set()      # staged buckets whose gradients changed after the launch
+        self._done = set()
+
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.single_rank_collectives)
+
+    def _async_ok(self) -> bool:
+        return self.active() and not (self.grad.is_cuda and dist.get_backend() == "gloo")
+
+    def begin(self) -> None:
+        """Start of a reduction cycle (after ``zero_grad``): nothing launched, nothing reduced."""
+        self._work.clear()
+        self._stale.clear()
+        self._done.clear()
+
+    def launched(self, i: int) -> bool:
+        return i in self._work or i in self._done
+
+    def launch(self, i: int, staged: bool = False) -> None:
+        """The gradients of bucket i are final (staged: probably final): start their all-reduce."""
+        if self.launched(i):
+            raise RuntimeError(f"bucket {i} was already reduced in this cycle (a second micro-step after a synchronising one?)")
+        if not self._async_ok():
+            return                                    # reduced synchronously in finish()
+        a, b = self.bounds[i]
+        buf = self.grad[a:b]
+        if staged:
+            buf = buf.clone()
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.grad.device))
+            with torch.cuda.stream(self.side):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        self._work[i] = (work, buf if staged else None)
+
+    def invalidate(self, i: int) -> None:
+        """A gradient inside staged bucket i was written after its launch."""
+        if i in self._work and self._work[i][1] is not None:
+            self._stale.add(i)
+
+    def finish(self, i: int) -> None:
+        """Bucket i holds the sum over the ranks when the caller's stream reaches this point."""
+        if i in self._done:
+            return
+        a, b = self.bounds[i]
+        if i in self._work:
+            work, staging = self._work.pop(i)
+            work.wait()
+            if staging is None:
+                self._done.add(i)
+                return
+            if i not in self._stale:
+                self.grad[a:b].copy_(staging)
+                self._done.add(i)
+                return
+        if self.active():
+            if dist.get_world_size() > 1:
+                sum_over_ranks(self.grad[a:b])
+            else:
+                dist.all_reduce(self.grad[a:b], op=dist.ReduceOp.SUM)
+        self._done.add(i)
+
+    def finish_all(self) -> None:
+        for i in range(len(self.bounds)):
+            self.finish(i)

@@ -324,11 +324,14 @@ class LamTrainer:
 
     def __init__(self, lam: Lam, lr: float = 5e-5, weight_decay: float = 1e-2, betas=(0.9, 0.999), eps: float = 1e-8,
                  num_warmup_steps: int = 0, loss: Optional[FocalLossDevice] = None, train_encoder: bool = False,
-                 backbone_lr: Optional[float] = None):
+                 backbone_lr: Optional[float] = None, encoder_buckets: int = 4):
         """backbone_lr: learning rate of the ``image_encoder.*`` tensors (the reference's ``backbone_lr`` parameter group,
         models/lam.py:340-346; needs train_encoder=True - with a frozen backbone the reference raises as well).
         train_encoder=False: ``get_learnable_params({'freeze_backbone': True})`` - the image encoder is frozen (and absent from
-        the flat buffer).  train_encoder=True: every parameter trains, as with parameters/trainval/coco20i/mae_noembs.yaml (no
+        the flat buffer).  encoder_buckets: the encoder's share of the flat gradient (345 MB for ViT-B) is all-reduced in this many
+        pieces, each followed by its AdamW launch (``parallel.BucketedGradReducer``); the decoder-side gradients (40 MB) are one more
+        bucket, launched from inside the backward pass - they are final when the encoder backward starts.
+        train_encoder=True: every parameter trains, as with parameters/trainval/coco20i/mae_noembs.yaml (no
         ``freeze_backbone``: models/lam.py:347 returns ``self.parameters()``); needs an HF ViT encoder (train_encoder.py)."""
         if lam._device().type != "cuda":
             raise RuntimeError("LamTrainer needs the model on an MI355X (there is no CPU path)")
@@ -358,12 +361,33 @@ class LamTrainer:
         # accumulates over substitution steps, experiment/run.py:503-527) and, in apply_update, over the ranks
         self._touched = [False] * len(named)
         for i, (_, p) in enumerate(named):
-            p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._touched.__setitem__(_i, True))
+            p.register_post_accumulate_grad_hook(lambda _p, _i=i: self._on_grad(_i))
         lrs = None if backbone_lr is None else [backbone_lr if "image_encoder" in k else lr for k, _ in named]
         self.opt = FlatAdamW([p for _, p in named], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                              num_warmup_steps=num_warmup_steps, lrs=lrs)
         for (_, p), gv in zip(named, self.opt.grad_views):
             p.grad = gv                      # autograd accumulates straight into the flat gradient buffer
+        # gradient buckets in buffer order: the encoder tensors (first in named_parameters order) in ``encoder_buckets`` pieces cut at
+        # tensor boundaries, everything else (neck, prompt encoder, mask decoder, dead tail) as the last one
+        sizes = [p.numel() for _, p in named]
+        n_enc = sum(1 for k, _ in named if k.startswith("image_encoder."))
+        if any(k.startswith("image_encoder.") for k, _ in named[n_enc:]):
+            raise RuntimeError("image_encoder tensors are expected to lead the parameter order")
+        enc_total, bounds, off, cut = sum(sizes[:n_enc]), [], 0, 0
+        nb = max(1, int(encoder_buckets))
+        for i in range(n_enc):
+            off += sizes[i]
+            if off - cut >= enc_total / nb and off < enc_total:
+                bounds.append((cut, off))
+                cut = off
+        if enc_total > cut:
+            bounds.append((cut, enc_total))
+        self._enc_buckets = list(range(len(bounds)))
+        self._dec_bucket = len(bounds)
+        bounds.append((enc_total, sum(sizes)))
+        from .parallel import BucketedGradReducer
+        self.reducer = BucketedGradReducer(self.opt.grad, bounds)
+        self._dec_index0 = n_enc                 # parameters [n_enc, ...) live in the decoder bucket
         self.crit = loss or FocalLossDevice()
         self.engine = lam.engine()           # host-side helpers + the frozen encoder (its packed weights never change)
         self.graph = DecoderGraph(lam, self.engine)
@@ -375,8 +399,19 @@ class LamTrainer:
             self._anchor = torch.zeros(1, device=lam._device(), requires_grad=True)
             self._enc_idx = [i for i, k in enumerate(self.names) if k.startswith("image_encoder.")]
 
-    def forward_backward(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
+    def _on_grad(self, i: int) -> None:
+        self._touched[i] = True
+        if i >= self._dec_index0:
+            self.reducer.invalidate(self._dec_bucket)      # (only matters if the bucket's staged reduction has already been launched)
+
+    def forward_backward(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0, sync: bool = False) -> Dict[str, Tensor]:
+        """sync=True: this is the LAST micro-step before ``apply_update`` (DDP's "not no_sync"): gradient buckets are handed to the
+        all-reduce as they become final - the decoder-side bucket when the encoder backward starts, the encoder buckets right behind
+        the backward pass - and ``apply_update`` must be the next call.  sync=False (default): gradients only accumulate; whatever has
+        not been reduced by then is reduced inside ``apply_update``."""
         lam = self.lam
+        if any(self.reducer.launched(i) for i in range(len(self.reducer.bounds))):
+            raise RuntimeError("forward_backward after a synchronising micro-step: call apply_update() first")
         with torch.cuda.device(lam._device()):
             with torch.no_grad():
                 inp, _ = lam._prepare(batch, with_post=False, eng=self.engine)
@@ -404,14 +439,23 @@ class LamTrainer:
                 e_rows = encode_trainable(self.enc_graph, im.flatten(0, 1), self._anchor)
                 for i in self._enc_idx:
                     self._touched[i] = True
+                # the encoder's backward node is the last one autograd runs (it was created first): every decoder-side gradient has
+                # been accumulated by then, so their bucket starts travelling under the encoder backward (a copy is reduced; a
+                # gradient that does arrive later invalidates it and the bucket is reduced in place at the end)
+                self.enc_graph.before_backward = (lambda: self.reducer.launch(self._dec_bucket, staged=True)) if sync else None
             out = self.graph.forward(e_rows, b, n, g, inp, batch["dims"], neck_input=True)
             loss = _FocalObjective.apply(out["logits"], gt.to(lam._device()), self.crit)
             (loss / loss_normalizer).backward()
+            if sync:                                  # everything is final now: the remaining buckets leave in buffer order
+                for i in range(len(self.reducer.bounds)):
+                    if not self.reducer.launched(i):
+                        self.reducer.launch(i)
         return {"loss": loss.detach(), "logits": out["logits"].detach(), "class_examples_embeddings": out["class_examples_embeddings"].detach()}
 
     def zero_grad(self) -> None:
         self.opt.zero_grad()
         self._touched = [False] * len(self.names)
+        self.reducer.begin()
 
     def apply_update(self) -> None:
         """SUM all-reduce of the flat gradient over the ranks + the AdamW launches over the tensors that received a gradient ON ANY
@@ -420,7 +464,8 @@ class LamTrainer:
         used-parameter bitmap the same way, experiment/run.py:123) - otherwise replicas of ``point_embeddings.*``,
         ``not_a_point_embed``, ``mask_downscaling.*`` ... would step on some ranks only and drift apart."""
         active = any_over_ranks(self._touched, device=self.lam._device())
-        self.opt.step(active=active)
+        self.opt.step(active=active, reducer=self.reducer)
+        self.reducer.begin()
         self._touched = [False] * len(self.names)
         # packed / converted weight copies of the inference engine are stale now; the trainer's own engine only serves the frozen
         # encoder and host-side helpers, so nothing of it is re-packed until the model is next used for inference; a trainable
@@ -431,6 +476,6 @@ class LamTrainer:
 
     def step(self, batch: Dict[str, Any], gt: Tensor, loss_normalizer: float = 1.0) -> Dict[str, Tensor]:
         self.zero_grad()
-        res = self.forward_backward(batch, gt, loss_normalizer)
+        res = self.forward_backward(batch, gt, loss_normalizer, sync=True)
         self.apply_update()
         return res

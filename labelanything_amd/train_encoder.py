@@ -53,6 +53,7 @@ class HfEncoderGraph:
         self.precise = tuple(lam.precise) if precise is None else tuple(precise)
         self._eng = None
         self._eng_stale = True
+        self.before_backward = None        # optional callback at the head of ``backward`` (LamTrainer: launch the decoder-side gradient bucket)
         self.w: Dict[str, Tensor] = {k: v for k, v in lam.state_dict(keep_vars=True).items() if k.startswith("image_encoder.")}
         missing = [k for k, v in self.w.items() if v.is_floating_point() and k not in grads]
         if missing:
@@ -219,6 +220,8 @@ class HfEncoderGraph:
     @torch.no_grad()
     def backward(self, d_out: Tensor) -> None:
         """d_out: gradient w.r.t. ``forward``'s result [Bn * hw, E] fp32.  Adds every encoder parameter's gradient to ``grads``."""
+        if self.before_backward is not None:
+            self.before_backward()
         amax = float(d_out.abs().max())
         if not math.isfinite(amax):
             raise FloatingPointError("non-finite gradient at the encoder output")

@@ -121,3 +121,79 @@ def test_flat_gradient_all_reduce_two_ranks():
     expect = sum(torch.randn(1000, generator=torch.Generator().manual_seed(7 + r)) for r in range(2)) / 2
     assert res[0][1] == res[1][1]
     assert float((torch.tensor(res[0][1]) - expect).abs().max()) < 1e-6
+
+
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from labelanything_amd.parallel import BucketedGradReducer, sum_over_ranks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(70 + rank)
+    base = torch.randn(10_000, generator=g)
+    single = base.clone()
+    sum_over_ranks(single)                                   # the one-collective form of round 3
+    # (a) four in-place buckets + one STAGED bucket launched early, all waited in order
+    grad = base.clone()
+    red = BucketedGradReducer(grad, [(0, 2000), (2000, 4100), (4100, 6000), (6000, 8192), (8192, 10_000)])
+    red.begin()
+    red.launch(4, staged=True)                               # "decoder" bucket from inside the backward pass
+    for i in range(4):
+        red.launch(i)                                        # "encoder" buckets right behind it
+    for i in range(5):
+        red.finish(i)
+    same_a = torch.equal(grad, single)
+    # (b) a gradient written into the staged bucket AFTER its launch: the copy is dropped, the bucket is reduced in place
+    grad2 = base.clone()
+    red2 = BucketedGradReducer(grad2, [(0, 8192), (8192, 10_000)])
+    red2.begin()
+    red2.launch(1, staged=True)
+    grad2[9000:9100] += 1.0 + rank                           # late accumulation (both ranks, different values)
+    red2.invalidate(1)
+    red2.launch(0)
+    red2.finish_all()
+    expect2 = base.clone()
+    expect2[9000:9100] += 1.0 + rank
+    sum_over_ranks(expect2)
+    same_b = torch.equal(grad2, expect2)
+    # (c) nothing launched before the optimizer step: finish_all reduces everything; a double launch is refused
+    grad3 = base.clone()
+    red3 = BucketedGradReducer(grad3, [(0, 5000), (5000, 10_000)])
+    red3.begin()
+    red3.finish_all()
+    same_c = torch.equal(grad3, single)
+    red3.begin()
+    red3.launch(0)
+    try:
+        red3.launch(0)
+        refused = False
+    except RuntimeError:
+        refused = True
+    red3.finish_all()
+    q.put((rank, same_a, same_b, same_c, refused))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_all_reduce_equals_the_single_collective():
+    """the flat gradient reduced in buckets (one of them staged and launched early, as LamTrainer does for the
+    decoder-side gradients) is bit-identical to the single collective on two ranks, also when a late gradient invalidates the staged
+    copy."""
+    import pytest
+    import torch.multiprocessing as mp
+    from labelanything_amd.parallel import BucketedGradReducer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True, True, True), (1, True, True, True, True)]
+    with pytest.raises(ValueError):
+        BucketedGradReducer(torch.zeros(10), [(0, 4), (5, 10)])        # buckets must tile the buffer
+    one = BucketedGradReducer(torch.ones(10), [(0, 10)])               # no process group: everything is a no-op
+    one.begin()
+    one.launch(0, staged=True)
+    one.finish_all()
+    assert torch.equal(one.grad, torch.ones(10))
