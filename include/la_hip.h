@@ -332,6 +332,26 @@ int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T
 int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
                 float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream);
 
+/* ---- backward of the SAM ViTDet attention (window / global attention with the decomposed relative-position bias,
+ * /root/reference/label_anything/models/image_encoder.py:200-255,340-376; trainable through models/lam.py:321-347 when nothing is frozen) ---- */
+
+/* la_attn_fwd in rel-pos mode with the terms from la_relpos_terms (relh, relw fp32 [B*heads, T, G], T == G*G, G <= 64) that also writes
+ * the log2-domain log-sum-exp of every query row like la_attn_fwd_lse: the saved-activation forward of a trainable SAM block. */
+int la_attn_fwd_relpos_lse(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, float* lse, int B, int heads,
+                           int T, int Tpad, int G, int E, float scale, int dt, void* stream);
+
+/* la_attn_bwd with S = scale q.k + relh[q][key / G] + relw[q][key % G] (G <= 32, or G == 64): the same outputs, plus
+ * drelh[q][kh] = sum_kw dS[q][(kh, kw)] and drelw[q][kw] = sum_kh dS[q][(kh, kw)] (fp32 [B*heads, T, G], every entry written). */
+int la_attn_bwd_relpos(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
+                       float* dvec, void* dqkv, const float* relh, const float* relw, float* drelh, float* drelw, int B, int heads, int T,
+                       int Tpad, int G, int E, float scale, int dt, void* stream);
+
+/* Backward of the rel-pos terms themselves (relh[q][kh] = q . Rh[qy - kh + G - 1], relw[q][kw] = q . Rw[qx - kw + G - 1], q unscaled;
+ * image_encoder.py:340-376): dq rows of dqkv += the terms' share (read-modify-write of the 16-bit rows la_attn_bwd_relpos wrote);
+ * dtabh / dtabw fp32 [(2G - 1), 64] += gscale * table gradients (atomics over images, heads and rows).  tabh / tabw fp32 [(2G - 1), 64]. */
+int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, const float* drelw, const float* tabh, const float* tabw, float* dtabh,
+                  float* dtabw, int B, int heads, int G, int E, float gscale, int dt, void* stream);
+
 /* dst = scale * src, n contiguous elements, between LA_F32 and LA_F16 / LA_BF16 (either direction) or LA_F32 -> LA_F32 (in place allowed). */
 int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float scale, void* stream);
 

@@ -61,6 +61,7 @@ EXPORTS = [
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
+    "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd",
 ]
 
 
@@ -441,6 +442,27 @@ def attn_bwd(qkv, out16, dout16, kt, qt, dot, lse, dvec, dqkv, b: int, heads: in
     _check(lib().la_attn_bwd(_ptr(qkv), _ptr(out16), _ptr(dout16), _ptr(kt), _ptr(qt), _ptr(dot), _ptr(lse), _ptr(dvec), _ptr(dqkv),
                              C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad), C.c_int(e), C.c_float(scale), C.c_int(dt_of(qkv)),
                              _stream()), "la_attn_bwd")
+
+
+def attn_fwd_relpos_lse(qkv, vt, out16, relh, relw, lse, b: int, heads: int, t: int, tpad: int, g: int, e: int, scale: float) -> None:
+    _dev(qkv)
+    _check(lib().la_attn_fwd_relpos_lse(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), _ptr(lse), C.c_int(b), C.c_int(heads),
+                                        C.c_int(t), C.c_int(tpad), C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(dt_of(qkv)), _stream()),
+           "la_attn_fwd_relpos_lse")
+
+
+def attn_bwd_relpos(qkv, out16, dout16, kt, qt, dot, lse, dvec, dqkv, relh, relw, drelh, drelw, b: int, heads: int, t: int, tpad: int, g: int,
+                    e: int, scale: float) -> None:
+    _dev(qkv)
+    _check(lib().la_attn_bwd_relpos(_ptr(qkv), _ptr(out16), _ptr(dout16), _ptr(kt), _ptr(qt), _ptr(dot), _ptr(lse), _ptr(dvec), _ptr(dqkv),
+                                    _ptr(relh), _ptr(relw), _ptr(drelh), _ptr(drelw), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad),
+                                    C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(dt_of(qkv)), _stream()), "la_attn_bwd_relpos")
+
+
+def relpos_bwd(qkv, dqkv, drelh, drelw, tabh, tabw, dtabh, dtabw, b: int, heads: int, g: int, e: int, gscale: float = 1.0) -> None:
+    _dev(qkv)
+    _check(lib().la_relpos_bwd(_ptr(qkv), _ptr(dqkv), _ptr(drelh), _ptr(drelw), _ptr(tabh), _ptr(tabw), _ptr(dtabh), _ptr(dtabw), C.c_int(b),
+                               C.c_int(heads), C.c_int(g), C.c_int(e), C.c_float(gscale), C.c_int(dt_of(qkv)), _stream()), "la_relpos_bwd")
 
 
 def cast(src, dst, scale: float = 1.0) -> None:

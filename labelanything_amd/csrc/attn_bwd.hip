@@ -32,6 +32,12 @@ struct AttnBwdEncArgs {
   void* dqkv;           // [B*T, 3E] 16-bit: dq | dk | dv rows (written)
   int B, heads, T, Tpad, E;
   float scale;
+  // decomposed relative-position bias (SAM ViTDet blocks, image_encoder.py:340-376): S = scale q.k + relh[q][key / G] + relw[q][key % G]
+  const float* relh;    // [B*heads, T, G] fp32 (la_relpos_terms), nullptr = plain attention
+  const float* relw;
+  float* drelh;         // [B*heads, T, G] fp32: d relh[q][kh] = sum_kw dS[q][(kh, kw)]   (written by the dq kernel)
+  float* drelw;         //                       d relw[q][kw] = sum_kh dS[q][(kh, kw)]
+  int G;
 };
 
 // stage rows [row0, row0 + 64) (clamped to maxrow) x 64 columns of a row-major 16-bit matrix into one swizzled LDS tile
@@ -71,7 +77,11 @@ template <typename T> __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// BIAS 0: plain.  BIAS 1: rel-pos bias, any G <= 32 (per-wave LDS tables of the wave's 32 query rows, as the forward's MODE 1; the bias
+// gradients are scatter-added into a second pair of tables with ds_add_f32 - the two half-lanes of a query row hit the same entries).
+// BIAS 2: G == 64 - a 64-key tile is exactly one key row: relh[q][tile] is one scalar per tile, relw[q][0..63] lives in the 32 score
+// registers' positions for the whole kernel, d relw accumulates in 32 more registers and d relh[q][tile] is one store per tile.
+template <typename T, int BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 3 * TILE_B;             // K rows | V rows | K^T
@@ -127,6 +137,46 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 
   const int ntiles = (T_ + 63) >> 6;
   dma(0, 0);
+  // ---- bias tables -------------------------------------------------------------------------------------------------------------
+  const int G = a.G, GS = G + 1;
+  float* my_bh = nullptr;       // BIAS 1: [32][GS] relh rows of the wave's queries | [32][GS] relw | [32][GS] d relh | [32][GS] d relw
+  const int* keyinfo = nullptr;
+  f32x16 rw[2], drw[2];         // BIAS 2: relw / d relw of the lane's 32 key columns
+  const float* rhq = nullptr;
+  if (BIAS == 1) {
+    float* tab = reinterpret_cast<float*>(smem + 2 * STAGE);
+    my_bh = tab + wave * 4 * 32 * GS;
+    for (int idx = lane; idx < 32 * G; idx += 64) {
+      const int i = idx / G, k = idx % G;
+      const size_t src = ((size_t)bh * T_ + min(qblk * 128 + wave * 32 + i, T_ - 1)) * G + k;
+      my_bh[i * GS + k] = a.relh[src];
+      my_bh[(32 + i) * GS + k] = a.relw[src];
+      my_bh[(64 + i) * GS + k] = 0.f;
+      my_bh[(96 + i) * GS + k] = 0.f;
+    }
+    int* ki = reinterpret_cast<int*>(tab + 4 * 4 * 32 * GS);
+    for (int k = tid; k < a.Tpad; k += 256) {
+      const int kk = min(k, T_ - 1);
+      ki[k] = ((kk / G) << 16) | (kk % G);
+    }
+    keyinfo = ki;
+  }
+  if (BIAS == 2) {
+    rhq = a.relh + ((size_t)bh * T_ + qc) * 64;
+    const float* p = a.relw + ((size_t)bh * T_ + qc) * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + t * 32 + 8 * g4 + 4 * fh);
+        rw[t][g4 * 4 + 0] = v.x;
+        rw[t][g4 * 4 + 1] = v.y;
+        rw[t][g4 * 4 + 2] = v.z;
+        rw[t][g4 * 4 + 3] = v.w;
+        drw[t][g4 * 4 + 0] = drw[t][g4 * 4 + 1] = drw[t][g4 * 4 + 2] = drw[t][g4 * 4 + 3] = 0.f;
+      }
+  }
+  const float inv_c = 1.0f / a.scale;            // the bias enters in units of the raw score (score = scale * (q.k + bias / scale))
   dma_wait<0>();
   __syncthreads();
   // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
@@ -155,15 +205,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
       }
     }
     const bool tail = j * 64 + 64 > T_;
+    float rh = 0.f, drh = 0.f;
+    if (BIAS == 2) rh = rhq[j];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = j * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const float sv_ = (tail && key >= T_) ? BWD_NEG_BIG : s[t][r];
+        float sraw = s[t][r];
+        int info = 0;
+        if (BIAS == 1) {
+          info = keyinfo[key];
+          sraw += (my_bh[fr * GS + (info >> 16)] + my_bh[(32 + fr) * GS + (info & 0xffff)]) * inv_c;
+        }
+        if (BIAS == 2) sraw += (rh + rw[t][r]) * inv_c;
+        const float sv_ = (tail && key >= T_) ? BWD_NEG_BIG : sraw;
         const float p = __builtin_amdgcn_exp2f(fmaf(sv_, c2, -lse2));
-        s[t][r] = p * (dp[t][r] - dsum);           // dS^T (before the 1/sqrt(d) factor, applied at the end)
+        const float dsv = p * (dp[t][r] - dsum);   // dS^T (before the 1/sqrt(d) factor, applied at the end)
+        s[t][r] = dsv;
+        if (BIAS == 1 && q < T_ && !(tail && key >= T_)) {
+          atomicAdd(&my_bh[(64 + fr) * GS + (info >> 16)], dsv);
+          atomicAdd(&my_bh[(96 + fr) * GS + (info & 0xffff)], dsv);
+        }
+        if (BIAS == 2) {
+          drh += dsv;
+          drw[t][r] += dsv;
+        }
       }
+    if (BIAS == 2) {
+      drh += __shfl_xor(drh, 32, 64);
+      if (q < T_ && fh == 0) a.drelh[((size_t)bh * T_ + q) * 64 + j] = drh;
+    }
     uint4 dsf[4];
     to_b_frags<T>(s, dsf);
 #pragma unroll
@@ -188,10 +260,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
         *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
       }
   }
+  if (BIAS == 2 && q < T_) {
+    float* p = a.drelw + ((size_t)bh * T_ + q) * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(p + t * 32 + 8 * g4 + 4 * fh) =
+            make_float4(drw[t][g4 * 4 + 0], drw[t][g4 * 4 + 1], drw[t][g4 * 4 + 2], drw[t][g4 * 4 + 3]);
+  }
+  if (BIAS == 1) {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int idx = lane; idx < 32 * G; idx += 64) {
+      const int i = idx / G, k = idx % G;
+      const int qi = qblk * 128 + wave * 32 + i;
+      if (qi < T_) {
+        a.drelh[((size_t)bh * T_ + qi) * G + k] = my_bh[(64 + i) * GS + k];
+        a.drelw[((size_t)bh * T_ + qi) * G + k] = my_bh[(96 + i) * GS + k];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-template <typename T>
+// BIAS: the rel-pos terms of (query register, key lane) are read straight from the fp32 term arrays (a fixed register = one query row:
+// the 64 keys of the wave read inside one <= 256-byte row of relh / relw)
+template <typename T, bool BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 4 * TILE_B + 512;       // Q rows | dO rows | Q^T | dO^T | LSE (64 floats) | D (64 floats)
@@ -214,6 +309,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
       vf[ks] = *reinterpret_cast<const uint4*>(pk + a.E + ks * 16);
     }
   }
+  const int G = BIAS ? a.G : 1;
+  const int kh_l = kc / G, kw_l = kc % G;
+  const float inv_c = 1.0f / a.scale;
   const unsigned lds0 = lds_addr_of(smem);
   const T* qbase = qkv + (size_t)b * T_ * E3 + h * 64;
   const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * 64;
@@ -280,6 +378,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = g4 * 4 + k;
+          if (BIAS) {
+            const size_t row = ((size_t)bh * T_ + min(i * 64 + t * 32 + 8 * g4 + 4 * fh + k, T_ - 1)) * G;
+            s[t][r] += (a.relh[row + kh_l] + a.relw[row + kw_l]) * inv_c;
+          }
           const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -lv[k]));    // rows beyond T carry LSE = +BIG: p = 0
           s[t][r] = p;
           ds[t][r] = p * (dp[t][r] - dvv[k]);
@@ -355,6 +457,83 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
   }
 }
 
+// launch both backward kernels (dq first: it writes D); bias 0 plain, 1 rel-pos G <= 32, 2 rel-pos G == 64
+template <typename T, int BIAS>
+static void launch_attn_bwd_t(const AttnBwdEncArgs& a, hipStream_t st) {
+  const int nblk = (a.T + 127) / 128 * a.B * a.heads;
+  const int lds_dq = 2 * 3 * TILE_B + (BIAS == 1 ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int) : 0);
+  constexpr int LDS_DKV = 2 * (4 * TILE_B + 512);
+  static unsigned long long m1 = 0, m2 = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS>), 160 * 1024, m1);
+  ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0)>), LDS_DKV, m2);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, BIAS>), dim3(nblk), dim3(256), lds_dq, st, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, (BIAS != 0)>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+}
+static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream_t st) {
+  if (dt == LA_F16) {
+    if (bias == 0) launch_attn_bwd_t<f16_t, 0>(a, st);
+    else if (bias == 1) launch_attn_bwd_t<f16_t, 1>(a, st);
+    else launch_attn_bwd_t<f16_t, 2>(a, st);
+  } else {
+    if (bias == 0) launch_attn_bwd_t<bf16_t, 0>(a, st);
+    else if (bias == 1) launch_attn_bwd_t<bf16_t, 1>(a, st);
+    else launch_attn_bwd_t<bf16_t, 2>(a, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the decomposed rel-pos terms (image_encoder.py:340-376: rel_h[q][kh] = q . Rh[qy - kh + G - 1], rel_w[q][kw] =
+// q . Rw[qx - kw + G - 1], q UNSCALED) given d rel_h / d rel_w from attn_bwd_dq_kernel.  One workgroup per (image-head, query row y):
+//   dq[x][d]     += sum_kh drelh[x][kh] Rh[y - kh + G - 1][d] + sum_kw drelw[x][kw] Rw[x - kw + G - 1][d]      (added to the 16-bit dq rows)
+//   dRh[y - kh + G - 1][d] += sum_x drelh[x][kh] q[x][d]        dRw[r][d] += sum_{x - kw + G - 1 = r} drelw[x][kw] q[x][d]   (fp32 atomics:
+//   the tables are shared by every image, head and row).  Vector ALU only: 2 G^2 64 MACs per workgroup, a rounding error next to the
+//   attention products.  Tables / table gradients are fp32 [(2 G - 1), hd_tab] with the first 64 columns used.
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
+                                                         const float* __restrict__ drelw, const float* __restrict__ tabh,
+                                                         const float* __restrict__ tabw, float* __restrict__ dtabh, float* __restrict__ dtabw,
+                                                         int B, int heads, int G, int E, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sq = reinterpret_cast<float*>(smem);          // [G][64] q of the row (fp32)
+  float* sdh = sq + G * 64;                            // [G][G] drelh of the row's queries
+  float* sdw = sdh + G * G;                            // [G][G] drelw
+  const int y = blockIdx.x % G, bh = blockIdx.x / G, h = bh % heads, b = bh / heads;
+  const int T_ = G * G, E3 = 3 * E, tid = threadIdx.x;
+  const size_t row0 = (size_t)b * T_ + (size_t)y * G;
+  for (int i = tid; i < G * 64; i += 256) sq[i] = (float)qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
+  for (int i = tid; i < G * G; i += 256) {
+    sdh[i] = drelh[((size_t)bh * T_ + (size_t)y * G) * G + i];
+    sdw[i] = drelw[((size_t)bh * T_ + (size_t)y * G) * G + i];
+  }
+  __syncthreads();
+  // dq rows
+  for (int i = tid; i < G * 64; i += 256) {
+    const int x = i / 64, d = i & 63;
+    float acc = 0.f;
+    for (int k = 0; k < G; ++k)
+      acc += sdh[x * G + k] * tabh[(size_t)(y - k + G - 1) * 64 + d] + sdw[x * G + k] * tabw[(size_t)(x - k + G - 1) * 64 + d];
+    T* p = dqkv + (row0 + x) * E3 + h * 64 + d;
+    *p = (T)((float)*p + acc);
+  }
+  // table gradients (un-scaled by gscale = 1 / loss scale is NOT applied here: the caller's buffers carry the loss scale like every
+  // other gradient of the backward pass; gscale is a plain multiplier for callers that want one)
+  for (int i = tid; i < G * 64; i += 256) {            // dRh[y - kh + G - 1][d]: kh = i / 64
+    const int kh = i / 64, d = i & 63;
+    float acc = 0.f;
+    for (int x = 0; x < G; ++x) acc += sdh[x * G + kh] * sq[x * 64 + d];
+    atomicAdd(&dtabh[(size_t)(y - kh + G - 1) * 64 + d], acc * gscale);
+  }
+  for (int i = tid; i < (2 * G - 1) * 64; i += 256) {  // dRw[r][d] = sum over (x, kw) with x - kw + G - 1 = r
+    const int r = i / 64, d = i & 63;
+    float acc = 0.f;
+    for (int x = 0; x < G; ++x) {
+      const int kw = x + G - 1 - r;
+      if (kw >= 0 && kw < G) acc += sdw[x * G + kw] * sq[x * 64 + d];
+    }
+    atomicAdd(&dtabw[(size_t)r * 64 + d], acc * gscale);
+  }
+}
+
 }  // namespace la
 
 extern "C" int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T, int Tpad, void* dst, int dt, void* stream) {
@@ -378,22 +557,39 @@ extern "C" int la_attn_bwd(const void* qkv, const void* out16, const void* dout1
   LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd: bad dtype %d", dt);
-  la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale};
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int nblk = (T + 127) / 128 * B * heads;
-  constexpr int LDS_DQ = 2 * 3 * la::TILE_B, LDS_DKV = 2 * (4 * la::TILE_B + 512);
-  static unsigned long long m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-  if (dt == LA_F16) {
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dq_kernel<la::f16_t>), LDS_DQ, m1);
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dkv_kernel<la::f16_t>), LDS_DKV, m2);
-    hipLaunchKernelGGL(la::attn_bwd_dq_kernel<la::f16_t>, dim3(nblk), dim3(256), LDS_DQ, st, a);      // first: it writes D
-    hipLaunchKernelGGL(la::attn_bwd_dkv_kernel<la::f16_t>, dim3(nblk), dim3(256), LDS_DKV, st, a);
-  } else {
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dq_kernel<la::bf16_t>), LDS_DQ, m3);
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::attn_bwd_dkv_kernel<la::bf16_t>), LDS_DKV, m4);
-    hipLaunchKernelGGL(la::attn_bwd_dq_kernel<la::bf16_t>, dim3(nblk), dim3(256), LDS_DQ, st, a);
-    hipLaunchKernelGGL(la::attn_bwd_dkv_kernel<la::bf16_t>, dim3(nblk), dim3(256), LDS_DKV, st, a);
-  }
+  la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale, nullptr, nullptr, nullptr, nullptr, 0};
+  la::launch_attn_bwd(a, 0, dt, reinterpret_cast<hipStream_t>(stream));
   LA_CHECK_LAUNCH("la_attn_bwd");
+  return 0;
+}
+
+extern "C" int la_attn_bwd_relpos(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot,
+                                  float* lse, float* dvec, void* dqkv, const float* relh, const float* relw, float* drelh, float* drelw, int B,
+                                  int heads, int T, int Tpad, int G, int E, float scale, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && out16 && dout16 && kt && qt && dot && lse && dvec && dqkv && relh && relw && drelh && drelw, "la_attn_bwd_relpos: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd_relpos: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd_relpos: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(G * G == T && (G <= 32 || G == 64), "la_attn_bwd_relpos: T == G*G with G <= 32 or G == 64 (T=%d G=%d)", T, G);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd_relpos: bad dtype %d", dt);
+  la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale, relh, relw, drelh, drelw, G};
+  la::launch_attn_bwd(a, G == 64 ? 2 : 1, dt, reinterpret_cast<hipStream_t>(stream));
+  LA_CHECK_LAUNCH("la_attn_bwd_relpos");
+  return 0;
+}
+
+extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, const float* drelw, const float* tabh, const float* tabw,
+                             float* dtabh, float* dtabw, int B, int heads, int G, int E, float gscale, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && dqkv && drelh && drelw && tabh && tabw && dtabh && dtabw, "la_relpos_bwd: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * 64, "la_relpos_bwd: needs head_dim 64, G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_bwd: bad dtype %d", dt);
+  const int lds = (G * 64 + 2 * G * G) * (int)sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dt == LA_F16)
+    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(B * heads * G), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
+                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+  else
+    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::bf16_t>, dim3(B * heads * G), dim3(256), lds, st, (const la::bf16_t*)qkv, (la::bf16_t*)dqkv, drelh,
+                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+  LA_CHECK_LAUNCH("la_relpos_bwd");
   return 0;
 }

@@ -1048,6 +1048,28 @@ extern "C" int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, flo
   return 0;
 }
 
+extern "C" int la_attn_fwd_relpos_lse(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, float* lse, int B, int heads,
+                                      int T, int Tpad, int G, int E, float scale, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && vt && out16 && relh && relw && lse, "la_attn_fwd_relpos_lse: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_fwd_relpos_lse: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_relpos_lse: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd_relpos_lse: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_relpos_lse: bad dtype %d", dt);
+  la::AttnArgs a{qkv, vt, out16, relh, relw, nullptr, nullptr, B, heads, T, Tpad, G, E, scale, lse};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (G == 64) {
+    const size_t lds = 4 * 32 * 65 * sizeof(float);
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 2>(a, lds, st);
+    else la::launch_attn<la::bf16_t, 2>(a, lds, st);
+  } else {
+    const size_t lds = 4 * 2 * 32 * (G + 1) * sizeof(float) + (size_t)Tpad * sizeof(int);
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 1>(a, lds, st);
+    else la::launch_attn<la::bf16_t, 1>(a, lds, st);
+  }
+  LA_CHECK_LAUNCH("la_attn_fwd_relpos_lse");
+  return 0;
+}
+
 extern "C" int la_qk_fp8(const void* qkv, long rows, int E, void* qk8, int dt, void* stream) {
   LA_CHECK_ARG(qkv && qk8 && rows > 0 && E > 0 && (E % 8) == 0 && (dt == LA_F16 || dt == LA_BF16), "la_qk_fp8: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
