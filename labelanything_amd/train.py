@@ -393,11 +393,12 @@ class LamTrainer:
         self.graph = DecoderGraph(lam, self.engine)
         self.enc_graph = None
         if self.train_encoder:
-            from .train_encoder import HfEncoderGraph
-            self.enc_graph = HfEncoderGraph(lam, {k: gv for k, gv in zip(self.names, self.opt.grad_views) if k.startswith("image_encoder.")},
-                                            precise=self.train_precise)
+            from .train_encoder import HfEncoderGraph, SamEncoderGraph
+            graph_cls = SamEncoderGraph if lam.cfg.encoder_spec.kind == "sam" else HfEncoderGraph
+            self.enc_graph = graph_cls(lam, {k: gv for k, gv in zip(self.names, self.opt.grad_views) if k.startswith("image_encoder.")},
+                                       precise=self.train_precise)
             self._anchor = torch.zeros(1, device=lam._device(), requires_grad=True)
-            self._enc_idx = [i for i, k in enumerate(self.names) if k.startswith("image_encoder.")]
+            self._enc_idx = [i for i, k in enumerate(self.names) if graph_cls.owns(k)]
 
     def _on_grad(self, i: int) -> None:
         self._touched[i] = True
@@ -439,6 +440,9 @@ class LamTrainer:
                 e_rows = encode_trainable(self.enc_graph, im.flatten(0, 1), self._anchor)
                 for i in self._enc_idx:
                     self._touched[i] = True
+                if lam.cfg.encoder_spec.kind == "sam" and lam.cfg.use_vit_sam_neck:
+                    # the SAM neck (image_encoder.py:92-108) on the decoder graph's autograd operators, exact fp32
+                    e_rows = self.graph.conv_neck("image_encoder.neck", e_rows, b * n, g)
                 # the encoder's backward node is the last one autograd runs (it was created first): every decoder-side gradient has
                 # been accumulated by then, so their bucket starts travelling under the encoder backward (a copy is reduced; a
                 # gradient that does arrive later invalidates it and the bucket is reduced in place at the end)

@@ -40,11 +40,18 @@ class HfEncoderGraph:
     """One trainable HF ViT encoder.  ``grads``: parameter name (``image_encoder....``) -> fp32 tensor the gradient is ADDED to."""
 
     TARGET_MAX = 64.0
+    KIND = "hf"
+
+    @staticmethod
+    def owns(key: str) -> bool:
+        """Parameters whose gradient this graph writes (every ``image_encoder.*`` tensor here)."""
+        return key.startswith("image_encoder.")
 
     def __init__(self, lam, grads: Dict[str, Tensor], precise=None):
         spec = lam.cfg.encoder_spec
-        if spec is None or spec.kind != "hf":
-            raise NotImplementedError("the encoder backward covers the HF ViT stack (ViT-MAE / DINO / IN21k); the SAM ViTDet stack is forward only")
+        if spec is None or spec.kind != self.KIND:
+            raise NotImplementedError(f"{type(self).__name__} is the backward of the {self.KIND!r} encoder stack (HfEncoderGraph: ViT-MAE / DINO / "
+                                      "IN21k; SamEncoderGraph: the SAM ViTDet stack)")
         if spec.head_dim != 64:
             raise NotImplementedError(f"encoder backward needs 64-wide heads (got {spec.head_dim})")
         self.lam, self.spec, self.grads = lam, spec, grads
@@ -55,7 +62,9 @@ class HfEncoderGraph:
         self._eng_stale = True
         self.before_backward = None        # optional callback at the head of ``backward`` (LamTrainer: launch the decoder-side gradient bucket)
         self.w: Dict[str, Tensor] = {k: v for k, v in lam.state_dict(keep_vars=True).items() if k.startswith("image_encoder.")}
-        missing = [k for k, v in self.w.items() if v.is_floating_point() and k not in grads]
+        grads = {k: v for k, v in grads.items() if self.owns(k)}
+        self.grads = grads
+        missing = [k for k, v in self.w.items() if v.is_floating_point() and self.owns(k) and k not in grads]
         if missing:
             raise KeyError(f"no gradient slot for {missing[:3]} ...")
         n = sum(self.w[k].numel() for k in grads)
@@ -342,6 +351,179 @@ class HfEncoderGraph:
             gp = sv[emb + "position_embeddings"].view(-1, e)        # [1 + gin^2, E]
             gp[0].add_(dpos_rows[0])
             L.gemm_tn(b, dpos_rows[1:].contiguous(), gp[1:])
+
+
+class SamEncoderGraph(HfEncoderGraph):
+    """One trainable SAM ViTDet block stack (models/image_encoder.py:110-131 without the neck; blocks :134-197, attention :200-255, window
+    partition :258-304, decomposed relative positions :307-376): ``lam_b`` / ``lam_l`` / ``lam_h``-style models with nothing frozen
+    (models/lam.py:321-347).  Same machinery as the HF stack (16-bit operands, loss-scaled backward, split-K weight gradients); what is
+    different:
+      * window blocks: LayerNorm output is zero-padded to a multiple of the window AFTER the norm and cut into windows (the training
+        forward keeps the padded rows: their q / k / v are the bias, they are attended to, their outputs are dropped - exactly the
+        reference); the partition / un-partition are row gathers with an index built once per geometry;
+      * attention carries the decomposed rel-pos bias: la_relpos_terms -> la_attn_fwd_relpos_lse forward, la_attn_bwd_relpos +
+        la_relpos_bwd backward (d rel_pos_h / d rel_pos_w accumulate over images, heads and query rows);
+      * no CLS token, a learned absolute position embedding of the full grid, LayerNorm eps 1e-6.
+    The SAM neck (1x1 conv, LayerNorm2d, 3x3 conv, LayerNorm2d) is NOT in this graph: the trainer runs it through the decoder graph's
+    autograd operators (``DecoderGraph.conv_neck``), so ``image_encoder.neck.*`` is excluded from ``owns``."""
+
+    KIND = "sam"
+
+    @staticmethod
+    def owns(key: str) -> bool:
+        return key.startswith("image_encoder.") and not key.startswith("image_encoder.neck.")
+
+    def _win_index(self, bn: int, g: int, ws: int, dev) -> Tensor:
+        """Row of image-order token (b, y, x) in the zero-padded, window-partitioned layout [bn * nw * nw * ws * ws]."""
+        key = ("widx", bn, g, ws)
+        t = self._tbufs.get(key)
+        if t is None:
+            nw = (g + ws - 1) // ws
+            b = torch.arange(bn).view(bn, 1, 1)
+            y = torch.arange(g).view(1, g, 1)
+            x = torch.arange(g).view(1, 1, g)
+            t = ((((b * nw + y // ws) * nw + x // ws) * ws + y % ws) * ws + x % ws).reshape(-1).to(dev)
+            self._tbufs[key] = t
+        return t
+
+    @torch.no_grad()
+    def forward(self, images: Tensor) -> Tensor:
+        """(Bn, 3, S, S) fp32 on the device -> the last block's state [Bn * hw, E] fp32 NHWC rows, activations kept for ``backward``."""
+        eng = self.engine()
+        spec, w, p = self.spec, eng.w32, eng.p
+        pre = "image_encoder"
+        images = images.contiguous()
+        bn, _, s, _ = images.shape
+        e, heads, g, ws = spec.dim, spec.heads, s // spec.patch, spec.window
+        if g != spec.pos_grid:
+            raise ValueError(f"the SAM stack has a fixed position embedding: image side {spec.img_size}, got {s}")
+        hw, rows = g * g, bn * g * g
+        dev, dt = images.device, eng.dt
+        a, akw = eng.patches("enc.patchA", images, rows, spec.patch)
+        res = torch.empty(rows, e, device=dev)
+        L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
+        scale = spec.head_dim ** -0.5
+        nw = (g + ws - 1) // ws
+        layers: List[dict] = []
+        for i in range(spec.depth):
+            bp = f"{pre}.blocks.{i}"
+            is_global = i in spec.global_idx
+            nb, gg = (bn, g) if is_global else (bn * nw * nw, ws)
+            t = gg * gg
+            arows, tpad = nb * t, _ceil(t, 64)
+            for ax in ("h", "w"):
+                if w[f"{bp}.attn.rel_pos_{ax}"].shape[0] != 2 * gg - 1:
+                    raise NotImplementedError("training through resampled rel-pos tables (get_rel_pos interpolation) is not built")
+            sv = {"x_in": res, "global": is_global, "nb": nb, "g": gg, "t": t, "tpad": tpad, "arows": arows}
+            x16 = torch.empty(rows, e, device=dev, dtype=dt)
+            eng.ln(res, bp + ".norm1", 1e-6, out16=x16)
+            if is_global:
+                xa = x16
+            else:                                    # pad-after-norm windows: padded rows are zero
+                xa = torch.zeros(arows, e, device=dev, dtype=dt)
+                xa.index_copy_(0, self._win_index(bn, g, ws, dev), x16)
+            sv["xa"] = xa
+            sv["qkv"] = torch.empty(arows, 3 * e, device=dev, dtype=dt)
+            self._qkv_plain(eng, xa, bp + ".qkv.w", sv["qkv"], e)
+            sv["relh"] = torch.empty(nb * heads, t, gg, device=dev)
+            sv["relw"] = torch.empty(nb * heads, t, gg, device=dev)
+            L.relpos_terms(sv["qkv"], nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], sv["relh"], sv["relw"])
+            vt = torch.zeros(nb * heads, 64, tpad, device=dev, dtype=dt)
+            L.head_transpose(sv["qkv"], 2 * e, nb, heads, t, tpad, vt)
+            sv["ao"] = torch.empty(arows, e, device=dev, dtype=dt)
+            sv["lse"] = torch.empty(nb * heads, tpad, device=dev)
+            L.attn_fwd_relpos_lse(sv["qkv"], vt, sv["ao"], sv["relh"], sv["relw"], sv["lse"], nb, heads, t, tpad, gg, e, scale)
+            x_mid = torch.empty(rows, e, device=dev)
+            if is_global:
+                eng.gemm_w(sv["ao"], bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=x_mid)
+            else:                                    # proj on every window row, real tokens gathered back into image order
+                yw = torch.empty(arows, e, device=dev)
+                eng.gemm_w(sv["ao"], bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], out32=yw)
+                L.add_cast(res, yw.index_select(0, self._win_index(bn, g, ws, dev)), rows, out32=x_mid, dt=L._DT[dt])
+            sv["x_mid"] = x_mid
+            x16b = torch.empty(rows, e, device=dev, dtype=dt)
+            sv["xnb"] = x16b
+            eng.ln(x_mid, bp + ".norm2", 1e-6, out16=x16b)
+            sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+            sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+            eng.gemm_w(x16b, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=sv["pre"])
+            L.gelu_fwd16(sv["pre"], sv["post"])
+            res = torch.empty(rows, e, device=dev)
+            eng.gemm_w(sv["post"], bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=x_mid, out32=res)
+            layers.append(sv)
+        self.ctx = dict(images=images, layers=layers, bn=bn, g=g, hw=hw, rows=rows, e=e, heads=heads, scale=scale, dt=dt, ws=ws)
+        return res
+
+    def _backward_scaled(self, d_out: Tensor, s: float) -> None:
+        c = self.ctx
+        if c is None:
+            raise RuntimeError("SamEncoderGraph.backward without a forward")
+        self._xt_key = None
+        spec, w, sv = self.spec, self.w, self.sviews
+        pre = "image_encoder"
+        bn, g, hw, rows, e, heads, dt, ws = c["bn"], c["g"], c["hw"], c["rows"], c["e"], c["heads"], c["dt"], c["ws"]
+        dev = d_out.device
+        dres = torch.empty(rows, e, device=dev)
+        L.cast(d_out.contiguous(), dres, s)
+        d16 = torch.empty(rows, e, device=dev, dtype=dt)
+        dh = torch.empty(rows, spec.mlp, device=dev)
+        dpre32 = torch.empty(rows, spec.mlp, device=dev)
+        dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
+        dxn = torch.empty(rows, e, device=dev)
+        dx = torch.empty(rows, e, device=dev)
+        for i in reversed(range(spec.depth)):
+            bp = f"{pre}.blocks.{i}"
+            a = c["layers"][i]
+            nb, gg, t, tpad, arows = a["nb"], a["g"], a["t"], a["tpad"], a["arows"]
+            # ---- MLP: res = x_mid + lin2(gelu(lin1(LN2(x_mid)))) -----------------------------------------------------------------
+            L.cast(dres, d16)
+            self._linear_bwd(dres, d16, a["post"], bp + ".mlp.lin2.weight", bp + ".mlp.lin2.bias", dx32=dh)
+            need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
+            L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
+            self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], bp + ".mlp.lin1.weight", bp + ".mlp.lin1.bias", dx32=dxn)
+            L.layernorm_bwd(a["x_mid"], dxn, w[bp + ".norm2.weight"], w[bp + ".norm2.bias"], 1e-6, False, dx, sv[bp + ".norm2.weight"],
+                            sv[bp + ".norm2.bias"])
+            L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])
+            # ---- attention: x_mid = x_in + unpartition(proj(attn(partition(LN1(x_in))))) ------------------------------------------
+            if a["global"]:
+                dy16, dy32 = d16, dres
+            else:                                    # the dropped (padded) output rows receive no gradient
+                widx = self._win_index(bn, g, ws, dev)
+                dy16 = torch.zeros(arows, e, device=dev, dtype=dt)
+                dy16.index_copy_(0, widx, d16)
+                dy32 = None
+            dao = torch.empty(arows, e, device=dev, dtype=dt)
+            self._linear_bwd(dy32, dy16, a["ao"], bp + ".attn.proj.weight", bp + ".attn.proj.bias", dx16=dao)
+            kt = torch.empty(nb * heads, 64, tpad, device=dev, dtype=dt)
+            qt, dot = torch.empty_like(kt), torch.empty_like(kt)
+            L.head_transpose(a["qkv"], e, nb, heads, t, tpad, kt)
+            L.head_transpose(a["qkv"], 0, nb, heads, t, tpad, qt)
+            L.head_transpose(dao, 0, nb, heads, t, tpad, dot)
+            dvec = torch.empty(nb * heads, tpad, device=dev)
+            dqkv16 = torch.empty(arows, 3 * e, device=dev, dtype=dt)
+            drelh, drelw = torch.empty_like(a["relh"]), torch.empty_like(a["relw"])
+            L.attn_bwd_relpos(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, a["relh"], a["relw"], drelh, drelw, nb, heads, t,
+                              tpad, gg, e, c["scale"])
+            L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, w[bp + ".attn.rel_pos_h"].detach().contiguous(),
+                         w[bp + ".attn.rel_pos_w"].detach().contiguous(), sv[bp + ".attn.rel_pos_h"], sv[bp + ".attn.rel_pos_w"], nb, heads,
+                         gg, e)
+            if not self._wgrad(dqkv16, None, a["xa"], sv[bp + ".attn.qkv.weight"], db=sv[bp + ".attn.qkv.bias"]):
+                dq32 = self._tbuf("dqkv32", arows, 3 * e, torch.float32)
+                L.cast(dqkv16, dq32)
+                L.colsum_acc(dq32, sv[bp + ".attn.qkv.bias"])
+            dxa = torch.empty(arows, e, device=dev)
+            L.gemm(dqkv16, self._wt16(bp + ".attn.qkv", lambda: w[bp + ".attn.qkv.weight"], dt), out32=dxa)
+            dxn_i = dxa if a["global"] else dxa.index_select(0, self._win_index(bn, g, ws, dev))
+            L.layernorm_bwd(a["x_in"], dxn_i.contiguous(), w[bp + ".norm1.weight"], w[bp + ".norm1.bias"], 1e-6, False, dx, sv[bp + ".norm1.weight"],
+                            sv[bp + ".norm1.bias"])
+            L.add_cast(dres, dx, rows, out32=dres, dt=L._DT[dt])
+        # ---- patch embedding + absolute position embedding: res0[b, i] = patch_i W^T + b + pos[i] -------------------------------------
+        k = 3 * spec.patch * spec.patch
+        a32 = torch.empty(rows, k, device=dev)
+        L.im2col_patch(c["images"], spec.patch, a32)
+        self._wgrad(None, dres, a32, sv[pre + ".patch_embed.proj.weight"].view(e, k))
+        L.colsum_acc(dres, sv[pre + ".patch_embed.proj.bias"])
+        sv[pre + ".pos_embed"].view(hw, e).add_(dres.view(bn, hw, e).sum(dim=0))        # (a few thousand rows of bookkeeping)
 
 
 class _EncoderFn(torch.autograd.Function):

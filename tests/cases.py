@@ -113,3 +113,14 @@ TRAIN_ENC_CASE = dict(
     episode=dict(batch=1, n_ways=1, k_shots=2, image_size=240, seed=122, prompts=("mask", "point")),
     lr=1e-3, weight_decay=1e-2, steps=2, warmup=2,
 )
+
+
+# Training fixture with a TRAINABLE SAM ViTDet encoder (tests/golden/train_step_sam.safetensors): the reduced SAM stack of the forward
+# fixtures (one padded 8 x 8 window block on the 14 x 14 grid + one global block, rel-pos tables, absolute position embedding), SAM neck
+# 128 -> 96, LAM neck 96 -> 64, masks + points; nothing frozen - what ``lam_b`` trains when ``freeze_backbone`` is absent (lam.py:321-347).
+TRAIN_SAM_CASE = dict(
+    cfg=LamConfig(encoder="sam_tiny", image_size=224, image_embed_dim=96, embed_dim=64, spatial_convs=3, custom_preprocess=False),
+    weight_seed=23,
+    episode=dict(batch=1, n_ways=1, k_shots=2, image_size=224, seed=123, prompts=("mask", "point")),
+    lr=1e-3, weight_decay=1e-2, steps=2, warmup=2,
+)

@@ -76,3 +76,101 @@ def test_relpos_attention_forward_lse_and_backward_match_torch(shape):
     for name, mine, ref in (("dRh", dtabh, rh.grad), ("dRw", dtabw, rw.grad)):
         err = float((mine.double().cpu() - ref).abs().max()) / float(ref.abs().max())
         assert err <= 3e-3, (name, err)
+
+
+def _sam_cfg():
+    from labelanything_amd.config import LamConfig
+    import tests.cases  # noqa: F401  (registers sam_tiny)
+    return LamConfig(encoder="sam_tiny", image_size=224, image_embed_dim=96, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+
+
+def test_sam_block_stack_gradients_of_a_linear_functional_match_oracle_autograd():
+    """SamEncoderGraph alone (patch + position embedding, one padded-window block, one global block; the neck is the trainer's business):
+    L = sum(R * last_block_state(images)), every owned parameter's gradient - rel-pos tables and the position embedding included -
+    against torch autograd of the CPU oracle's fp32 encoder (pinned on the reference)."""
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train_encoder import SamEncoderGraph
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    cfg = _sam_cfg()
+    g = torch.Generator().manual_seed(224)
+    images = torch.randn(2, 3, 224, 224, generator=g)
+    sd = init_state_dict(cfg, 33)
+    wref = {k: (v.clone().requires_grad_(True) if k.startswith("image_encoder.") and v.is_floating_point() else v) for k, v in sd.items()}
+    _, last_ref = O.sam_encoder(wref, geometry_for(cfg), images, return_last_block=True)           # (Bn, E, g, g)
+    r = torch.randn(last_ref.shape, generator=g)
+    (last_ref * r).sum().backward()
+    lam = Lam(cfg, seed=33).cuda()
+    names = [k for k, _ in lam.named_parameters() if SamEncoderGraph.owns(k)]
+    assert names and not any("neck" in k for k in names)
+    grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}
+    graph = SamEncoderGraph(lam, grads)
+    out = graph.forward(images.cuda())
+    bn, c, gg, _ = last_ref.shape
+    ref_rows = last_ref.detach().permute(0, 2, 3, 1).reshape(bn * gg * gg, c)
+    assert float((out.cpu() - ref_rows).abs().max()) <= 1e-3 * float(ref_rows.abs().max())
+    graph.backward(r.permute(0, 2, 3, 1).reshape(bn * gg * gg, c).contiguous().cuda())
+    torch.cuda.synchronize()
+    gmax = max(float(wref[k].grad.abs().max()) for k in names)
+    worst = {}
+    for k in names:
+        ref = wref[k].grad
+        worst[k] = float((grads[k].cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * gmax)
+    order = sorted(worst.items(), key=lambda kv: -kv[1])
+    print(f"SAM block-stack gradients (linear functional, loss scale {graph.last_scale:g}): worst", [(k[14:], f"{v:.2e}") for k, v in order[:8]])
+    assert order[0][1] <= 1e-2, order[:8]
+    for k in ("image_encoder.blocks.0.attn.rel_pos_h", "image_encoder.blocks.1.attn.rel_pos_w", "image_encoder.pos_embed"):
+        assert float(grads[k].abs().max()) > 0 and worst[k] <= 1e-2, (k, worst[k])
+
+
+def test_steps_with_trainable_sam_encoder_match_the_reference_fixture():
+    """tests/golden/train_step_sam.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up with NO frozen
+    parameters on the reduced SAM model (tools/make_golden_train.py sam): losses, per-tensor gradient norms of the first step, the full
+    gradient and the final value of 17 tensors (15 of them inside the image encoder: rel-pos tables, position embedding, qkv, SAM neck)."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from tests.cases import TRAIN_SAM_CASE as case
+    from tests.helpers import GOLDEN, rel_err
+    gold = load_file(os.path.join(GOLDEN, "train_step_sam.safetensors"))
+    with open(os.path.join(GOLDEN, "train_step_sam.json")) as fh:
+        keys = json.load(fh)["keys"]
+    batch = make_episode(**case["episode"])
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    start = {k: p.detach().clone() for k, p in lam.named_parameters()}
+    tr = LamTrainer(lam, lr=case["lr"], weight_decay=case["weight_decay"], num_warmup_steps=case["warmup"], train_encoder=True)
+    assert sorted(tr.names) == keys
+    losses = []
+    for step in range(case["steps"]):
+        tr.zero_grad()
+        res = tr.forward_backward(batch, gold["gt"])
+        losses.append(float(res["loss"]))
+        if step == 0:
+            assert rel_err(res["logits"], gold["logits0"]) <= 1e-3
+            g0 = {k: gv.clone() for k, gv in zip(tr.names, tr.opt.grad_views)}
+        tr.apply_update()
+    assert torch.allclose(torch.tensor(losses), gold["loss"], rtol=2e-3, atol=0), (losses, gold["loss"])
+    gn = torch.stack([g0[k].norm() for k in keys]).cpu()
+    floor_g = 1e-2 * float(gold["grad_norm"].max())
+    rel_n = (gn - gold["grad_norm"]).abs() / gold["grad_norm"].clamp_min(floor_g)
+    print("trainable-SAM fixture: worst gradient-norm error", float(rel_n.max()), keys[int(rel_n.argmax())])
+    assert float(rel_n.max()) <= 3e-2
+    params = dict(lam.named_parameters())
+    gmax = max(float(v.abs().max()) for k, v in gold.items() if k.startswith("grad."))
+    worst = 0.0
+    for k, v in gold.items():
+        if k.startswith("grad."):
+            err = float((g0[k[5:]].cpu() - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gmax)
+            worst = max(worst, err)
+            assert err <= 3e-2, (k, err)
+        if k.startswith("final."):
+            name = k[6:]
+            mine, ref0 = params[name].detach().cpu(), start[name].cpu()
+            sig = gold["grad." + name].abs() > 5e-2 * gold["grad." + name].abs().max()
+            step_ref, step_mine = (v - ref0)[sig], (mine - ref0)[sig]
+            assert float((step_mine - step_ref).abs().max()) <= 5e-2 * float(step_ref.abs().max()), name
+    print("trainable-SAM fixture: worst entry-wise gradient error", worst)

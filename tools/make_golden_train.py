@@ -36,10 +36,23 @@ FULL_ENC = ["image_encoder.embeddings.patch_embeddings.projection.weight", "imag
             "prompt_encoder.transformer.layers.0.cross_attn_token_to_image.v_proj.weight", "mask_decoder.output_upscaling.0.weight"]
 
 
+FULL_SAM = ["image_encoder.pos_embed", "image_encoder.patch_embed.proj.weight", "image_encoder.blocks.0.attn.rel_pos_h",
+            "image_encoder.blocks.0.attn.rel_pos_w", "image_encoder.blocks.0.attn.qkv.weight", "image_encoder.blocks.0.attn.qkv.bias",
+            "image_encoder.blocks.0.norm1.weight", "image_encoder.blocks.1.attn.rel_pos_h", "image_encoder.blocks.1.attn.rel_pos_w",
+            "image_encoder.blocks.1.attn.proj.weight", "image_encoder.blocks.1.mlp.lin1.weight", "image_encoder.blocks.1.mlp.lin2.bias",
+            "image_encoder.neck.0.weight", "image_encoder.neck.2.weight", "image_encoder.neck.3.bias", "neck.0.weight",
+            "mask_decoder.output_upscaling.0.weight"]
+
+
 def main():
-    from tests.cases import TRAIN_CASE, TRAIN_ENC_CASE
-    run(TRAIN_CASE, "train_step", FULL, seed_gt=9)
-    run(TRAIN_ENC_CASE, "train_step_encoder", FULL_ENC, seed_gt=11)
+    from tests.cases import TRAIN_CASE, TRAIN_ENC_CASE, TRAIN_SAM_CASE
+    which = sys.argv[1:] or ["decoder", "hf", "sam"]
+    if "decoder" in which:
+        run(TRAIN_CASE, "train_step", FULL, seed_gt=9)
+    if "hf" in which:
+        run(TRAIN_ENC_CASE, "train_step_encoder", FULL_ENC, seed_gt=11)
+    if "sam" in which:          # the SAM ViTDet stack trainable (window + global rel-pos attention, position embedding, SAM neck)
+        run(TRAIN_SAM_CASE, "train_step_sam", FULL_SAM, seed_gt=13)
 
 
 def _to_4x(k: str) -> str:
