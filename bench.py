@@ -64,6 +64,12 @@ WORKLOADS = {
                        model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                                   class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
                        episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=2, train=True),     # the reference batches 2-16 episodes (mae_noembs.yaml:94)
+    # the headline geometry (cfg2) as a TRAINING step: SAM ViT-B 1024 with nothing frozen when run with --train-encoder (lam_b,
+    # models/lam.py:321-347: window + global attention with decomposed rel-pos, SAM neck) - round 4's SAM-stack backward
+    "cfg2_train": dict(desc="cfg2 geometry as a TRAINING step: SAM ViT-B 1024px + LabelAnything decoder, 1-way 1-shot episodes, focal objective, "
+                            "backward, gradient all-reduce, AdamW (--train-encoder: the SAM ViTDet stack trains too)",
+                       model=dict(encoder="vit_b", image_size=1024, image_embed_dim=256, embed_dim=256, spatial_convs=3, custom_preprocess=False),
+                       episode=dict(n_ways=1, k_shots=1, image_size=1024), default_episodes=2, train=True),
 }
 
 
