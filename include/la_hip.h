@@ -292,22 +292,23 @@ int la_classify_bwd(const float* dseg, const float* feat, const float* protos, i
 int la_row_broadcast(const float* src, long groups, int rep, int D, float scale, float* out, void* stream);
 
 /* ---- fused image-side kernels of the TwoWayTransformer (models/transformer.py:255-329): the (groups, hw, D) stream is read once per
- * attention.  D = 256, 8 heads (internal width 128, head width 16).  Weight planes are fp16 [rows, cols] pairs hi = rn(W), lo = rn(W - hi);
+ * attention.  8 heads; D = 256 (internal width DI = 128, head width 16: every published LabelAnything decoder) or D = 512 (DI = 256, head
+ * width 32: the published SAM-1024 decoder geometry).  Weight planes are fp16 [rows, cols] pairs hi = rn(W), lo = rn(W - hi);
  * the activations are split the same way on the fly, so every projection carries ~21 mantissa bits through the fast MFMA. ---- */
 
 /* The positional encoding enters as a constant table per layer: (img + pe) W^T + b = img W^T + (pe W^T + b); pek / peq = pe W^T + b,
- * fp32 [hw, 128], computed once by the caller.
+ * fp32 [hw, DI], computed once by the caller.
  *
  * tokens -> image attention (cross_attn_token_to_image / final_attn_token_to_image without q_proj / out_proj, which act on the few tokens):
- * out[g, t, :] = softmax_hw(q[g, t] . K_g^T / sqrt(16)) V_g per head, K = img Wk^T + pek, V = img Wv^T + bv computed tile by tile and
- * never written.  img fp32 [G*hw, D], wk / wv planes [128, D], q fp32 [G*nt, 128] (projected, bias included),
- * part = scratch fp32 [G * ceil(hw / 128) * 4 * nt * 8 * 18], out fp32 [G*nt, 128]. */
+ * out[g, t, :] = softmax_hw(q[g, t] . K_g^T / sqrt(hd)) V_g per head, K = img Wk^T + pek, V = img Wv^T + bv computed tile by tile (64 rows)
+ * and never written.  img fp32 [G*hw, D], wk / wv planes [DI, D], q fp32 [G*nt, DI] (projected, bias included),
+ * part = scratch fp32 [G * ceil(hw / 64) * 2 * nt * 8 * (2 + hd)], out fp32 [G*nt, DI]. */
 int la_twoway_t2i(const float* img, const void* wk_hi, const void* wk_lo, const void* wv_hi, const void* wv_lo, const float* pek,
                   const float* bv, const float* q, int G, int hw, int nt, int D, int heads, float* part, float* out, void* stream);
 
 /* image -> tokens attention + out_proj + residual + LayerNorm (cross_attn_image_to_token + norm4), IN PLACE:
- * img <- LN(img + softmax_t((img Wq^T + peq) . k^T / sqrt(16)) v Wo^T + bo).  k, v fp32 [G*nt, 128] (projected token keys / values),
- * wq planes [128, D], wo planes [D, 128], nt <= 32. */
+ * img <- LN(img + softmax_t((img Wq^T + peq) . k^T / sqrt(hd)) v Wo^T + bo).  k, v fp32 [G*nt, DI] (projected token keys / values),
+ * wq planes [DI, D], wo planes [D, DI], nt <= 32. */
 int la_twoway_i2t(float* img, const void* wq_hi, const void* wq_lo, const float* peq, const float* k, const float* v, const void* wo_hi,
                   const void* wo_lo, const float* bo, const float* gamma, const float* beta, float eps, int G, int hw, int nt, int D,
                   int heads, void* stream);

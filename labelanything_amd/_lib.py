@@ -404,11 +404,16 @@ def row_broadcast(src, groups: int, rep: int, d: int, scale: float, out) -> None
 
 
 # ---- fused image-side kernels of the two-way transformer (csrc/twoway.hip) -----------------------------------------------------
+def twoway_part_size(groups: int, hw: int, nt: int, d: int) -> int:
+    """fp32 elements of la_twoway_t2i's partials buffer: [groups][64-row tiles][2 row tiles of 32][nt][8 heads][2 + head width]."""
+    return groups * ((hw + 63) // 64) * 2 * nt * 8 * (2 + d // 16)
+
+
 def twoway_t2i(img, wk, wv, pek, bv, q, groups: int, hw: int, nt: int, heads: int, part, out) -> None:
-    """wk / wv: (hi, lo) fp16 plane pairs [128, D]; pek = pe @ Wk.T + bk [hw, 128]."""
+    """wk / wv: (hi, lo) fp16 plane pairs [D / 2, D]; pek = pe @ Wk.T + bk [hw, D / 2].  D = 256 or 512, 8 heads."""
     _f32c(img, pek, bv, q, part, out)
     d = img.shape[1]
-    need = groups * ((hw + 127) // 128) * 4 * nt * 8 * 18
+    need = twoway_part_size(groups, hw, nt, d)
     if part.numel() < need:
         raise ValueError(f"twoway_t2i: scratch too small ({part.numel()} < {need})")
     _check(lib().la_twoway_t2i(_ptr(img), _ptr(wk[0]), _ptr(wk[1]), _ptr(wv[0]), _ptr(wv[1]), _ptr(pek), _ptr(bv), _ptr(q),
@@ -417,7 +422,7 @@ def twoway_t2i(img, wk, wv, pek, bv, q, groups: int, hw: int, nt: int, heads: in
 
 
 def twoway_i2t(img, wq, peq, k, v, wo, bo, gamma, beta, eps: float, groups: int, hw: int, nt: int, heads: int) -> None:
-    """peq = pe @ Wq.T + bq [hw, 128]; img is updated in place."""
+    """peq = pe @ Wq.T + bq [hw, D / 2]; img is updated in place."""
     _f32c(img, peq, k, v, bo, gamma, beta)
     _check(lib().la_twoway_i2t(_ptr(img), _ptr(wq[0]), _ptr(wq[1]), _ptr(peq), _ptr(k), _ptr(v), _ptr(wo[0]), _ptr(wo[1]), _ptr(bo),
                                _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(groups), C.c_int(hw), C.c_int(nt), C.c_int(img.shape[1]),

@@ -1,7 +1,7 @@
 // Fused image-side kernels of the TwoWayTransformer (models/transformer.py:255-329, common.py:57-148): the (groups, hw, D) fp32
 // stream of the prompt encoder / mask decoder is read ONCE per attention instead of once per projection, score pass and norm.
 //
-//   la_twoway_t2i  tokens -> image attention: per 128-row tile  K = x Wk^T + PEK,  V = x Wv^T + bv  on the fast MFMA with operands split
+//   la_twoway_t2i  tokens -> image attention: per 64-row tile  K = x Wk^T + PEK,  V = x Wv^T + bv  on the fast MFMA with operands split
 //                  on the fly (x = x_hi + x_lo fp16 planes, weights pre-split: hi.hi + lo.hi + hi.lo, ~21 mantissa bits), then the
 //                  tile's softmax partials (m, l, sum p V) for every (token, head) straight from the accumulator layout - K and V never
 //                  leave the registers.  la_twoway_merge folds the partials of a group's tiles.
@@ -9,28 +9,43 @@
 //                  group's tokens per head, O -> [hi | lo] planes in LDS -> Y = O Wo^T + bo + x -> LN -> written back in place.
 //                  One read and one write of the stream per layer.
 // The positional encoding never enters the kernels: (x + pe) W^T + b = x W^T + (pe W^T + b), and PEK / PEQ = pe W^T + b is a constant
-// [hw, 128] table per layer (the caller computes it once).
+// [hw, DI] table per layer (the caller computes it once).
 //
-// A tile's 128 rows are requested in ONE burst and live in registers for the whole kernel (wave w owns rows 32 w .. 32 w + 31, lane l
-// the columns 4 l .. 4 l + 3: 1 KiB coalesced per row): one memory latency per tile instead of one per k-chunk, and the residual of
-// the LayerNorm epilogue needs no second read.  One workgroup of 4 waves per CU (512 registers per lane).
-// D = 256 (internal 128, 8 heads of 16): the geometry of every published model (other widths take the unfused path).
+// Round 4 shape (rounds 1-3: one 128-row tile per CU, 4 waves of 512 registers).  A tile is 64 rows; its 4 waves form a 2 x 2 grid -
+// wave (rt, ch) multiplies row tile rt (32 rows) against column half ch of every product - and, for the published decoder width
+// D = 256, a workgroup needs 80 KiB of LDS and <= 256 registers per lane, so TWO tiles are in flight per CU: one tile's row burst /
+// store burst overlaps the other's MFMA phases, and every SIMD holds two waves (a lone wave issues a VALU instruction every ~8 cycles,
+// two waves every ~4: profiles/r03_notes.md 3).  The same code instantiated for D = 512 (the published SAM-1024 decoder geometry,
+// parameters/validation/old/COCO_Fold0_sam.yaml:255-270; internal width 256, 8 heads of 32) takes 160 KiB and one tile per CU.
+// Rows are requested in ONE burst and live in registers for the whole kernel (wave w owns rows 16 w .. 16 w + 15 for loading, staging
+// and the LayerNorm epilogue; lane l the columns 4 l .. 4 l + 3 of every 256-column block: 1 KiB coalesced per row and block).
+// Weights stream through LDS in "k16 slabs": for 16 consecutive K columns, [plane][rows][32 B] (LDS-DMA pieces of 32 rows), ring of three.
 #include <cstdlib>
 #include "la_common.h"
 #include "../../include/la_hip.h"
 
 namespace la {
 
-constexpr int TW_ROWS = 128;      // stream rows per workgroup
-constexpr int TW_BK = 32;         // columns per weight chunk
-constexpr int TW_DI = 128;        // internal width of the cross attentions (D / 2)
-constexpr int TW_HD = 16;         // head width
-constexpr int TW_APLANE = TW_ROWS * 64;     // one 32-column plane chunk: 128 rows x 64 B = 8 KiB
+constexpr int TW_ROWS = 64;       // stream rows per workgroup
+constexpr int TW_APL = TW_ROWS * 64;        // one 32-column plane chunk of the tile: 64 rows x 64 B = 4 KiB
+constexpr int TW_XPL = 2 * 4 * TW_APL;      // x planes in LDS: [hi | lo][4 chunks] = 128 columns at a time, 32 KiB
 constexpr int TW_MAXT = 32;
-constexpr int TW_YLD = 256 + 4;
+
+template <int DI> struct TwCfg {
+  static constexpr int D = 2 * DI;          // stream width
+  static constexpr int HD = DI / 8;         // head width (8 heads)
+  static constexpr int NV = D / 256;        // float4 per lane and row
+  static constexpr int NJ = DI / 64;        // 32-column accumulator tiles per wave in the DI-wide products (column half ch)
+  static constexpr int NY = D / 64;         // ... in the D-wide product Y = O Wo^T
+  static constexpr int NCO = DI / 32;       // 32-column chunks of O
+  static constexpr int YLD = D + 4;
+};
 
 // 64-byte rows (32 halfs): 16-byte chunk c of row r in slot c ^ ((r >> 2) & 3) - conflict-free ds_read_b128 fragments
 __device__ __forceinline__ int tw_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// 32-byte rows of a k16 weight slab: 16-byte half c of row r in slot c ^ ((r >> 3) & 1) (16 consecutive rows = 512 B = all 64 banks twice;
+// the flip moves rows 8-15 of every 16 onto the other half of the bank row)
+__device__ __forceinline__ int tw_woff(int row, int c) { return row * 32 + ((c ^ ((row >> 3) & 1)) << 4); }
 
 // hi / lo planes of 4 consecutive values -> two 8-byte LDS stores
 __device__ __forceinline__ void split_store4(char* hi_plane, char* lo_plane, int off, float4 v) {
@@ -44,27 +59,53 @@ __device__ __forceinline__ void split_store4(char* hi_plane, char* lo_plane, int
   *reinterpret_cast<uint2*>(lo_plane + off) = l;
 }
 
-// this wave's 32 rows of the tile: row rr in xs[rr], lane -> columns 4 lane .. 4 lane + 3 (rows beyond hw read as zero)
-__device__ __forceinline__ void load_rows(const float* xg, int D, int row0, int hw, int lane, float4 (&xs)[32]) {
+// this wave's 16 rows of the tile: row rr, 256-column block v in xs[rr][v], lane -> columns 256 v + 4 lane .. + 3 (rows beyond hw read as zero)
+template <int NV>
+__device__ __forceinline__ void load_rows(const float* xg, int D, int row0, int hw, int lane, float4 (&xs)[16][NV]) {
 #pragma unroll
-  for (int rr = 0; rr < 32; ++rr) {
+  for (int rr = 0; rr < 16; ++rr) {
     const int row = row0 + rr;
-    xs[rr] = *reinterpret_cast<const float4*>(xg + (size_t)min(row, hw - 1) * D + lane * 4);
-    if (row >= hw) xs[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xs[rr][v] = *reinterpret_cast<const float4*>(xg + (size_t)min(row, hw - 1) * D + v * 256 + lane * 4);
+      if (row >= hw) xs[rr][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 
-// columns [128 half, +128) of this wave's rows -> A-operand plane chunks [4][128 rows x 64 B] (hi at pa, lo at pa + 4 planes); the 32
+// columns [128 sg, +128) of this wave's 16 rows -> A-operand plane chunks [4][64 rows x 64 B] (hi at pa, lo at pa + 4 chunks); the 32
 // lanes that hold those columns do the work
-__device__ __forceinline__ void stage_half(char* pa, int wave, int lane, int half, const float4 (&xs)[32]) {
-  if ((lane >> 5) == half) {
+template <int NV>
+__device__ __forceinline__ void stage_group(char* pa, int wave, int lane, int sg, const float4 (&xs)[16][NV]) {
+  if ((lane >> 5) == (sg & 1)) {
     const int li = lane & 31;
-    char* hi = pa + (li >> 3) * TW_APLANE;
-    char* lo = hi + 4 * TW_APLANE;
+    char* hi = pa + (li >> 3) * TW_APL;
+    char* lo = hi + 4 * TW_APL;
     const int sub = (li & 1) * 8, c16 = (li & 7) >> 1;
 #pragma unroll
-    for (int rr = 0; rr < 32; ++rr) split_store4(hi, lo, tw_off(wave * 32 + rr, c16) + sub, xs[rr]);
+    for (int rr = 0; rr < 16; ++rr) split_store4(hi, lo, tw_off(wave * 16 + rr, c16) + sub, xs[rr][sg >> 1]);
   }
+}
+
+// One k16 slab of NP weight planes with NR rows each: K columns [16 kk, +16) of every row, [plane][row][32 B] (tw_woff) at LDS byte
+// address dst.  Pieces of 32 rows (1 KiB); the workgroup's 4 waves take pieces wave, wave + 4, ...  (NP * NR / 32 pieces, a multiple of 4)
+template <int NP, int NR>
+__device__ __forceinline__ void dma_slab(const f16_t* const (&planes)[NP], int ldw, int kk, unsigned dst, int wave, int lane) {
+  constexpr int PIECES = NP * NR / 32;
+#pragma unroll
+  for (int i = 0; i < PIECES / 4; ++i) {
+    const int piece = i * 4 + wave;
+    const int plane = piece / (NR / 32), r = (piece % (NR / 32)) * 32 + (lane >> 1);
+    const int c = (lane & 1) ^ ((r >> 3) & 1);
+    dma16(planes[plane] + (size_t)r * ldw + kk * 16 + c * 8, dst + piece * 1024);
+  }
+}
+
+// head sum over HD consecutive lanes of the 32-lane half
+template <int HD> __device__ __forceinline__ float head_sum(float v) {
+  v = row16_sum(v);
+  if (HD == 32) v += __shfl_xor(v, 16, 64);
+  return v;
 }
 
 struct TwT2iArgs {
@@ -73,118 +114,103 @@ struct TwT2iArgs {
   const float* pek;      // [hw, DI]  pe Wk^T + bk
   const float* bv;       // [DI]
   const float* q;        // [G * nt, DI] projected queries (bias included)
-  float* part;           // [G][S][4][nt][8][2 + HD]
-  int G, hw, nt, D, S;
+  float* part;           // [G][S][2][nt][8][2 + HD]
+  int G, hw, nt, S;
   float scale;
 };
 
-// LDS: x planes [0, 64K) (half of K at a time) | weight ring: three chunks of 32 KiB (wk_hi, wk_lo, wv_hi, wv_lo x 128 rows x 64 B) at [64K, 160K)
-__global__ __launch_bounds__(256, 1) void twoway_t2i_kernel(TwT2iArgs a) {
+// LDS: x planes [0, 32K) (128 columns of K at a time) | ring of three k16 slabs (wk_hi, wk_lo, wv_hi, wv_lo x DI rows x 32 B) behind them
+template <int DI>
+__global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_t2i_kernel(TwT2iArgs a) {
+  using C = TwCfg<DI>;
+  constexpr int SLAB = 4 * DI * 32, NKK = C::D / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* pa = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 1, ch = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
   const int g = blockIdx.y, split = blockIdx.x;
   const int row0 = split * TW_ROWS;
-  const float* xg = a.img + (size_t)g * a.hw * a.D;
+  const float* xg = a.img + (size_t)g * a.hw * C::D;
+  const f16_t* const planes[4] = {a.wk_hi, a.wk_lo, a.wv_hi, a.wv_lo};
+  const unsigned lds_w = lds_addr_of(smem + TW_XPL);
+  constexpr int PW = 4 * DI / 32 / 4;               // DMA pieces per wave and slab
+  dma_slab<4, DI>(planes, C::D, 0, lds_w, wave, lane);
+  dma_slab<4, DI>(planes, C::D, 1, lds_w + SLAB, wave, lane);
+  float4 xs[16][C::NV];
+  load_rows<C::NV>(xg, C::D, row0 + wave * 16, a.hw, lane, xs);
+  float pk[C::NJ][16];               // this lane's entries of the PEK table (accumulator layout): requested BEHIND the row burst (below)
 
-  // weight chunk = 4 planes x 128 rows = 32 pieces of 16 rows, 8 per wave; ring of three chunks, all three issued BEFORE the row burst so
-  // that they are on chip by the time the rows are (vmcnt retires in order)
-  unsigned wsoff[8];
-  const f16_t* wbase[8];
+  f32x16 kacc[C::NJ], vacc[C::NJ];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int piece = wave * 8 + i;
-    const int r = (piece & 7) * 16 + (lane >> 2);
-    wsoff[i] = (unsigned)(((size_t)r * a.D + (((lane & 3) ^ ((r >> 2) & 3)) << 3)) * 2);
-    const int plane = piece >> 3;
-    wbase[i] = plane == 0 ? a.wk_hi : plane == 1 ? a.wk_lo : plane == 2 ? a.wv_hi : a.wv_lo;
-  }
-  const unsigned lds_w = lds_addr_of(smem + 65536);
-  auto dma_w = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma16s(wbase[i] + kc * TW_BK, wsoff[i], lds_w + (kc % 3) * 32768 + (wave * 8 + i) * 1024);
-  };
-  dma_w(0);
-  dma_w(1);
-  dma_w(2);
-  float4 xs[32];
-  load_rows(xg, a.D, row0 + wave * 32, a.hw, lane, xs);
-  float pk[4][16];                  // this lane's 64 entries of the PEK table (accumulator layout), requested with the rows
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      pk[j][r] = a.pek[(size_t)min(row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1) * TW_DI + j * 32 + fr];
-
-  f32x16 kacc[4], vacc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) kacc[j][r] = vacc[j][r] = 0.f;
 
-  const int nkc = a.D / TW_BK;       // 8
-  for (int kc = 0; kc < nkc; ++kc) {
-    if ((kc & 3) == 0) stage_half(pa, wave, lane, kc >> 2, xs);      // (waits for the row burst the first time, hence for chunks 0-2)
-    if (kc >= 1 && kc + 2 < nkc) dma_w(kc + 2);                      // into the slot chunk kc - 1 left at the last barrier
-    {                                                                // chunk kc landed; the (up to two) younger ones stay in flight
-      const int younger = min(2, nkc - 1 - kc);
-      if (younger == 2) dma_wait<16>();
-      else if (younger == 1) dma_wait<8>();
-      else dma_wait<0>();
-    }
+  for (int kk = 0; kk < NKK; ++kk) {
+    if (kk + 1 < NKK) dma_wait<PW>();                // slab kk landed (slab kk + 1 may still travel)
+    else dma_wait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                    // ... for every wave, and every wave is done with step kk - 1
     asm volatile("" ::: "memory");
-    const char* pw = smem + 65536 + (kc % 3) * 32768;
-    const char* pah = pa + (kc & 3) * TW_APLANE;
+    if (kk + 2 < NKK) dma_slab<4, DI>(planes, C::D, kk + 2, lds_w + ((kk + 2) % 3) * SLAB, wave, lane);
+    if ((kk & 7) == 0) {                             // next 128 columns of the rows -> planes (the first time: waits for the row burst)
+      stage_group<C::NV>(pa, wave, lane, kk >> 3, xs);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kk == 0) {                                 // only needed behind the loop: 16 NJ more requests per lane that would stretch the burst
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(wave * 32 + fr, ks * 2 + fh));
-      const uint4 al = *reinterpret_cast<const uint4*>(pah + 4 * TW_APLANE + tw_off(wave * 32 + fr, ks * 2 + fh));
+        for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint4 wf[4];
-#pragma unroll
-        for (int pl = 0; pl < 4; ++pl) wf[pl] = *reinterpret_cast<const uint4*>(pw + pl * TW_APLANE + tw_off(j * 32 + fr, ks * 2 + fh));
-        kacc[j] = Half16<f16_t>::mfma32(ah, wf[0], kacc[j]);
-        kacc[j] = Half16<f16_t>::mfma32(al, wf[0], kacc[j]);
-        kacc[j] = Half16<f16_t>::mfma32(ah, wf[1], kacc[j]);
-        vacc[j] = Half16<f16_t>::mfma32(ah, wf[2], vacc[j]);
-        vacc[j] = Half16<f16_t>::mfma32(al, wf[2], vacc[j]);
-        vacc[j] = Half16<f16_t>::mfma32(ah, wf[3], vacc[j]);
+          for (int r = 0; r < 16; ++r)
+            pk[j][r] = a.pek[(size_t)min(row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1) * DI + ch * (DI / 2) + j * 32 + fr];
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();    // weight slot kc % 3 (and, every 4th chunk, the x planes) may be restaged
-    asm volatile("" ::: "memory");
+    const char* pw = smem + TW_XPL + (kk % 3) * SLAB;
+    const char* pah = pa + ((kk >> 1) & 3) * TW_APL;
+    const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
+    const uint4 al = *reinterpret_cast<const uint4*>(pah + 4 * TW_APL + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
+#pragma unroll
+    for (int j = 0; j < C::NJ; ++j) {
+      const int wr = ch * (DI / 2) + j * 32 + fr;
+      uint4 wf[4];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) wf[pl] = *reinterpret_cast<const uint4*>(pw + pl * DI * 32 + tw_woff(wr, fh));
+      kacc[j] = Half16<f16_t>::mfma32(ah, wf[0], kacc[j]);
+      kacc[j] = Half16<f16_t>::mfma32(al, wf[0], kacc[j]);
+      kacc[j] = Half16<f16_t>::mfma32(ah, wf[1], kacc[j]);
+      vacc[j] = Half16<f16_t>::mfma32(ah, wf[2], vacc[j]);
+      vacc[j] = Half16<f16_t>::mfma32(al, wf[2], vacc[j]);
+      vacc[j] = Half16<f16_t>::mfma32(ah, wf[3], vacc[j]);
+    }
   }
-  // ---- + PEK / bv; accumulator layout: lane -> column j*32 + fr, register r -> row (r & 3) + 8 (r >> 2) + 4 fh of the wave's 32 rows -------
+  // ---- + PEK / bv; accumulator layout: lane -> column ch DI/2 + j 32 + fr, register r -> row (r & 3) + 8 (r >> 2) + 4 fh of row tile rt --
   bool rv[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) rv[r] = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh < a.hw;
+  for (int r = 0; r < 16; ++r) rv[r] = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh < a.hw;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float bvv = a.bv[j * 32 + fr];
+  for (int j = 0; j < C::NJ; ++j) {
+    const float bvv = a.bv[ch * (DI / 2) + j * 32 + fr];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       kacc[j][r] += pk[j][r];
       vacc[j][r] += bvv;
     }
   }
-  // ---- softmax partials of every (token, head) over this wave's 32 rows -------------------------------------------------------------------
-  // a head = 16 consecutive columns = one 16-lane row of the wave: q.k is a 16-lane butterfly sum, the row set of a lane is (r, fh)
-  float* pbase = a.part + (((size_t)g * a.S + split) * 4 + wave) * a.nt * 8 * (2 + TW_HD);
+  // ---- softmax partials of every (token, head of this column half) over the wave's 32 rows ----------------------------------------------
+  // a head = HD consecutive columns = HD consecutive lanes: q.k is a lane butterfly, the row set of a lane is (r, fh)
+  float* pbase = a.part + (((size_t)g * a.S + split) * 2 + rt) * a.nt * 8 * (2 + C::HD);
   for (int t = 0; t < a.nt; ++t) {
-    const float* qt = a.q + ((size_t)g * a.nt + t) * TW_DI;
+    const float* qt = a.q + ((size_t)g * a.nt + t) * DI + ch * (DI / 2);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < C::NJ; ++j) {
       const float qv = qt[j * 32 + fr] * a.scale;
       float s[16];
       float m = -3.0e38f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = row16_sum(kacc[j][r] * qv);
+        const float v = head_sum<C::HD>(kacc[j][r] * qv);
         s[r] = rv[r] ? v : -3.0e38f;
         m = fmaxf(m, s[r]);
       }
@@ -199,10 +225,11 @@ __global__ __launch_bounds__(256, 1) void twoway_t2i_kernel(TwT2iArgs a) {
       l += __shfl_xor(l, 32, 64);
       o += __shfl_xor(o, 32, 64);
       if (fh == 0) {
-        const int head = j * 2 + (fr >> 4);
-        float* dst = pbase + ((size_t)t * 8 + head) * (2 + TW_HD);
-        dst[2 + (fr & 15)] = o;
-        if ((fr & 15) == 0) {
+        const int col = j * 32 + fr;
+        const int head = ch * 4 + col / C::HD;
+        float* dst = pbase + ((size_t)t * 8 + head) * (2 + C::HD);
+        dst[2 + (col % C::HD)] = o;
+        if ((col % C::HD) == 0) {
           dst[0] = m;
           dst[1] = l;
         }
@@ -211,12 +238,13 @@ __global__ __launch_bounds__(256, 1) void twoway_t2i_kernel(TwT2iArgs a) {
   }
 }
 
-// fold the partials of a group's tiles: out[g, t, head * HD + c] = sum_p e^{m_p - M} o_p / sum_p e^{m_p - M} l_p
-__global__ __launch_bounds__(128) void twoway_merge_kernel(const float* __restrict__ part, int nparts, int nt, float* __restrict__ out) {
+// fold the partials of a group's tiles: out[g, t, head * HD + c] = sum_p e^{m_p - M} o_p / sum_p e^{m_p - M} l_p   (8 HD threads)
+template <int HD>
+__global__ __launch_bounds__(8 * HD) void twoway_merge_kernel(const float* __restrict__ part, int nparts, int nt, float* __restrict__ out) {
   const int g = blockIdx.y, t = blockIdx.x;
-  const int head = threadIdx.x >> 4, c = threadIdx.x & 15;
-  const float* p0 = part + ((size_t)g * nparts * nt + t) * 8 * (2 + TW_HD) + head * (2 + TW_HD);
-  const size_t pstride = (size_t)nt * 8 * (2 + TW_HD);
+  const int head = threadIdx.x / HD, c = threadIdx.x % HD;
+  const float* p0 = part + ((size_t)g * nparts * nt + t) * 8 * (2 + HD) + head * (2 + HD);
+  const size_t pstride = (size_t)nt * 8 * (2 + HD);
   float M = -3.0e38f;
   for (int p = 0; p < nparts; ++p) M = fmaxf(M, p0[p * pstride]);
   float l = 0.f, o = 0.f;
@@ -225,18 +253,18 @@ __global__ __launch_bounds__(128) void twoway_merge_kernel(const float* __restri
     l += f * p0[p * pstride + 1];
     o += f * p0[p * pstride + 2 + c];
   }
-  out[((size_t)g * nt + t) * TW_DI + head * TW_HD + c] = o / l;
+  out[((size_t)g * nt + t) * (8 * HD) + head * HD + c] = o / l;
 }
 
 // =================================================================================================================================
 // image -> tokens attention + out_proj + residual + LayerNorm, in place on the stream.
-//   phase 1  Q = x Wq^T (+ PEQ)          8 weight chunks of 32 columns (LDS-DMA ring of two), x planes staged half of K at a time
-//   phase 2  per 32-column tile (= 2 heads): online softmax over the group's tokens (token k / v in LDS as fp32), 16-lane butterfly for
-//            q.k; O = softmax . v goes to LDS as [hi | lo] planes in the MFMA A-operand image (each wave reads back only its own rows)
-//   phase 3  Y = O Wo^T                  4 weight chunks of 32 columns of O; 8 accumulator tiles per wave
-//   phase 4  Y + bo -> LDS (row-major fp32), then one WAVE per row: + x (still in registers), LayerNorm, 1 KiB coalesced store
-// LDS (160 KiB): x planes, later O planes [0, 64K) | weight ring [64K, 128K) (2 x 16 KiB in phase 1, 2 x 32 KiB in phase 3) | token
-// k / v fp32 [128K, 160K); the Y tile of phase 4 (130 KiB) reuses everything.  nt <= 32.
+//   phase 1  Q = x Wq^T (+ PEQ)          D / 16 k16 slabs of Wq, two per barrier (ring of three pairs), x planes staged 128 columns of K at a time
+//   phase 2  per 32-column tile: online softmax over the group's tokens (their k / v rows come straight from global memory: a few KiB,
+//            L1-resident), lane butterfly for q.k; O = softmax . v goes to LDS as [hi | lo] planes in the MFMA A-operand image
+//   phase 3  Y = O Wo^T                  DI / 16 k16 slabs of Wo; D / 64 accumulator tiles per wave
+//   phase 4  Y + bo -> LDS (row-major fp32), then one WAVE per row: + x (still in registers), LayerNorm, coalesced store
+// LDS: x planes [0, 32K), later the O planes [0, DI / 32 x 8K) | slab ring behind max(x planes, O planes); the Y tile of phase 4 reuses
+// everything.  D = 256: 80 KiB (two workgroups per CU); D = 512: 160 KiB.  nt <= 32.
 // =================================================================================================================================
 struct TwI2tArgs {
   float* img;            // [G * hw, D] in / out
@@ -246,111 +274,112 @@ struct TwI2tArgs {
   const f16_t *wo_hi, *wo_lo;      // [D, DI]
   const float *bo, *gamma, *beta;  // [D]
   float eps, scale;
-  int G, hw, nt, D;
+  int G, hw, nt;
 };
 
-__global__ __launch_bounds__(256, 1) void twoway_i2t_kernel(TwI2tArgs a) {
+#ifdef LA_DEBUG
+__device__ unsigned long long g_tw_stamps[4 * 16];      // [wave][i]: s_memtime of workgroup (0, 0) at the phase boundaries of twoway_i2t_kernel
+#define TW_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                                                         \
+      unsigned long long t_;                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+      if ((threadIdx.x & 63) == 0) g_tw_stamps[(threadIdx.x >> 6) * 16 + (i)] = t_;                   \
+    }                                                                                                 \
+  } while (0)
+#else
+#define TW_STAMP(i) do {} while (0)
+#endif
+
+template <int DI>
+__global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_i2t_kernel(TwI2tArgs a) {
+  using C = TwCfg<DI>;
+  constexpr int D = C::D;
+  constexpr int SLAB1 = 2 * DI * 32, SLAB3 = 2 * D * 32, NKK1 = D / 16, NKK3 = DI / 16;
+  constexpr int OPL = 2 * C::NCO * TW_APL;                          // O planes: 32 KiB (DI 128) / 64 KiB (DI 256)
+  constexpr int RING0 = OPL > TW_XPL ? OPL : TW_XPL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* pa = smem;                                   // x planes (phase 1), O planes (phases 2-3): [hi | lo][4 chunks][128 rows x 64 B]
-  float* tk = reinterpret_cast<float*>(smem + 131072);            // [nt][128]
-  float* tv = tk + TW_MAXT * TW_DI;                               // [nt][128]
-  float* yt = reinterpret_cast<float*>(smem);        // phase 4: [128][TW_YLD]
+  char* pa = smem;                                   // x planes (phase 1), O planes (phases 2-3)
+  float* yt = reinterpret_cast<float*>(smem);        // phase 4: [64][YLD]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = wave >> 1, ch = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
   const int g = blockIdx.y, row0 = blockIdx.x * TW_ROWS;
-  float* xg = a.img + (size_t)g * a.hw * a.D;
+  float* xg = a.img + (size_t)g * a.hw * D;
 
-  // phase-1 weight ring: four chunks of 16 KiB (wq_hi, wq_lo x 128 rows x 64 B); the first four leave BEFORE the row burst, so they are
-  // on chip by the time the rows are (vmcnt retires in order)
-  unsigned wsoff[4];
-  const f16_t* wbase[4];
+  const f16_t* const wq[2] = {a.wq_hi, a.wq_lo};
+  const f16_t* const wo[2] = {a.wo_hi, a.wo_lo};
+  const unsigned lds_w = lds_addr_of(smem + RING0);
+  constexpr int PW1 = 2 * DI / 32 / 4, PW3 = 2 * D / 32 / 4;        // DMA pieces per wave and slab
+  TW_STAMP(0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;                  // 2 planes x 8 groups of 16 rows
-    const int r = (piece & 7) * 16 + (lane >> 2);
-    wsoff[i] = (unsigned)(((size_t)r * a.D + (((lane & 3) ^ ((r >> 2) & 3)) << 3)) * 2);
-    wbase[i] = (piece >> 3) ? a.wq_lo : a.wq_hi;
-  }
-  const unsigned lds_w = lds_addr_of(smem + 65536);
-  auto dma_wq = [&](int kc) {
+  for (int k0 = 0; k0 < 4; ++k0) dma_slab<2, DI>(wq, D, k0, lds_w + k0 * SLAB1, wave, lane);
+  float4 xs[16][C::NV];
+  load_rows<C::NV>(xg, D, row0 + wave * 16, a.hw, lane, xs);
+  float pq[C::NJ][16];               // this lane's entries of the PEQ table (accumulator layout): requested BEHIND the row burst (below)
+  // ---- phase 1: k32 steps (two k16 slabs per barrier), ring of three slab pairs ---------------------------------------------------------
+  f32x16 qacc[C::NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma16s(wbase[i] + kc * TW_BK, wsoff[i], lds_w + (kc & 3) * 16384 + (wave * 4 + i) * 1024);
-  };
-#pragma unroll
-  for (int kc = 0; kc < 4; ++kc) dma_wq(kc);
-  float4 xs[32];
-  load_rows(xg, a.D, row0 + wave * 32, a.hw, lane, xs);
-  // this lane's 64 entries of the PEQ table (accumulator layout), requested together with the rows: one latency, not 64
-  float pq[4][16];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1);
-      pq[j][r] = a.peq[(size_t)row * TW_DI + j * 32 + fr];
-    }
-  for (int i = tid; i < a.nt * TW_DI; i += 256) {
-    tk[i] = a.k[(size_t)g * a.nt * TW_DI + i];
-    tv[i] = a.v[(size_t)g * a.nt * TW_DI + i];
-  }
-  // ---- phase 1 ------------------------------------------------------------------------------------------------------------------
-  f32x16 qacc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) qacc[j][r] = 0.f;
-  const int nkc = a.D / TW_BK;       // 8
-  for (int kc = 0; kc < nkc; ++kc) {
-    if ((kc & 3) == 0) stage_half(pa, wave, lane, kc >> 2, xs);
-    if (kc >= 1 && kc + 3 < nkc) dma_wq(kc + 3);                      // into the slot chunk kc - 1 left at the last barrier
-    {                                                                 // chunk kc landed; the (up to three) younger ones stay in flight
-      const int younger = min(3, nkc - 1 - kc);
-      if (younger == 3) dma_wait<12>();
-      else if (younger == 2) dma_wait<8>();
-      else if (younger == 1) dma_wait<4>();
-      else dma_wait<0>();
-    }
+  for (int kp = 0; kp < NKK1 / 2; ++kp) {
+    if (kp + 1 < NKK1 / 2) dma_wait<2 * PW1>();      // pair kp landed (pair kp + 1 may still travel)
+    else dma_wait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* pw = smem + 65536 + (kc & 3) * 16384;
-    const char* pah = pa + (kc & 3) * TW_APLANE;
+    if (kp + 2 < NKK1 / 2) {
+      dma_slab<2, DI>(wq, D, 2 * kp + 4, lds_w + ((2 * kp + 4) % 6) * SLAB1, wave, lane);
+      dma_slab<2, DI>(wq, D, 2 * kp + 5, lds_w + ((2 * kp + 5) % 6) * SLAB1, wave, lane);
+    }
+    if ((kp & 3) == 0) {
+      stage_group<C::NV>(pa, wave, lane, kp >> 2, xs);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kp == 0) {
+        TW_STAMP(1);                                 // row burst landed, first 128 columns staged
+        // the PEQ entries are only needed in phase 2: 16 NJ more requests per lane that would otherwise stretch the row burst
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(wave * 32 + fr, ks * 2 + fh));
-      const uint4 al = *reinterpret_cast<const uint4*>(pah + 4 * TW_APLANE + tw_off(wave * 32 + fr, ks * 2 + fh));
+        for (int j = 0; j < C::NJ; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint4 wh = *reinterpret_cast<const uint4*>(pw + tw_off(j * 32 + fr, ks * 2 + fh));
-        const uint4 wl = *reinterpret_cast<const uint4*>(pw + TW_APLANE + tw_off(j * 32 + fr, ks * 2 + fh));
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1);
+            pq[j][r] = a.peq[(size_t)row * DI + ch * (DI / 2) + j * 32 + fr];
+          }
+      }
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int kk = 2 * kp + h2;
+      const char* pw = smem + RING0 + (kk % 6) * SLAB1;
+      const char* pah = pa + (kp & 3) * TW_APL;
+      const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(rt * 32 + fr, h2 * 2 + fh));
+      const uint4 al = *reinterpret_cast<const uint4*>(pah + 4 * TW_APL + tw_off(rt * 32 + fr, h2 * 2 + fh));
+#pragma unroll
+      for (int j = 0; j < C::NJ; ++j) {
+        const int wr = ch * (DI / 2) + j * 32 + fr;
+        const uint4 wh = *reinterpret_cast<const uint4*>(pw + tw_woff(wr, fh));
+        const uint4 wl = *reinterpret_cast<const uint4*>(pw + DI * 32 + tw_woff(wr, fh));
         qacc[j] = Half16<f16_t>::mfma32(ah, wh, qacc[j]);
         qacc[j] = Half16<f16_t>::mfma32(al, wh, qacc[j]);
         qacc[j] = Half16<f16_t>::mfma32(ah, wl, qacc[j]);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
   }
-  // phase 3's first two weight chunks travel during the attention phase (the ring is free: every wave passed the last barrier)
-  unsigned osoff[8];
-  const f16_t* obase[8];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the x planes and the phase-1 ring
+  asm volatile("" ::: "memory");
+  TW_STAMP(2);                                       // phase 1 done
+  // phase 3's first two weight slabs travel during the attention phase
+  dma_slab<2, D>(wo, DI, 0, lds_w, wave, lane);
+  dma_slab<2, D>(wo, DI, 1, lds_w + SLAB3, wave, lane);
+  // ---- phase 2: attention over the tokens, one 32-column tile at a time ----------------------------------------------------------
+  const float* tkg = a.k + (size_t)g * a.nt * DI + ch * (DI / 2);
+  const float* tvg = a.v + (size_t)g * a.nt * DI + ch * (DI / 2);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int piece = wave * 8 + i;                  // 2 planes x 16 groups of 16 rows (Wo has D = 256 rows)
-    const int r = (piece & 15) * 16 + (lane >> 2);
-    osoff[i] = (unsigned)(((size_t)r * TW_DI + (((lane & 3) ^ ((r >> 2) & 3)) << 3)) * 2);
-    obase[i] = (piece >> 4) ? a.wo_lo : a.wo_hi;
-  }
-  auto dma_wo = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma16s(obase[i] + kc * TW_BK, osoff[i], lds_w + (kc & 1) * 32768 + (wave * 8 + i) * 1024);
-  };
-  dma_wo(0);
-  dma_wo(1);
-  // ---- phase 2: attention over the tokens, one 32-column tile (two heads) at a time -------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < C::NJ; ++j) {
     float m[16], l[16], o[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -359,10 +388,10 @@ __global__ __launch_bounds__(256, 1) void twoway_i2t_kernel(TwI2tArgs a) {
       l[r] = o[r] = 0.f;
     }
     for (int t = 0; t < a.nt; ++t) {
-      const float kv = tk[t * TW_DI + j * 32 + fr], vv = tv[t * TW_DI + j * 32 + fr];
+      const float kv = tkg[t * DI + j * 32 + fr], vv = tvg[t * DI + j * 32 + fr];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float s = row16_sum(qacc[j][r] * kv);
+        const float s = head_sum<C::HD>(qacc[j][r] * kv);
         const float mn = fmaxf(m[r], s);
         const float corr = __expf(m[r] - mn), p = __expf(s - mn);
         l[r] = l[r] * corr + p;
@@ -370,102 +399,150 @@ __global__ __launch_bounds__(256, 1) void twoway_i2t_kernel(TwI2tArgs a) {
         m[r] = mn;
       }
     }
-    // O -> [hi | lo] planes in the A-operand image of k-chunk j: row = wave * 32 + (r & 3) + 8 (r >> 2) + 4 fh, column fr.  Lane pairs
-    // (fr, fr ^ 1) hold neighbouring columns: they trade halves over DPP, the even lane stores the hi dword and the odd lane the lo
+    // O -> [hi | lo] planes in the A-operand image of O's 32-column chunk oc: row = rt 32 + (r & 3) + 8 (r >> 2) + 4 fh, column fr.  Lane
+    // pairs (fr, fr ^ 1) hold neighbouring columns: they trade halves over DPP, the even lane stores the hi dword and the odd lane the lo
     // dword of the pair (one 32-bit LDS store per lane instead of two 16-bit ones)
+    const int oc = ch * C::NJ + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float ov = o[r] * __builtin_amdgcn_rcpf(l[r]);
       const float hv = (float)(f16_t)ov, lv = ov - hv;
       const float hn = dpp_mov<0xB1>(hv), ln = dpp_mov<0xB1>(lv);          // the neighbour's values
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      const int off = j * TW_APLANE + tw_off(row, fr >> 3) + (fr & 6) * 2;
+      const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      const int off = oc * TW_APL + tw_off(row, fr >> 3) + (fr & 6) * 2;
       const bool odd = fr & 1;
       const uint32_t w = odd ? pack2<f16_t>(ln, lv) : pack2<f16_t>(hv, hn);
-      *reinterpret_cast<uint32_t*>(pa + (odd ? 4 * TW_APLANE : 0) + off) = w;
+      *reinterpret_cast<uint32_t*>(pa + (odd ? C::NCO * TW_APL : 0) + off) = w;
     }
   }
-  // ---- phase 3: Y = O Wo^T, weight chunks double buffered ---------------------------------------------------------------------------------
-  f32x16 yacc[8];
+  TW_STAMP(3);                                       // phase 2 done
+  // ---- phase 3: Y = O Wo^T, k16 slabs of Wo in the ring ------------------------------------------------------------------------------
+  f32x16 yacc[C::NY];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
+  for (int j = 0; j < C::NY; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) yacc[j][r] = 0.f;
-  for (int kc = 0; kc < TW_DI / TW_BK; ++kc) {
-    if (kc >= 1 && kc + 1 < TW_DI / TW_BK) dma_wo(kc + 1);            // chunks 0 and 1 left during the attention phase
-    if (kc + 1 < TW_DI / TW_BK) dma_wait<8>();
+  for (int kk = 0; kk < NKK3; ++kk) {
+    if (kk + 1 < NKK3) dma_wait<PW3>();
     else dma_wait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                    // (kk == 0: also orders the O planes of every wave before the first read)
     asm volatile("" ::: "memory");
-    const char* pw = smem + 65536 + (kc & 1) * 32768;
+    if (kk + 2 < NKK3) dma_slab<2, D>(wo, DI, kk + 2, lds_w + ((kk + 2) % 3) * SLAB3, wave, lane);
+    const char* pw = smem + RING0 + (kk % 3) * SLAB3;
+    const char* pah = pa + (kk >> 1) * TW_APL;
+    const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
+    const uint4 al = *reinterpret_cast<const uint4*>(pah + C::NCO * TW_APL + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint4 ah = *reinterpret_cast<const uint4*>(pa + kc * TW_APLANE + tw_off(wave * 32 + fr, ks * 2 + fh));
-      const uint4 al = *reinterpret_cast<const uint4*>(pa + 4 * TW_APLANE + kc * TW_APLANE + tw_off(wave * 32 + fr, ks * 2 + fh));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint4 wh = *reinterpret_cast<const uint4*>(pw + tw_off(j * 32 + fr, ks * 2 + fh));
-        const uint4 wl = *reinterpret_cast<const uint4*>(pw + 256 * 64 + tw_off(j * 32 + fr, ks * 2 + fh));
-        yacc[j] = Half16<f16_t>::mfma32(ah, wh, yacc[j]);
-        yacc[j] = Half16<f16_t>::mfma32(al, wh, yacc[j]);
-        yacc[j] = Half16<f16_t>::mfma32(ah, wl, yacc[j]);
-      }
+    for (int j = 0; j < C::NY; ++j) {
+      const int wr = ch * (D / 2) + j * 32 + fr;
+      const uint4 wh = *reinterpret_cast<const uint4*>(pw + tw_woff(wr, fh));
+      const uint4 wl = *reinterpret_cast<const uint4*>(pw + D * 32 + tw_woff(wr, fh));
+      yacc[j] = Half16<f16_t>::mfma32(ah, wh, yacc[j]);
+      yacc[j] = Half16<f16_t>::mfma32(al, wh, yacc[j]);
+      yacc[j] = Half16<f16_t>::mfma32(ah, wl, yacc[j]);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
   }
-  // ---- phase 4: + bias -> LDS row-major, then a wave per row: residual (registers), LayerNorm, store -----------------------------------------
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float bov = a.bo[j * 32 + fr];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) yt[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * TW_YLD + j * 32 + fr] = yacc[j][r] + bov;
-  }
-  // (each wave wrote and now reads only its own 32 rows; the barrier above already retired every other use of this LDS)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const float4 gm = reinterpret_cast<const float4*>(a.gamma)[lane], bt = reinterpret_cast<const float4*>(a.beta)[lane];
-  // four passes over the wave's 32 rows, each with 32 independent chains (LDS reads, DPP reductions, stores all pipeline)
+  __builtin_amdgcn_s_barrier();                      // every wave is done with the O planes and the ring: the Y tile may overwrite them
+  asm volatile("" ::: "memory");
+  TW_STAMP(4);                                       // phase 3 done
+  // ---- phase 4: + bias -> LDS row-major, then a wave per row: residual (registers), LayerNorm, store -----------------------------------
 #pragma unroll
-  for (int rr = 0; rr < 32; ++rr) {
-    const float4 y = *reinterpret_cast<const float4*>(&yt[(wave * 32 + rr) * TW_YLD + lane * 4]);
-    xs[rr].x += y.x; xs[rr].y += y.y; xs[rr].z += y.z; xs[rr].w += y.w;
+  for (int j = 0; j < C::NY; ++j) {
+    const int col = ch * (D / 2) + j * 32 + fr;
+    const float bov = a.bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yt[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * C::YLD + col] = yacc[j][r] + bov;
   }
-  float mu[32], rs[32];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                      // a row's columns come from two waves (ch 0 / 1); its reader is a third
+  asm volatile("" ::: "memory");
+  float4 gm[C::NV], bt[C::NV];
 #pragma unroll
-  for (int rr = 0; rr < 32; ++rr) mu[rr] = wave_sum_dpp((xs[rr].x + xs[rr].y) + (xs[rr].z + xs[rr].w)) * (1.0f / 256.0f);
-#pragma unroll
-  for (int rr = 0; rr < 32; ++rr) {
-    xs[rr].x -= mu[rr]; xs[rr].y -= mu[rr]; xs[rr].z -= mu[rr]; xs[rr].w -= mu[rr];
-    rs[rr] = wave_sum_dpp((xs[rr].x * xs[rr].x + xs[rr].y * xs[rr].y) + (xs[rr].z * xs[rr].z + xs[rr].w * xs[rr].w));
+  for (int v = 0; v < C::NV; ++v) {
+    gm[v] = reinterpret_cast<const float4*>(a.gamma)[v * 64 + lane];
+    bt[v] = reinterpret_cast<const float4*>(a.beta)[v * 64 + lane];
   }
 #pragma unroll
-  for (int rr = 0; rr < 32; ++rr) {
-    const int row = row0 + wave * 32 + rr;
-    const float rstd = 1.0f / sqrtf(rs[rr] * (1.0f / 256.0f) + a.eps);
-    if (row < a.hw)
-      *reinterpret_cast<float4*>(xg + (size_t)row * a.D + lane * 4) =
-          make_float4(xs[rr].x * rstd * gm.x + bt.x, xs[rr].y * rstd * gm.y + bt.y, xs[rr].z * rstd * gm.z + bt.z, xs[rr].w * rstd * gm.w + bt.w);
+  for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+    for (int v = 0; v < C::NV; ++v) {
+      const float4 y = *reinterpret_cast<const float4*>(&yt[(wave * 16 + rr) * C::YLD + v * 256 + lane * 4]);
+      xs[rr][v].x += y.x; xs[rr][v].y += y.y; xs[rr][v].z += y.z; xs[rr][v].w += y.w;
+    }
+  float mu[16], rs[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < C::NV; ++v) sum += (xs[rr][v].x + xs[rr][v].y) + (xs[rr][v].z + xs[rr][v].w);
+    mu[rr] = wave_sum_dpp(sum) * (1.0f / D);
   }
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < C::NV; ++v) {
+      xs[rr][v].x -= mu[rr]; xs[rr][v].y -= mu[rr]; xs[rr][v].z -= mu[rr]; xs[rr][v].w -= mu[rr];
+      sq += (xs[rr][v].x * xs[rr][v].x + xs[rr][v].y * xs[rr][v].y) + (xs[rr][v].z * xs[rr][v].z + xs[rr][v].w * xs[rr][v].w);
+    }
+    rs[rr] = wave_sum_dpp(sq);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = row0 + wave * 16 + rr;
+    const float rstd = 1.0f / sqrtf(rs[rr] * (1.0f / D) + a.eps);
+    if (row < a.hw) {
+#pragma unroll
+      for (int v = 0; v < C::NV; ++v)
+        *reinterpret_cast<float4*>(xg + (size_t)row * D + v * 256 + lane * 4) =
+            make_float4(xs[rr][v].x * rstd * gm[v].x + bt[v].x, xs[rr][v].y * rstd * gm[v].y + bt[v].y, xs[rr][v].z * rstd * gm[v].z + bt[v].z,
+                        xs[rr][v].w * rstd * gm[v].w + bt[v].w);
+    }
+  }
+  TW_STAMP(5);                                       // stores issued
+}
+
+template <int DI> static void launch_t2i(const TwT2iArgs& a, float* out, hipStream_t st) {
+  constexpr int LDS = TW_XPL + 3 * 4 * DI * 32;
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(twoway_t2i_kernel<DI>), LDS, attr_mask);
+  hipLaunchKernelGGL(twoway_t2i_kernel<DI>, dim3(a.S, a.G), dim3(256), LDS, st, a);
+  hipLaunchKernelGGL(twoway_merge_kernel<DI / 8>, dim3(a.nt, a.G), dim3(DI), 0, st, a.part, a.S * 2, a.nt, out);
+}
+
+template <int DI> static void launch_i2t(const TwI2tArgs& a, hipStream_t st) {
+  using C = TwCfg<DI>;
+  constexpr int OPL = 2 * C::NCO * TW_APL, RING0 = OPL > TW_XPL ? OPL : TW_XPL;
+  constexpr int RING = 3 * 2 * C::D * 32, YT = TW_ROWS * C::YLD * 4;
+  constexpr int LDS = (RING0 + RING) > YT ? (RING0 + RING) : YT;
+  static_assert(LDS <= 160 * 1024, "two-way tile does not fit the LDS");
+  static unsigned long long attr_mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(twoway_i2t_kernel<DI>), LDS, attr_mask);
+  hipLaunchKernelGGL(twoway_i2t_kernel<DI>, dim3((a.hw + TW_ROWS - 1) / TW_ROWS, a.G), dim3(256), LDS, st, a);
 }
 
 }  // namespace la
 
+#ifdef LA_DEBUG
+extern "C" int la_dbg_twoway_stamps(unsigned long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(la::g_tw_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
 extern "C" int la_twoway_t2i(const float* img, const void* wk_hi, const void* wk_lo, const void* wv_hi, const void* wv_lo, const float* pek,
                              const float* bv, const float* q, int G, int hw, int nt, int D, int heads, float* part, float* out, void* stream) {
   LA_CHECK_ARG(img && wk_hi && wk_lo && wv_hi && wv_lo && pek && bv && q && part && out, "la_twoway_t2i: null pointer");
-  LA_CHECK_ARG(D == 2 * la::TW_DI && heads == 8, "la_twoway_t2i: built for D = 256 with 8 heads (got D=%d heads=%d)", D, heads);
+  LA_CHECK_ARG((D == 256 || D == 512) && heads == 8, "la_twoway_t2i: built for D = 256 / 512 with 8 heads (got D=%d heads=%d)", D, heads);
   LA_CHECK_ARG(G > 0 && hw > 0 && nt > 0, "la_twoway_t2i: bad shape");
   const int S = (hw + la::TW_ROWS - 1) / la::TW_ROWS;
   la::TwT2iArgs a{img, (const la::f16_t*)wk_hi, (const la::f16_t*)wk_lo, (const la::f16_t*)wv_hi, (const la::f16_t*)wv_lo, pek, bv, q,
-                  part, G, hw, nt, D, S, 1.0f / sqrtf((float)la::TW_HD)};
+                  part, G, hw, nt, S, 1.0f / sqrtf((float)(D / 16))};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  constexpr int LDS = 160 * 1024;
-  static unsigned long long attr_mask = 0;
-  la::ensure_dyn_lds(reinterpret_cast<const void*>(la::twoway_t2i_kernel), LDS, attr_mask);
-  hipLaunchKernelGGL(la::twoway_t2i_kernel, dim3(S, G), dim3(256), LDS, st, a);
-  hipLaunchKernelGGL(la::twoway_merge_kernel, dim3(nt, G), dim3(128), 0, st, part, S * 4, nt, out);
+  if (D == 256) la::launch_t2i<128>(a, out, st);
+  else la::launch_t2i<256>(a, out, st);
   LA_CHECK_LAUNCH("la_twoway_t2i");
   return 0;
 }
@@ -474,14 +551,13 @@ extern "C" int la_twoway_i2t(float* img, const void* wq_hi, const void* wq_lo, c
                              const void* wo_hi, const void* wo_lo, const float* bo, const float* gamma, const float* beta, float eps, int G,
                              int hw, int nt, int D, int heads, void* stream) {
   LA_CHECK_ARG(img && wq_hi && wq_lo && peq && k && v && wo_hi && wo_lo && bo && gamma && beta, "la_twoway_i2t: null pointer");
-  LA_CHECK_ARG(D == 2 * la::TW_DI && heads == 8, "la_twoway_i2t: built for D = 256 with 8 heads (got D=%d heads=%d)", D, heads);
+  LA_CHECK_ARG((D == 256 || D == 512) && heads == 8, "la_twoway_i2t: built for D = 256 / 512 with 8 heads (got D=%d heads=%d)", D, heads);
   LA_CHECK_ARG(G > 0 && hw > 0 && nt > 0 && nt <= la::TW_MAXT, "la_twoway_i2t: nt=%d out of range (1..%d)", nt, la::TW_MAXT);
   la::TwI2tArgs a{img, (const la::f16_t*)wq_hi, (const la::f16_t*)wq_lo, peq, k, v, (const la::f16_t*)wo_hi, (const la::f16_t*)wo_lo, bo, gamma,
-                  beta, eps, 1.0f / sqrtf((float)la::TW_HD), G, hw, nt, D};
-  constexpr int LDS = 160 * 1024;
-  static unsigned long long attr_mask = 0;
-  la::ensure_dyn_lds(reinterpret_cast<const void*>(la::twoway_i2t_kernel), LDS, attr_mask);
-  hipLaunchKernelGGL(la::twoway_i2t_kernel, dim3((hw + la::TW_ROWS - 1) / la::TW_ROWS, G), dim3(256), LDS, reinterpret_cast<hipStream_t>(stream), a);
+                  beta, eps, 1.0f / sqrtf((float)(D / 16)), G, hw, nt};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (D == 256) la::launch_i2t<128>(a, st);
+  else la::launch_i2t<256>(a, st);
   LA_CHECK_LAUNCH("la_twoway_i2t");
   return 0;
 }

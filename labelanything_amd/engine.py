@@ -153,7 +153,7 @@ class LamEngine:
         self.mean_kx: Dict[str, int] = {}   # block prefix -> columns of its '.mean.w32' that multiply mean(x) (the rest multiply mean(o))
         # the image side of the two-way transformers runs in the fused kernels (one read / one read + write of the stream per
         # attention, csrc/twoway.hip) for the published decoder geometry; fuse_twoway=False keeps the GEMM + attention + norm chain
-        self.fuse_twoway = bool(fuse_twoway) and cfg.embed_dim == 256 and cfg.dec_heads == 8 and decoder_dtype == torch.float32
+        self.fuse_twoway = bool(fuse_twoway) and cfg.embed_dim in (256, 512) and cfg.dec_heads == 8 and decoder_dtype == torch.float32
         self.window_scatter = bool(window_scatter)
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
@@ -837,7 +837,7 @@ class LamEngine:
         di = self.cfg.embed_dim // 2
         if self.fused_ok(nt):
             o = self.f32(tag + ".t2i.o", (groups * nt, di))
-            part = self.f32(tag + ".t2i.part", (groups * ((hw + 127) // 128) * 4 * nt * 8 * 18,))
+            part = self.f32(tag + ".t2i.part", (L.twoway_part_size(groups, hw, nt, self.cfg.embed_dim),))
             L.twoway_t2i(img32, p[ca + ".k_proj.planes"], p[ca + ".v_proj.planes"], self.pe_table(ca + ".k_proj", pe32), w[ca + ".v_proj.bias"], q,
                          groups, hw, nt, self.cfg.dec_heads, part, o)
             return o

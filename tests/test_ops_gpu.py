@@ -651,11 +651,13 @@ def _planes(w):
     return hi.contiguous(), (w - hi.float()).to(torch.float16).contiguous()
 
 
-@pytest.mark.parametrize("g,hw,nt", [(3, 900, 5), (2, 4096, 1), (1, 128, 11), (5, 200, 32)])
-def test_fused_twoway_image_side_kernels(L, g, hw, nt):
-    """la_twoway_t2i / la_twoway_i2t (D = 256, 8 heads) against the same mathematics in torch fp32: k / v / q projections from the
-    (groups, hw, D) stream, softmax attention against / over a handful of tokens, out_proj + residual + LayerNorm."""
-    d, di, heads, hd = 256, 128, 8, 16
+@pytest.mark.parametrize("d", [256, 512])
+@pytest.mark.parametrize("g,hw,nt", [(3, 900, 5), (2, 4096, 1), (1, 128, 11), (5, 200, 32), (2, 50, 3)])
+def test_fused_twoway_image_side_kernels(L, g, hw, nt, d):
+    """la_twoway_t2i / la_twoway_i2t (D = 256: 8 heads of 16, two 64-row tiles in flight per CU; D = 512: 8 heads of 32, the published
+    SAM-1024 decoder geometry) against the same mathematics in torch fp32: k / v / q projections from the (groups, hw, D) stream, softmax
+    attention against / over a handful of tokens, out_proj + residual + LayerNorm."""
+    di, heads, hd = d // 2, 8, d // 16
     x = rnd(g * hw, d, seed=31)
     pe = rnd(hw, d, seed=32)
     wk, wv, wq = (rnd(di, d, seed=33 + i) / 16 for i in range(3))
@@ -669,14 +671,14 @@ def test_fused_twoway_image_side_kernels(L, g, hw, nt):
         return t.view(g, n, heads, hd).transpose(1, 2)
     # tokens -> image
     kk, vv = xp @ wk.t() + bk, x @ wv.t() + bv
-    att = torch.softmax(heads_of(qt, nt) @ heads_of(kk, hw).transpose(-1, -2) / 4.0, dim=-1) @ heads_of(vv, hw)
+    att = torch.softmax(heads_of(qt, nt) @ heads_of(kk, hw).transpose(-1, -2) / math.sqrt(hd), dim=-1) @ heads_of(vv, hw)
     ref_t2i = att.transpose(1, 2).reshape(g * nt, di)
-    part = torch.empty(g * ((hw + 127) // 128) * 4 * nt * 8 * 18, device="cuda")
+    part = torch.full((L.twoway_part_size(g, hw, nt, d),), float("nan"), device="cuda")
     out = torch.empty(g * nt, di, device="cuda")
     L.twoway_t2i(x, _planes(wk), _planes(wv), (pe @ wk.t() + bk).contiguous(), bv, qt, g, hw, nt, heads, part, out)
     # image -> tokens, in place
     qq = xp @ wq.t() + bq
-    o = torch.softmax(heads_of(qq, hw) @ heads_of(kt, nt).transpose(-1, -2) / 4.0, dim=-1) @ heads_of(vt, nt)
+    o = torch.softmax(heads_of(qq, hw) @ heads_of(kt, nt).transpose(-1, -2) / math.sqrt(hd), dim=-1) @ heads_of(vt, nt)
     y = o.transpose(1, 2).reshape(g * hw, di) @ wo.t() + bo + x
     ref_i2t = F.layer_norm(y, (d,), gamma, beta, 1e-5)
     img = x.clone()
