@@ -104,7 +104,7 @@ def test_bench_workloads_describe_valid_models_and_episodes():
     import bench
     from labelanything_amd.config import LamConfig
     from labelanything_amd.episodes import make_episode
-    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg3_train"}
+    assert set(bench.WORKLOADS) == {"cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg3_train", "cfg2_train"}
     for name, w in bench.WORKLOADS.items():
         cfg = LamConfig(**w["model"])
         ep = dict(w["episode"])

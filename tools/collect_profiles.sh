@@ -1,9 +1,10 @@
 #!/bin/bash
 # Run on the MI355X box (via gpurun) from the repo root: refreshes everything the judge reads under profiles/ for round $1.
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04'
+# (the timeline tools need the measurement library: make -C labelanything_amd/csrc DEBUG=1 before the call - the .so travels with the snapshot)
 # Outputs land in gpurun_out/profiles_<round>/ (merged back by gpurun); copy them into profiles/ and commit.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -29,10 +30,20 @@ python tools/pmc_traffic.py $(find $OUT/pmc4 -name 'f_counter_collection.csv' | 
 #     numerics variants of the headline: plain 16-bit operands (round-1 numerics, misses 1e-3) and bf16
 for w in cfg1 cfg3 cfg4 cfg5 cfg3_train; do timeout 600 python bench.py --workload $w --no-cpu-baseline --no-eager-baseline > $OUT/${R}_bench_$w.json 2>> $OUT/bench.stderr; done
 timeout 600 python bench.py --workload cfg3_train --train-encoder --no-cpu-baseline > $OUT/${R}_bench_cfg3_train_encoder.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --workload cfg2_train --train-encoder --no-cpu-baseline > $OUT/${R}_bench_cfg2_train_encoder.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --workload cfg5 --attn-fp8 --no-cpu-baseline > $OUT/${R}_bench_cfg5_fp8.json 2>> $OUT/bench.stderr
+# On an 8-GPU node (the driver's SCALE run; nothing here can launch it): one rank per GPU over RCCL, bucketed gradient all-reduce
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --workload cfg3_train --train-encoder
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 8
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise patch,v,proj,neck > $OUT/${R}_bench_cfg2_weight_planes.json 2>> $OUT/bench.stderr
 timeout 600 python tools/attn_fp8_report.py > $OUT/${R}_attn_fp8.log 2>&1
 timeout 600 python tools/gemm_ab.py > $OUT/${R}_gemm_ab.log 2>&1
-timeout 900 python -m pytest tests/test_parity_seeds_gpu.py tests/test_encoder_train_gpu.py tests/test_train_gpu.py::test_cfg3_train_step_at_full_size -m gpu -q -s > $OUT/${R}_parity_seeds.log 2>&1
+if [ -f labelanything_amd/libla_hip_dbg.so ]; then
+  timeout 300 python tools/gemm_seam.py > $OUT/${R}_gemm_seam_timeline.log 2>&1
+  timeout 300 python tools/twoway_phases.py > $OUT/${R}_twoway_phases.log 2>&1
+fi
+timeout 300 python tools/twoway_d512_ab.py > $OUT/${R}_twoway_d512_ab.log 2>&1
+timeout 900 python -m pytest tests/test_parity_seeds_gpu.py tests/test_encoder_train_gpu.py tests/test_sam_train_gpu.py tests/test_train_gpu.py::test_cfg3_train_step_at_full_size -m gpu -q -s > $OUT/${R}_parity_seeds.log 2>&1
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise none > $OUT/${R}_bench_cfg2_plain16.json 2>> $OUT/bench.stderr
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --dtype bf16 > $OUT/${R}_bench_cfg2_bf16.json 2>> $OUT/bench.stderr
 timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>&1

@@ -19,9 +19,8 @@ from labelanything_amd import _lib as L  # noqa: E402
 NST = 64
 dt = torch.float16
 M = int(os.environ.get("M", 131072))
-SHAPES = [("qk (16-bit epilogue)", M, 1536, 768, "o16", 0), ("lin1 (GELU)", M, 3072, 768, "gelu", 0), ("proj (atomic residual)", M, 768, 768, "res", 0),
-          ("proj (slab read-modify-write)", M, 768, 768, "res", 0x200), ("lin2 (atomic residual)", M, 768, 3072, "res", 0),
-          ("lin2 (slab read-modify-write)", M, 768, 3072, "res", 0x200)]
+SHAPES = [("qk (16-bit epilogue)", M, 1536, 768, "o16", 0), ("lin1 (GELU)", M, 3072, 768, "gelu", 0),
+          ("proj (fp32 residual through the slab)", M, 768, 768, "res", 0), ("lin2 (fp32 residual through the slab)", M, 768, 3072, "res", 0)]
 lib = L.lib()
 lib.la_dbg_gemm_stamps.argtypes = [C.c_void_p]
 buf = (C.c_ulonglong * (8 * NST))()
