@@ -486,8 +486,8 @@ static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream
 // q . Rw[qx - kw + G - 1], q UNSCALED) given d rel_h / d rel_w from attn_bwd_dq_kernel.  One workgroup per (image-head, query row y):
 //   dq[x][d]     += sum_kh drelh[x][kh] Rh[y - kh + G - 1][d] + sum_kw drelw[x][kw] Rw[x - kw + G - 1][d]      (added to the 16-bit dq rows)
 //   dRh[y - kh + G - 1][d] += sum_x drelh[x][kh] q[x][d]        dRw[r][d] += sum_{x - kw + G - 1 = r} drelw[x][kw] q[x][d]   (fp32 atomics:
-//   the tables are shared by every image, head and row).  Vector ALU only, every operand staged in LDS once per workgroup (the table rows
-//   the query row uses included: read from global memory inside the loops they were 2 G global loads per output element).  Tables / table gradients are fp32 [(2 G - 1), hd_tab] with the first 64 columns used.
+//   the tables are shared by every image, head and row).  Vector ALU only: 2 G^2 64 MACs per workgroup, a rounding error next to the
+//   attention products.  Tables / table gradients are fp32 [(2 G - 1), hd_tab] with the first 64 columns used.
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                          const float* __restrict__ drelw, const float* __restrict__ tabh,
@@ -497,16 +497,10 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ q
   float* sq = reinterpret_cast<float*>(smem);          // [G][64] q of the row (fp32)
   float* sdh = sq + G * 64;                            // [G][G] drelh of the row's queries
   float* sdw = sdh + G * G;                            // [G][G] drelw
-  float* sth = sdw + G * G;                            // [G][64]: Rh[y - kh + G - 1], kh = 0 .. G - 1 (the rows this query row uses)
-  float* stw = sth + G * 64;                           // [2G - 1][64]: Rw
   const int y = blockIdx.x % G, bh = blockIdx.x / G, h = bh % heads, b = bh / heads;
   const int T_ = G * G, E3 = 3 * E, tid = threadIdx.x;
   const size_t row0 = (size_t)b * T_ + (size_t)y * G;
-  for (int i = tid; i < G * 64; i += 256) {
-    sq[i] = (float)qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
-    sth[i] = tabh[(size_t)(y - i / 64 + G - 1) * 64 + (i & 63)];
-  }
-  for (int i = tid; i < (2 * G - 1) * 64; i += 256) stw[i] = tabw[i];
+  for (int i = tid; i < G * 64; i += 256) sq[i] = (float)qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
   for (int i = tid; i < G * G; i += 256) {
     sdh[i] = drelh[((size_t)bh * T_ + (size_t)y * G) * G + i];
     sdw[i] = drelw[((size_t)bh * T_ + (size_t)y * G) * G + i];
@@ -516,7 +510,8 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ q
   for (int i = tid; i < G * 64; i += 256) {
     const int x = i / 64, d = i & 63;
     float acc = 0.f;
-    for (int k = 0; k < G; ++k) acc += sdh[x * G + k] * sth[k * 64 + d] + sdw[x * G + k] * stw[(x - k + G - 1) * 64 + d];
+    for (int k = 0; k < G; ++k)
+      acc += sdh[x * G + k] * tabh[(size_t)(y - k + G - 1) * 64 + d] + sdw[x * G + k] * tabw[(size_t)(x - k + G - 1) * 64 + d];
     T* p = dqkv + (row0 + x) * E3 + h * 64 + d;
     *p = (T)((float)*p + acc);
   }
@@ -587,11 +582,8 @@ extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, co
   LA_CHECK_ARG(qkv && dqkv && drelh && drelw && tabh && tabw && dtabh && dtabw, "la_relpos_bwd: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * 64, "la_relpos_bwd: needs head_dim 64, G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_bwd: bad dtype %d", dt);
-  const int lds = (G * 64 + 2 * G * G + G * 64 + (2 * G - 1) * 64) * (int)sizeof(float);      // <= 96 KiB at G = 64
+  const int lds = (G * 64 + 2 * G * G) * (int)sizeof(float);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static unsigned long long m1 = 0, m2 = 0;
-  if (dt == LA_F16) la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::f16_t>), 96 * 1024, m1);
-  else la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::bf16_t>), 96 * 1024, m2);
   if (dt == LA_F16)
     hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(B * heads * G), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
                        drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
