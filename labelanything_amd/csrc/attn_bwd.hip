@@ -486,51 +486,123 @@ static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream
 // q . Rw[qx - kw + G - 1], q UNSCALED) given d rel_h / d rel_w from attn_bwd_dq_kernel.  One workgroup per (image-head, query row y):
 //   dq[x][d]     += sum_kh drelh[x][kh] Rh[y - kh + G - 1][d] + sum_kw drelw[x][kw] Rw[x - kw + G - 1][d]      (added to the 16-bit dq rows)
 //   dRh[y - kh + G - 1][d] += sum_x drelh[x][kh] q[x][d]        dRw[r][d] += sum_{x - kw + G - 1 = r} drelw[x][kw] q[x][d]   (fp32 atomics:
-//   the tables are shared by every image, head and row).  Vector ALU only: 2 G^2 64 MACs per workgroup, a rounding error next to the
-//   attention products.  Tables / table gradients are fp32 [(2 G - 1), hd_tab] with the first 64 columns used.
+//   the tables are shared by every image, head and row).  Tables / table gradients are fp32 [(2 G - 1), 64].
+// k-loop of an exact-fp32 MFMA product whose operands are gathered element by element: the 8 + 8 gathers of a chunk are issued before its
+// 8 MFMAs, so one load latency is paid per chunk instead of per step (NS2 = number of k pairs, a multiple of 8)
+template <typename FA, typename FB>
+__device__ __forceinline__ void mfma32_gather(f32x16& acc, int ns2, FA&& fa, FB&& fb) {
+  for (int c = 0; c < ns2; c += 8) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[u] = fa(c + u);
+      bv[u] = fb(c + u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                          const float* __restrict__ drelw, const float* __restrict__ tabh,
                                                          const float* __restrict__ tabw, float* __restrict__ dtabh, float* __restrict__ dtabw,
-                                                         int B, int heads, int G, int E, float gscale) {
+                                                         int B, int heads, int G, int E, float gscale, int RY) {
+  // Four small products per query row on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A lane (fr, fh) = A[row fr][k fh], B lane = B[k fh][col fr],
+  // accumulator register r / lane = row (r & 3) + 8 (r >> 2) + 4 fh / column fr), operands gathered from LDS with the index arithmetic of
+  // the decomposition (the vector-ALU form of round 4's first version spent 7.8 ms per SAM-B training step in these loops):
+  //   dq [x][d]  = drelh[x][:] . RhSel[:][d]  +  U[x][:] . Rw[:][d]       RhSel[kh] = Rh[y - kh + G - 1],  U[x][r] = drelw[x][x + G - 1 - r]
+  //   dRhSel[kh][d] = drelh[:][kh]^T . q[:][d]                            -> dRh[y - kh + G - 1]
+  //   dRw [r][d] = U[:][r]^T . q[:][d]
+  // One workgroup walks RY consecutive rows of one image-head and folds their table gradients on chip - dRw stays in its MFMA accumulators
+  // (its row index does not depend on y), dRh goes through an LDS table - so the tables receive ONE pass of atomics per workgroup: device-scope
+  // atomics of every workgroup on the same 12 K addresses are what the one-row-per-workgroup form was waiting for.
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sq = reinterpret_cast<float*>(smem);          // [G][64] q of the row (fp32)
-  float* sdh = sq + G * 64;                            // [G][G] drelh of the row's queries
-  float* sdw = sdh + G * G;                            // [G][G] drelw
-  const int y = blockIdx.x % G, bh = blockIdx.x / G, h = bh % heads, b = bh / heads;
-  const int T_ = G * G, E3 = 3 * E, tid = threadIdx.x;
-  const size_t row0 = (size_t)b * T_ + (size_t)y * G;
-  for (int i = tid; i < G * 64; i += 256) sq[i] = (float)qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
-  for (int i = tid; i < G * G; i += 256) {
-    sdh[i] = drelh[((size_t)bh * T_ + (size_t)y * G) * G + i];
-    sdw[i] = drelw[((size_t)bh * T_ + (size_t)y * G) * G + i];
+  const int GS = G + 1;                                // row stride of the two G x G arrays (a lane walks a column of drelh)
+  const int GP = (G + 31) & ~31, NREL = 2 * G - 1, RP = (NREL + 31) & ~31;
+  float* sdh = reinterpret_cast<float*>(smem);         // [G][GS] drelh of the row's queries
+  float* sdw = sdh + G * GS;                           // [G][GS] drelw
+  float* sah = sdw + G * GS;                           // [NREL][64] dRh of this workgroup's rows
+  T* sq = reinterpret_cast<T*>(sah + NREL * 64);       // [G][64] q of the row (16 bit, as stored)
+  const int nchunk = (G + RY - 1) / RY;
+  const int yc = blockIdx.x % nchunk, bh = blockIdx.x / nchunk, h = bh % heads, b = bh / heads;
+  const int T_ = G * G, E3 = 3 * E, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int ta = wave >> 1, tb = wave & 1, dcol = tb * 32 + fr;
+  f32x16 accw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[i][r] = 0.f;
+  for (int i = tid; i < NREL * 64; i += 256) sah[i] = 0.f;
+  for (int y = yc * RY; y < min(G, yc * RY + RY); ++y) {
+    const size_t row0 = (size_t)b * T_ + (size_t)y * G;
+    __syncthreads();                                   // the previous row's readers are done (first row: the zero fill has landed)
+    for (int i = tid; i < G * 64; i += 256) sq[i] = qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
+    for (int i = tid; i < G * G; i += 256) {
+      sdh[(i / G) * GS + i % G] = drelh[((size_t)bh * T_ + (size_t)y * G) * G + i];
+      sdw[(i / G) * GS + i % G] = drelw[((size_t)bh * T_ + (size_t)y * G) * G + i];
+    }
+    __syncthreads();
+    // ---- dq rows: tile (x rows ta, d columns tb) ---------------------------------------------------------------------------------
+    if (ta * 32 < G) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int x = ta * 32 + fr;
+      mfma32_gather(acc, GP / 2,
+                    [&](int s2) { const int kh = 2 * s2 + fh; return (x < G && kh < G) ? sdh[x * GS + kh] : 0.f; },
+                    [&](int s2) { const int kh = 2 * s2 + fh; return kh < G ? tabh[(size_t)(y - kh + G - 1) * 64 + dcol] : 0.f; });
+      mfma32_gather(acc, RP / 2,
+                    [&](int s2) { const int r = 2 * s2 + fh, kw = x + G - 1 - r; return (x < G && r < NREL && kw >= 0 && kw < G) ? sdw[x * GS + kw] : 0.f; },
+                    [&](int s2) { const int r = 2 * s2 + fh; return r < NREL ? tabw[(size_t)r * 64 + dcol] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int xo = ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (xo < G) {
+          T* p = dqkv + (row0 + xo) * E3 + h * 64 + dcol;
+          *p = (T)((float)*p + acc[r]);
+        }
+      }
+      // ---- dRh[y - kh + G - 1][d]: tile (kh rows ta, d columns tb); for a fixed y every (kh, d) is its own table entry ------------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int kh = ta * 32 + fr;
+      mfma32_gather(acc, GP / 2,
+                    [&](int s2) { const int xx = 2 * s2 + fh; return (kh < G && xx < G) ? sdh[xx * GS + kh] : 0.f; },
+                    [&](int s2) { const int xx = 2 * s2 + fh; return xx < G ? (float)sq[xx * 64 + dcol] : 0.f; });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ko = ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (ko < G) sah[(y - ko + G - 1) * 64 + dcol] += acc[r];
+      }
+    }
+    // ---- dRw[r][d]: 2 RP / 32 tiles (r rows, d columns), wave w owns tiles w and w + 4; accumulated over the workgroup's rows --------------
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const int t = wave + 4 * ti;
+      if (t < 2 * (RP / 32)) {
+        const int tr = t >> 1, tc = (t & 1) * 32 + fr, rr = tr * 32 + fr;
+        mfma32_gather(accw[ti], GP / 2,
+                      [&](int s2) { const int xx = 2 * s2 + fh, kw = xx + G - 1 - rr; return (rr < NREL && xx < G && kw >= 0 && kw < G) ? sdw[xx * GS + kw] : 0.f; },
+                      [&](int s2) { const int xx = 2 * s2 + fh; return xx < G ? (float)sq[xx * 64 + tc] : 0.f; });
+      }
+    }
   }
   __syncthreads();
-  // dq rows
-  for (int i = tid; i < G * 64; i += 256) {
-    const int x = i / 64, d = i & 63;
-    float acc = 0.f;
-    for (int k = 0; k < G; ++k)
-      acc += sdh[x * G + k] * tabh[(size_t)(y - k + G - 1) * 64 + d] + sdw[x * G + k] * tabw[(size_t)(x - k + G - 1) * 64 + d];
-    T* p = dqkv + (row0 + x) * E3 + h * 64 + d;
-    *p = (T)((float)*p + acc);
-  }
-  // table gradients (un-scaled by gscale = 1 / loss scale is NOT applied here: the caller's buffers carry the loss scale like every
-  // other gradient of the backward pass; gscale is a plain multiplier for callers that want one)
-  for (int i = tid; i < G * 64; i += 256) {            // dRh[y - kh + G - 1][d]: kh = i / 64
-    const int kh = i / 64, d = i & 63;
-    float acc = 0.f;
-    for (int x = 0; x < G; ++x) acc += sdh[x * G + kh] * sq[x * 64 + d];
-    atomicAdd(&dtabh[(size_t)(y - kh + G - 1) * 64 + d], acc * gscale);
-  }
-  for (int i = tid; i < (2 * G - 1) * 64; i += 256) {  // dRw[r][d] = sum over (x, kw) with x - kw + G - 1 = r
-    const int r = i / 64, d = i & 63;
-    float acc = 0.f;
-    for (int x = 0; x < G; ++x) {
-      const int kw = x + G - 1 - r;
-      if (kw >= 0 && kw < G) acc += sdw[x * G + kw] * sq[x * 64 + d];
+  // (gscale is a plain multiplier: the caller's buffers carry the loss scale like every other gradient of the backward pass)
+  for (int i = tid; i < NREL * 64; i += 256) atomicAdd(&dtabh[i], sah[i] * gscale);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int t = wave + 4 * ti;
+    if (t < 2 * (RP / 32)) {
+      const int tr = t >> 1, tc = (t & 1) * 32 + fr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (ro < NREL) atomicAdd(&dtabw[(size_t)ro * 64 + tc], accw[ti][r] * gscale);
+      }
     }
-    atomicAdd(&dtabw[(size_t)r * 64 + d], acc * gscale);
   }
 }
 
@@ -582,14 +654,25 @@ extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, co
   LA_CHECK_ARG(qkv && dqkv && drelh && drelw && tabh && tabw && dtabh && dtabw, "la_relpos_bwd: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * 64, "la_relpos_bwd: needs head_dim 64, G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_bwd: bad dtype %d", dt);
-  const int lds = (G * 64 + 2 * G * G) * (int)sizeof(float);
+  const int lds = (2 * G * (G + 1) + (2 * G - 1) * 64) * (int)sizeof(float) + G * 64 * 2;        // 73 KiB at G = 64: two workgroups per CU
+  // rows per workgroup.  Large grids (G == 64: 4 image-heads x 64 rows per CU): as many as keep >= ~3 workgroups per CU in the launch - the
+  // table atomics shrink by that factor.  Windows (G <= 32, tables of a few KiB, workgroups of 10 KiB): one row each - a row's three
+  // dependent global round trips (operands in, dq read-modify-write) are what it waits for, and only more resident workgroups hide them
+  // (measured on 100 x 12 windows of 14 x 14: 471 us with 14 rows per workgroup)
+  int ry = 1;
+  while (G > 32 && ry < G && (long)B * heads * ((G + 2 * ry - 1) / (2 * ry)) >= 768) ry *= 2;
+  const int grid = B * heads * ((G + ry - 1) / ry);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dt == LA_F16)
-    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(B * heads * G), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
-                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
-  else
-    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::bf16_t>, dim3(B * heads * G), dim3(256), lds, st, (const la::bf16_t*)qkv, (la::bf16_t*)dqkv, drelh,
-                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+  static unsigned long long m1 = 0, m2 = 0;
+  if (dt == LA_F16) {
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::f16_t>), 80 * 1024, m1);
+    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(grid), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
+                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry);
+  } else {
+    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::bf16_t>), 80 * 1024, m2);
+    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::bf16_t>, dim3(grid), dim3(256), lds, st, (const la::bf16_t*)qkv, (la::bf16_t*)dqkv, drelh,
+                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry);
+  }
   LA_CHECK_LAUNCH("la_relpos_bwd");
   return 0;
 }
