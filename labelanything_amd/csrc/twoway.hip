@@ -75,16 +75,23 @@ __device__ __forceinline__ void load_rows(const float* xg, int D, int row0, int 
 
 // columns [128 sg, +128) of this wave's 16 rows -> A-operand plane chunks [4][64 rows x 64 B] (hi at pa, lo at pa + 4 chunks); the 32
 // lanes that hold those columns do the work
-template <int NV>
-__device__ __forceinline__ void stage_group(char* pa, int wave, int lane, int sg, const float4 (&xs)[16][NV]) {
-  if ((lane >> 5) == (sg & 1)) {
+template <int NV, int V>
+__device__ __forceinline__ void stage_block(char* pa, int wave, int lane, int half, const float4 (&xs)[16][NV]) {
+  if ((lane >> 5) == half) {
     const int li = lane & 31;
     char* hi = pa + (li >> 3) * TW_APL;
     char* lo = hi + 4 * TW_APL;
     const int sub = (li & 1) * 8, c16 = (li & 7) >> 1;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) split_store4(hi, lo, tw_off(wave * 16 + rr, c16) + sub, xs[rr][sg >> 1]);
+    for (int rr = 0; rr < 16; ++rr) split_store4(hi, lo, tw_off(wave * 16 + rr, c16) + sub, xs[rr][V]);
   }
+}
+// (the 256-column block is selected by a wave-uniform branch over compile-time indices: a run-time index into xs would move the whole
+// row set into scratch memory - which is what the first D = 512 build did, 528 bytes per lane)
+template <int NV>
+__device__ __forceinline__ void stage_group(char* pa, int wave, int lane, int sg, const float4 (&xs)[16][NV]) {
+  if (NV == 1 || (sg >> 1) == 0) stage_block<NV, 0>(pa, wave, lane, sg & 1, xs);
+  else stage_block<NV, (NV > 1 ? 1 : 0)>(pa, wave, lane, sg & 1, xs);
 }
 
 // One k16 slab of NP weight planes with NR rows each: K columns [16 kk, +16) of every row, [plane][row][32 B] (tw_woff) at LDS byte
@@ -119,26 +126,21 @@ struct TwT2iArgs {
   float scale;
 };
 
-// LDS: x planes [0, 32K) (128 columns of K at a time) | ring of three k16 slabs (wk_hi, wk_lo, wv_hi, wv_lo x DI rows x 32 B) behind them
+// K / V projections of a 64-row tile held in registers + the tile's softmax partials (the compute part of la_twoway_t2i; also the tail
+// of the fused i2t + t2i kernel, which enters with the freshly normalised rows).  The caller has issued slabs 0 and 1 of the weight ring
+// at smem + ring0; the x planes live at smem[0, 32K).  LDS: 32 KiB + ring of three k16 slabs (wk_hi, wk_lo, wv_hi, wv_lo x DI rows x 32 B).
 template <int DI>
-__global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_t2i_kernel(TwT2iArgs a) {
+__device__ __forceinline__ void t2i_compute(const TwT2iArgs& a, char* smem, int ring0, int g, int split, float4 (&xs)[16][TwCfg<DI>::NV],
+                                            int wave, int lane) {
   using C = TwCfg<DI>;
   constexpr int SLAB = 4 * DI * 32, NKK = C::D / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PW = 4 * DI / 32 / 4;               // DMA pieces per wave and slab
   char* pa = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 1, ch = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
-  const int g = blockIdx.y, split = blockIdx.x;
   const int row0 = split * TW_ROWS;
-  const float* xg = a.img + (size_t)g * a.hw * C::D;
   const f16_t* const planes[4] = {a.wk_hi, a.wk_lo, a.wv_hi, a.wv_lo};
-  const unsigned lds_w = lds_addr_of(smem + TW_XPL);
-  constexpr int PW = 4 * DI / 32 / 4;               // DMA pieces per wave and slab
-  dma_slab<4, DI>(planes, C::D, 0, lds_w, wave, lane);
-  dma_slab<4, DI>(planes, C::D, 1, lds_w + SLAB, wave, lane);
-  float4 xs[16][C::NV];
-  load_rows<C::NV>(xg, C::D, row0 + wave * 16, a.hw, lane, xs);
+  const unsigned lds_w = lds_addr_of(smem + ring0);
   float pk[C::NJ][16];               // this lane's entries of the PEK table (accumulator layout): requested BEHIND the row burst (below)
 
   f32x16 kacc[C::NJ], vacc[C::NJ];
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_t2i_kernel(Tw
             pk[j][r] = a.pek[(size_t)min(row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1) * DI + ch * (DI / 2) + j * 32 + fr];
       }
     }
-    const char* pw = smem + TW_XPL + (kk % 3) * SLAB;
+    const char* pw = smem + ring0 + (kk % 3) * SLAB;
     const char* pah = pa + ((kk >> 1) & 3) * TW_APL;
     const uint4 ah = *reinterpret_cast<const uint4*>(pah + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
     const uint4 al = *reinterpret_cast<const uint4*>(pah + 4 * TW_APL + tw_off(rt * 32 + fr, (kk & 1) * 2 + fh));
@@ -236,6 +238,24 @@ __global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_t2i_kernel(Tw
       }
     }
   }
+}
+
+// LDS: x planes [0, 32K) (128 columns of K at a time) | ring of three k16 slabs behind them
+template <int DI>
+__global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_t2i_kernel(TwT2iArgs a) {
+  using C = TwCfg<DI>;
+  constexpr int SLAB = 4 * DI * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y, split = blockIdx.x;
+  const float* xg = a.img + (size_t)g * a.hw * C::D;
+  const f16_t* const planes[4] = {a.wk_hi, a.wk_lo, a.wv_hi, a.wv_lo};
+  const unsigned lds_w = lds_addr_of(smem + TW_XPL);
+  dma_slab<4, DI>(planes, C::D, 0, lds_w, wave, lane);
+  dma_slab<4, DI>(planes, C::D, 1, lds_w + SLAB, wave, lane);
+  float4 xs[16][C::NV];
+  load_rows<C::NV>(xg, C::D, split * TW_ROWS + wave * 16, a.hw, lane, xs);
+  t2i_compute<DI>(a, smem, TW_XPL, g, split, xs, wave, lane);
 }
 
 // fold the partials of a group's tiles: out[g, t, head * HD + c] = sum_p e^{m_p - M} o_p / sum_p e^{m_p - M} l_p   (8 HD threads)
