@@ -43,7 +43,7 @@ WORKLOADS = {
                  model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                             example_class_attention=False, custom_preprocess=False),
                  episode=dict(n_ways=1, k_shots=1, image_size=480), default_episodes=32),
-    "cfg3": dict(desc="BASELINE cfg3 geometry, forward only: ViT-MAE-B 480px, 5-way 5-shot episodes (26 images, 150 prompt pairs each)",
+    "cfg3": dict(desc="BASELINE cfg3 geometry, the forward pass alone (its training step: cfg3_train): ViT-MAE-B 480px, 5-way 5-shot episodes (26 images, 150 prompt pairs each)",
                  model=dict(encoder="vit_b_mae", image_size=480, image_embed_dim=768, embed_dim=256, spatial_convs=3,
                             class_encoder={"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": 256}, custom_preprocess=False),
                  episode=dict(n_ways=5, k_shots=5, image_size=480), default_episodes=2),

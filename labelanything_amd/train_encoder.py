@@ -1,5 +1,6 @@
 """Training THROUGH the image encoder (SURVEY 8f row 1 as BASELINE cfg3 names it): forward with saved activations and a hand-written
-backward of the HF ViT stack (transformers ViTModel under models/build_encoder.py:83-100) on HIP kernels.
+backward on HIP kernels of the HF ViT stack (``HfEncoderGraph``: transformers ViTModel under models/build_encoder.py:83-100) and of the
+SAM ViTDet stack (``SamEncoderGraph``: models/image_encoder.py:110-376).
 
 Which configuration this is: ``parameters/trainval/coco20i/mae_noembs.yaml`` has no ``freeze_backbone``, so
 ``Lam.get_learnable_params`` (models/lam.py:321-347) returns ``self.parameters()`` - the ViT-B backbone (85.8 M parameters) trains
@@ -17,8 +18,10 @@ the flat gradient buffer (non-finite results: the step is repeated with a smalle
                                    that are not multiples of 256: the reduced test encoders) go to la_gemm_tn (exact-fp32 MFMA)
   attention        la_attn_fwd_lse / la_attn_bwd (flash form, recomputed probabilities, csrc/attn_bwd.hip)
   LayerNorm, GELU  la_layernorm_bwd, la_gelu_bwd16
-Scope: plain (HF) attention with 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5).  The SAM ViTDet stack (windows, decomposed
-relative positions) has no backward here; its trainings in the reference freeze it or use precomputed embeddings.
+  SAM stack         la_relpos_terms + la_attn_fwd_relpos_lse / la_attn_bwd_relpos + la_relpos_bwd (window and global attention with the
+                    decomposed rel-pos bias; gradients of rel_pos_h / rel_pos_w), windows as row gathers - see SamEncoderGraph
+Scope: 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5) and SAM ViT-B / -L; rel-pos tables of the block's own grid (training through
+get_rel_pos's resampling raises).
 """
 from __future__ import annotations
 
