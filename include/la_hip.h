@@ -297,7 +297,11 @@ int la_row_broadcast(const float* src, long groups, int rep, int D, float scale,
  * the activations are split the same way on the fly, so every projection carries ~21 mantissa bits through the fast MFMA. ---- */
 
 /* The positional encoding enters as a constant table per layer: (img + pe) W^T + b = img W^T + (pe W^T + b); pek / peq = pe W^T + b,
- * fp32 [hw, DI], computed once by the caller.
+ * fp32 [hw, DI], computed once by the caller and handed over in the kernels' own (accumulator) order: la_twoway_pe_layout(table [hw, DI],
+ * hw, DI, out [ceil(hw / 64) * 64 * DI]) rewrites a row-major table once per layer and grid. */
+int la_twoway_pe_layout(const float* table, int hw, int DI, float* out, void* stream);
+
+/*
  *
  * tokens -> image attention (cross_attn_token_to_image / final_attn_token_to_image without q_proj / out_proj, which act on the few tokens):
  * out[g, t, :] = softmax_hw(q[g, t] . K_g^T / sqrt(hd)) V_g per head, K = img Wk^T + pek, V = img Wv^T + bv computed tile by tile (64 rows)

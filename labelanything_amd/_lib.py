@@ -61,7 +61,7 @@ EXPORTS = [
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
-    "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd",
+    "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
 
 
@@ -409,8 +409,17 @@ def twoway_part_size(groups: int, hw: int, nt: int, d: int) -> int:
     return groups * ((hw + 63) // 64) * 2 * nt * 8 * (2 + d // 16)
 
 
+def twoway_pe_layout(table: torch.Tensor) -> torch.Tensor:
+    """pe @ W.T + b as fp32 [hw, D / 2] -> the same table in the order the fused two-way kernels read it (one pass, once per layer and grid)."""
+    _f32c(table)
+    hw, di = table.shape
+    out = torch.empty(((hw + 63) // 64) * 64 * di, device=table.device)
+    _check(lib().la_twoway_pe_layout(_ptr(table), C.c_int(hw), C.c_int(di), _ptr(out), _stream()), "la_twoway_pe_layout")
+    return out
+
+
 def twoway_t2i(img, wk, wv, pek, bv, q, groups: int, hw: int, nt: int, heads: int, part, out) -> None:
-    """wk / wv: (hi, lo) fp16 plane pairs [D / 2, D]; pek = pe @ Wk.T + bk [hw, D / 2].  D = 256 or 512, 8 heads."""
+    """wk / wv: (hi, lo) fp16 plane pairs [D / 2, D]; pek = twoway_pe_layout(pe @ Wk.T + bk).  D = 256 or 512, 8 heads."""
     _f32c(img, pek, bv, q, part, out)
     d = img.shape[1]
     need = twoway_part_size(groups, hw, nt, d)
@@ -422,7 +431,7 @@ def twoway_t2i(img, wk, wv, pek, bv, q, groups: int, hw: int, nt: int, heads: in
 
 
 def twoway_i2t(img, wq, peq, k, v, wo, bo, gamma, beta, eps: float, groups: int, hw: int, nt: int, heads: int) -> None:
-    """peq = pe @ Wq.T + bq [hw, D / 2]; img is updated in place."""
+    """peq = twoway_pe_layout(pe @ Wq.T + bq); img is updated in place."""
     _f32c(img, peq, k, v, bo, gamma, beta)
     _check(lib().la_twoway_i2t(_ptr(img), _ptr(wq[0]), _ptr(wq[1]), _ptr(peq), _ptr(k), _ptr(v), _ptr(wo[0]), _ptr(wo[1]), _ptr(bo),
                                _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(groups), C.c_int(hw), C.c_int(nt), C.c_int(img.shape[1]),

@@ -115,10 +115,46 @@ template <int HD> __device__ __forceinline__ float head_sum(float v) {
   return v;
 }
 
+// PE tables (pe Wk^T + bk, pe Wq^T + bq: fp32 [hw, DI], constant per layer and grid) are consumed in the ACCUMULATOR layout of the tile
+// kernels - lane (fr, fh) of wave (rt, ch), tile j, register r <-> row 64 s + 32 rt + (r & 3) + 8 (r >> 2) + 4 fh, column ch DI/2 + 32 j + fr.
+// Read row-major that is 16 NJ quarter-full requests per lane and tile (128 of the ~512 requests a 64-row tile issues); la_twoway_pe_layout
+// writes the table once in the order the kernels read it, [tile s][wave][j][k = r / 4][lane] float4: 4 NJ full requests per lane.
+template <int DI>
+__global__ __launch_bounds__(256) void twoway_pe_layout_kernel(const float* __restrict__ src, int hw, float* __restrict__ dst) {
+  constexpr int NJ = DI / 64;
+  const int s = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rt = wave >> 1, ch = wave & 1, fr = lane & 31, fh = lane >> 5;
+  for (int j = 0; j < NJ; ++j)
+    for (int k = 0; k < 4; ++k) {
+      float v[4];
+      for (int c = 0; c < 4; ++c) {
+        const int r = 4 * k + c;
+        const int row = min(s * TW_ROWS + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, hw - 1);
+        v[c] = src[(size_t)row * DI + ch * (DI / 2) + j * 32 + fr];
+      }
+      reinterpret_cast<float4*>(dst)[((((size_t)s * 4 + wave) * NJ + j) * 4 + k) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// this lane's 16 NJ entries of a laid-out PE table
+template <int NJ>
+__device__ __forceinline__ void load_pe(const float* tab, int split, int wave, int lane, float (&p)[NJ][16]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(tab)[((((size_t)split * 4 + wave) * NJ + j) * 4 + k) * 64 + lane];
+      p[j][4 * k + 0] = v.x;
+      p[j][4 * k + 1] = v.y;
+      p[j][4 * k + 2] = v.z;
+      p[j][4 * k + 3] = v.w;
+    }
+}
+
 struct TwT2iArgs {
   const float* img;      // [G * hw, D]
   const f16_t *wk_hi, *wk_lo, *wv_hi, *wv_lo;   // [DI, D] each
-  const float* pek;      // [hw, DI]  pe Wk^T + bk
+  const float* pek;      // pe Wk^T + bk in the layout of la_twoway_pe_layout
   const float* bv;       // [DI]
   const float* q;        // [G * nt, DI] projected queries (bias included)
   float* part;           // [G][S][2][nt][8][2 + HD]
@@ -161,13 +197,7 @@ __device__ __forceinline__ void t2i_compute(const TwT2iArgs& a, char* smem, int 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kk == 0) {                                 // only needed behind the loop: 16 NJ more requests per lane that would stretch the burst
-#pragma unroll
-        for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            pk[j][r] = a.pek[(size_t)min(row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1) * DI + ch * (DI / 2) + j * 32 + fr];
-      }
+      if (kk == 0) load_pe<C::NJ>(a.pek, split, wave, lane, pk);     // only needed behind the loop: requested behind the row burst
     }
     const char* pw = smem + ring0 + (kk % 3) * SLAB;
     const char* pah = pa + ((kk >> 1) & 3) * TW_APL;
@@ -289,7 +319,7 @@ __global__ __launch_bounds__(8 * HD) void twoway_merge_kernel(const float* __res
 struct TwI2tArgs {
   float* img;            // [G * hw, D] in / out
   const f16_t *wq_hi, *wq_lo;      // [DI, D]
-  const float* peq;      // [hw, DI]  pe Wq^T + bq
+  const float* peq;      // pe Wq^T + bq in the layout of la_twoway_pe_layout
   const float *k, *v;    // [G * nt, DI] projected token keys / values (bias included)
   const f16_t *wo_hi, *wo_lo;      // [D, DI]
   const float *bo, *gamma, *beta;  // [D]
@@ -360,14 +390,7 @@ __global__ __launch_bounds__(256, (DI == 128 ? 2 : 1)) void twoway_i2t_kernel(Tw
       asm volatile("" ::: "memory");
       if (kp == 0) {
         TW_STAMP(1);                                 // row burst landed, first 128 columns staged
-        // the PEQ entries are only needed in phase 2: 16 NJ more requests per lane that would otherwise stretch the row burst
-#pragma unroll
-        for (int j = 0; j < C::NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = min(row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, a.hw - 1);
-            pq[j][r] = a.peq[(size_t)row * DI + ch * (DI / 2) + j * 32 + fr];
-          }
+        load_pe<C::NJ>(a.peq, blockIdx.x, wave, lane, pq);     // only needed in phase 2: requested behind the row burst
       }
     }
 #pragma unroll
@@ -544,6 +567,16 @@ template <int DI> static void launch_i2t(const TwI2tArgs& a, hipStream_t st) {
 }
 
 }  // namespace la
+
+extern "C" int la_twoway_pe_layout(const float* table, int hw, int DI, float* out, void* stream) {
+  LA_CHECK_ARG(table && out && hw > 0 && (DI == 128 || DI == 256), "la_twoway_pe_layout: table [hw, DI] with DI = 128 / 256 (got hw=%d DI=%d)", hw, DI);
+  const int S = (hw + la::TW_ROWS - 1) / la::TW_ROWS;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (DI == 128) hipLaunchKernelGGL(la::twoway_pe_layout_kernel<128>, dim3(S), dim3(256), 0, st, table, hw, out);
+  else hipLaunchKernelGGL(la::twoway_pe_layout_kernel<256>, dim3(S), dim3(256), 0, st, table, hw, out);
+  LA_CHECK_LAUNCH("la_twoway_pe_layout");
+  return 0;
+}
 
 #ifdef LA_DEBUG
 extern "C" int la_dbg_twoway_stamps(unsigned long long* host_out) {

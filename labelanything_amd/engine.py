@@ -828,6 +828,7 @@ class LamEngine:
         if t is None:
             t = torch.empty(pe32.shape[0], self.w32[proj + ".weight"].shape[0], device=self.dev)
             L.gemm(pe32, self.w32[proj + ".weight"], bias=self.w32[proj + ".bias"], out32=t)
+            t = L.twoway_pe_layout(t)            # in the order the tile kernels read it (la_twoway_pe_layout)
             self._pe_tables[key] = t
         return t
 

@@ -675,14 +675,14 @@ def test_fused_twoway_image_side_kernels(L, g, hw, nt, d):
     ref_t2i = att.transpose(1, 2).reshape(g * nt, di)
     part = torch.full((L.twoway_part_size(g, hw, nt, d),), float("nan"), device="cuda")
     out = torch.empty(g * nt, di, device="cuda")
-    L.twoway_t2i(x, _planes(wk), _planes(wv), (pe @ wk.t() + bk).contiguous(), bv, qt, g, hw, nt, heads, part, out)
+    L.twoway_t2i(x, _planes(wk), _planes(wv), L.twoway_pe_layout((pe @ wk.t() + bk).contiguous()), bv, qt, g, hw, nt, heads, part, out)
     # image -> tokens, in place
     qq = xp @ wq.t() + bq
     o = torch.softmax(heads_of(qq, hw) @ heads_of(kt, nt).transpose(-1, -2) / math.sqrt(hd), dim=-1) @ heads_of(vt, nt)
     y = o.transpose(1, 2).reshape(g * hw, di) @ wo.t() + bo + x
     ref_i2t = F.layer_norm(y, (d,), gamma, beta, 1e-5)
     img = x.clone()
-    peq = (pe @ wq.t() + bq).contiguous()
+    peq = L.twoway_pe_layout((pe @ wq.t() + bq).contiguous())
     L.twoway_i2t(img, _planes(wq), peq, kt, vt, _planes(wo), bo, gamma, beta, 1e-5, g, hw, nt, heads)
     torch.cuda.synchronize()
     assert rel_err(out, ref_t2i) < 2e-5

@@ -21,7 +21,7 @@ for d, g, hw, nt in ((256, 120, 4096, 2), (256, 120, 4096, 8), (512, 60, 4096, 2
     planes = lambda w: (w.half().contiguous(), (w - w.half().float()).half().contiguous())
     x = rnd(g * hw, d)
     wq, wo = rnd(di, d) / 16, rnd(d, di) / 11
-    peq, kt, vt = rnd(hw, di), rnd(g * nt, di), rnd(g * nt, di)
+    peq, kt, vt = L.twoway_pe_layout(rnd(hw, di)), rnd(g * nt, di), rnd(g * nt, di)
     bo, gamma, beta = rnd(d), 1 + 0.1 * rnd(d), 0.1 * rnd(d)
     run = lambda: L.twoway_i2t(x, planes(wq), peq, kt, vt, planes(wo), bo, gamma, beta, 1e-5, g, hw, nt, 8)
     pq, po = planes(wq), planes(wo)
