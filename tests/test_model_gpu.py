@@ -386,6 +386,40 @@ def test_cfg3_decoder_at_full_size_matches_the_oracle_on_device_embeddings():
     assert rel_err(out["logits"], ref) <= 5e-5
 
 
+def test_cfg5_at_full_size_against_the_oracle_in_two_halves():
+    """BASELINE cfg5 at its own size (ViT-MAE-L 480, 10-way 5-shot: 51 images, 550 prompt pairs) against the CPU oracle without the
+    minutes a whole-episode oracle run would take: (a) the ViT-L encoder + LAM neck on THREE of the 51 images (the query and two
+    supports; 313 GMAC each) against the oracle's embeddings, <= 1e-3; (b) the whole decoder side (550 pairs x 900 positions, 11 classes)
+    by handing the HIP encoder's post-neck embeddings to the oracle's prompt encoder + mask decoder + post-processing, which must
+    reproduce the HIP logits to fp32 accumulation accuracy."""
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import geometry_for
+    lam, batch = _bench_model("cfg5")
+    rows = torch.arange(batch["flag_examples"].shape[2])
+    lam.selected_rows = rows
+    out = lam(batch)
+    e32, b, n, g = lam._embeddings_nhwc(batch, True)
+    d = lam.cfg.embed_dim
+    emb = e32.view(b, n, g * g, d).permute(0, 1, 3, 2).reshape(b, n, d, g, g).cpu()
+    w = init_state_dict(lam.cfg, 3)
+    geo = geometry_for(lam.cfg)
+    assert (b, n, g) == (1, 51, 30)
+    with torch.no_grad():
+        pick = [0, 1, 50]
+        sub = {"images": batch["images"][:, pick].float().cpu()}
+        ref_emb = O.episode_embeddings(w, geo, sub)[0]                                      # encoder + LAM neck: (3, D, g, g)
+        e_err = rel_err(emb[0, pick], ref_emb)
+        pts, bxs, msk = O.select_prompts(batch)
+        pe = O.prompt_encoder(w, geo, emb[:, 1:], pts, bxs, msk, batch["flag_examples"], rows)
+        low = O.mask_decoder(w, geo, emb[:, 0], pe["class_embeddings"])
+        ref = O.postprocess(geo, low, batch["dims"], batch.get("flag_gts"))
+    print(f"[cfg5 full size] embeddings of 3 images vs oracle {e_err:.3e}; decoder on device embeddings: logits {rel_err(out['logits'], ref):.3e}")
+    assert e_err <= 1e-3
+    assert rel_err(out["class_examples_embeddings"], pe["class_examples_embeddings"]) <= 2e-5
+    assert rel_err(out["logits"], ref) <= 5e-5
+
+
 # ---- BASELINE configs[4] as worded: "fp8 MFMA attention" ------------------------------------------------------------------------------
 FP8_BOUND = 3.5e-3      # stated bound of the opt-in switch (measured 3.1e-3 on the cfg1 fixture, 2.7e-3 on a cfg5 episode: profiles/r03_attn_fp8.log)
 
