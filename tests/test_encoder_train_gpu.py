@@ -296,3 +296,49 @@ def test_trainer_leaves_the_models_inference_numerics_alone():
     a = float(tr2.step(batch, gt)["loss"])
     b = float(tr2.step(batch, gt)["loss"])
     assert a != b                                                               # the second forward ran on re-packed (moved) weights
+
+
+def test_bf16_training_through_the_encoder_as_baseline_cfg3_words_it():
+    """BASELINE configs[2] says "bf16 training": the same graphs with bf16 MFMA operands (forward and backward; the loss scale stays a
+    power of two, bf16 would not need one).  8 mantissa bits instead of 11 cost what they cost in the forward (4e-3 class):
+    every encoder parameter's gradient of a linear functional against the oracle's autograd stays within 5e-2 of the tensor's largest
+    entry (fp16: 1e-2), and a full optimizer step runs finite and moves the encoder."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from labelanything_amd.train_encoder import HfEncoderGraph
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O
+    from tests.cases import CASES, geometry_for
+    from tests.test_train_gpu import make_gt
+    cfg = _hf_cfg(224)
+    g = torch.Generator().manual_seed(224)
+    images = torch.randn(3, 3, 224, 224, generator=g)
+    sd = init_state_dict(cfg, 31)
+    wref = {k: (v.clone().requires_grad_(True) if k.startswith("image_encoder.") and v.is_floating_point() else v) for k, v in sd.items()}
+    out_ref = O.hf_vit_encoder(wref, geometry_for(cfg), images)
+    r = torch.randn(out_ref.shape, generator=g)
+    (out_ref * r).sum().backward()
+    lam = Lam(cfg, seed=31, compute_dtype=torch.bfloat16).cuda()
+    names = [k for k, p in lam.named_parameters() if k.startswith("image_encoder.")]
+    grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}
+    graph = HfEncoderGraph(lam, grads)
+    out = graph.forward(images.cuda())
+    bn, c, gg, _ = out_ref.shape
+    ref_rows = out_ref.detach().permute(0, 2, 3, 1).reshape(bn * gg * gg, c)
+    f_err = float((out.cpu() - ref_rows).abs().max()) / float(ref_rows.abs().max())
+    graph.backward(r.permute(0, 2, 3, 1).reshape(bn * gg * gg, c).contiguous().cuda())
+    torch.cuda.synchronize()
+    gmax = max(float(wref[k].grad.abs().max()) for k in names)
+    worst = max(float((grads[k].cpu() - wref[k].grad).abs().max()) / max(float(wref[k].grad.abs().max()), 1e-2 * gmax) for k in names)
+    print(f"bf16 encoder graph: forward {f_err:.2e}, worst parameter gradient {worst:.2e}")
+    assert f_err <= 1e-2 and worst <= 5e-2, (f_err, worst)
+    case = CASES["hf_tiny_1w1s_masks"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    lam2 = Lam(case["cfg"], seed=3, compute_dtype=torch.bfloat16).cuda()
+    tr = LamTrainer(lam2, lr=1e-3, weight_decay=0.0, train_encoder=True)
+    qw = dict(lam2.named_parameters())["image_encoder.encoder.layer.0.attention.attention.query.weight"]
+    before = qw.detach().clone()
+    res = tr.step(batch, gt)
+    assert bool(torch.isfinite(res["loss"])) and bool(torch.isfinite(tr.opt.flat).all()) and not torch.equal(before, qw.detach())
