@@ -40,6 +40,21 @@ struct AttnBwdEncArgs {
   int G;
 };
 
+// Workgroup -> (image-head, 128-row block), as in the forward kernel (attn_enc.hip): workgroup b runs on XCD b % 8, so inside one XCD the
+// row block runs fastest and the workgroups an XCD has in flight share the tiles they loop over in its L2 (with the image-head fastest
+// every workgroup streams its own image-head's K / V or Q / dO from the fabric: 2.4 GB per launch at 52 x 12 x 901)
+__device__ __forceinline__ void bwd_block_map(const AttnBwdEncArgs& a, int& bh, int& blk) {
+  const int BH = a.B * a.heads, nb = (a.T + 127) / 128;
+  if ((BH & 7) == 0) {
+    const int idx = blockIdx.x >> 3;
+    blk = idx % nb;
+    bh = (idx / nb) * 8 + (blockIdx.x & 7);
+  } else {
+    bh = blockIdx.x % BH;
+    blk = blockIdx.x / BH;
+  }
+}
+
 // stage rows [row0, row0 + 64) (clamped to maxrow) x 64 columns of a row-major 16-bit matrix into one swizzled LDS tile
 template <typename T>
 __device__ __forceinline__ void stage_rows(const T* base, size_t ld, int row0, int maxrow, unsigned lds_tile, int wave, int lane) {
@@ -79,16 +94,19 @@ template <typename T> __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // BIAS 0: plain.  BIAS 1: rel-pos bias, any G <= 32 (per-wave LDS tables of the wave's 32 query rows, as the forward's MODE 1; the bias
 // gradients are scatter-added into a second pair of tables with ds_add_f32 - the two half-lanes of a query row hit the same entries).
+// BIAS 3: G <= 16 (the 14 x 14 windows) - no per-score work at all: the bias enters S^T as the product E R on the matrix pipe (R in hi + lo
+// 16-bit parts: exact to 2^-22), and d relh | d relw = E^T dS^T accumulates beside dQ^T from the same dS^T fragments.
 // BIAS 2: G == 64 - a 64-key tile is exactly one key row: relh[q][tile] is one scalar per tile, relw[q][0..63] lives in the 32 score
 // registers' positions for the whole kernel, d relw accumulates in 32 more registers and d relh[q][tile] is one store per tile.
 template <typename T, int BIAS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 3 * TILE_B;             // K rows | V rows | K^T
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int BH = a.B * a.heads;
-  const int bh = blockIdx.x % BH, qblk = blockIdx.x / BH;
+  int bh, qblk;
+  bwd_block_map(a, bh, qblk);
   const int h = bh % a.heads, b = bh / a.heads;
   const int T_ = a.T, E3 = 3 * a.E;
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -136,7 +154,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
   const int ntiles = (T_ + 63) >> 6;
-  dma(0, 0);
+  // the row blocks of an image-head run side by side on one XCD: each starts its loop at a different key tile so that they do not all
+  // ask the L2 for the same 24 KiB at the same moment (the sums are over all tiles either way; only the fp32 summation order moves)
+  const int rot = (int)((long)qblk * ntiles / ((T_ + 127) >> 7));
+  auto tile_of = [&](int it) { const int j = it + rot; return j >= ntiles ? j - ntiles : j; };
+  dma(tile_of(0), 0);
   // ---- bias tables -------------------------------------------------------------------------------------------------------------
   const int G = a.G, GS = G + 1;
   float* my_bh = nullptr;       // BIAS 1: [32][GS] relh rows of the wave's queries | [32][GS] relw | [32][GS] d relh | [32][GS] d relw
@@ -161,6 +183,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     }
     keyinfo = ki;
   }
+  // BIAS 3: the bias and its gradient as products with the 0 / 1 matrix E[key][c] (c < 16: key row == c; c >= 16: key column == c - 16)
+  uint4 rfh[2], rfl[2];         // R[c][q] = relh[q][c] | relw[q][c - 16], divided by the scale, hi + lo 16-bit parts: B operand of S^T += E R
+  f32x16 drel;                  // d R[c][q] = sum_key E^T[c][key] dS^T[key][q]
+  const char* et = nullptr;     // E^T [32][Tpad] 16-bit in LDS, rows padded by 16 bytes
+  int ETS = 0;
+  if (BIAS == 3) {
+    ETS = a.Tpad * 2 + 16;
+    char* etw = smem + 2 * STAGE;
+    int* ki = reinterpret_cast<int*>(etw + 32 * ETS);
+    for (int o = tid * 16; o < 32 * ETS; o += 256 * 16) *reinterpret_cast<uint4*>(etw + o) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const uint16_t one = (uint16_t)pack2<T>(1.0f, 0.0f);
+    for (int k = tid; k < a.Tpad; k += 256) {
+      const int kk = min(k, T_ - 1), kh = kk / G, kw = kk % G;
+      ki[k] = (kh << 16) | kw;
+      if (k < T_) {
+        *reinterpret_cast<uint16_t*>(etw + kh * ETS + k * 2) = one;
+        *reinterpret_cast<uint16_t*>(etw + (16 + kw) * ETS + k * 2) = one;
+      }
+    }
+    et = etw;
+    keyinfo = ki;
+    const float inv = 1.0f / a.scale;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* src = (ks == 0 ? a.relh : a.relw) + ((size_t)bh * T_ + qc) * G;
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = fh * 8 + 2 * i;
+        const float v0 = c < G ? src[c] * inv : 0.f, v1 = c + 1 < G ? src[c + 1] * inv : 0.f;
+        const T h0 = (T)v0, h1 = (T)v1;
+        hi[i] = pack2<T>((float)h0, (float)h1);
+        lo[i] = pack2<T>(v0 - (float)h0, v1 - (float)h1);
+      }
+      rfh[ks] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      rfl[ks] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) drel[r] = 0.f;
+  }
   if (BIAS == 2) {
     rhq = a.relh + ((size_t)bh * T_ + qc) * 64;
     const float* p = a.relw + ((size_t)bh * T_ + qc) * 64;
@@ -181,14 +244,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   __syncthreads();
   // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
   const bool idle_wave = qblk * 128 + wave * 32 >= T_;
-  for (int j = 0; j < ntiles; ++j) {
-    if (j + 1 < ntiles) dma(j + 1, (j + 1) & 1);
+  for (int it = 0; it < ntiles; ++it) {
+    const int j = tile_of(it);
+    if (it + 1 < ntiles) dma(tile_of(it + 1), (it + 1) & 1);
     if (idle_wave) {
       dma_wait<0>();
       __syncthreads();
       continue;
     }
-    const char* sk = smem + (j & 1) * STAGE;
+    const char* sk = smem + (it & 1) * STAGE;
     const char* sv = sk + TILE_B;
     const char* skt = sk + 2 * TILE_B;
     f32x16 s[2], dp[2];
@@ -196,6 +260,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = dp[t][r] = 0.f;
+      if (BIAS == 3) {
+        // the lane's key row of E: a one at c = key row (first k-step) and at c = 16 + key column (second); this lane holds c = fh*8 .. +8
+        const int info = keyinfo[j * 64 + t * 32 + fr];
+        const uint32_t one = pack2<T>(1.0f, 0.0f);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int pos = (ks == 0 ? (info >> 16) : (info & 0xffff)) - fh * 8;
+          const int d = pos >> 1;
+          const uint32_t val = one << ((pos & 1) * 16);
+          const uint4 ef = make_uint4(d == 0 ? val : 0u, d == 1 ? val : 0u, d == 2 ? val : 0u, d == 3 ? val : 0u);
+          s[t] = Half16<T>::mfma32(ef, rfh[ks], s[t]);
+          s[t] = Half16<T>::mfma32(ef, rfl[ks], s[t]);
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
@@ -245,6 +323,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
         const uint4 ktf = *reinterpret_cast<const uint4*>(skt + swz_off(d * 32 + fr, ks * 2 + fh));
         acc[d] = Half16<T>::mfma32(ktf, dsf[ks], acc[d]);
       }
+    if (BIAS == 3) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 etf = *reinterpret_cast<const uint4*>(et + fr * ETS + (j * 64 + ks * 16 + fh * 8) * 2);
+        drel = Half16<T>::mfma32(etf, dsf[ks], drel);
+      }
+    }
     dma_wait<0>();
     __syncthreads();
   }
@@ -269,6 +354,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
         *reinterpret_cast<float4*>(p + t * 32 + 8 * g4 + 4 * fh) =
             make_float4(drw[t][g4 * 4 + 0], drw[t][g4 * 4 + 1], drw[t][g4 * 4 + 2], drw[t][g4 * 4 + 3]);
   }
+  if (BIAS == 3 && q < T_) {
+    // register r of the accumulator is c = (r & 3) + 8 (r >> 2) + 4 fh: r < 8 the key rows, r >= 8 the key columns
+    float* ph = a.drelh + ((size_t)bh * T_ + q) * G;
+    float* pw = a.drelw + ((size_t)bh * T_ + q) * G;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int c = (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (c < G) {
+        ph[c] = drel[r];
+        pw[c] = drel[8 + r];
+      }
+    }
+  }
   if (BIAS == 1) {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -287,13 +385,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 // BIAS: the rel-pos terms of (query register, key lane) are read straight from the fp32 term arrays (a fixed register = one query row:
 // the 64 keys of the wave read inside one <= 256-byte row of relh / relw)
 template <typename T, bool BIAS>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 4 * TILE_B + 512;       // Q rows | dO rows | Q^T | dO^T | LSE (64 floats) | D (64 floats)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int BH = a.B * a.heads;
-  const int bh = blockIdx.x % BH, kblk = blockIdx.x / BH;
+  int bh, kblk;
+  bwd_block_map(a, bh, kblk);
   const int h = bh % a.heads, b = bh / a.heads;
   const int T_ = a.T, E3 = 3 * a.E;
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -337,18 +436,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
     for (int r = 0; r < 16; ++r) dv[d][r] = dk[d][r] = 0.f;
 
   const int ntiles = (T_ + 63) >> 6;
-  dma(0, 0);
+  const int rot = (int)((long)kblk * ntiles / ((T_ + 127) >> 7));      // (staggered start, as in the dQ kernel)
+  auto tile_of = [&](int it) { const int i = it + rot; return i >= ntiles ? i - ntiles : i; };
+  dma(tile_of(0), 0);
   dma_wait<0>();
   __syncthreads();
   const bool idle_wave = kblk * 128 + wave * 32 >= T_;       // (as in the dQ kernel: key rows beyond T)
-  for (int i = 0; i < ntiles; ++i) {
-    if (i + 1 < ntiles) dma(i + 1, (i + 1) & 1);
+  for (int it = 0; it < ntiles; ++it) {
+    const int i = tile_of(it);
+    if (it + 1 < ntiles) dma(tile_of(it + 1), (it + 1) & 1);
     if (idle_wave) {
       dma_wait<0>();
       __syncthreads();
       continue;
     }
-    const char* sq = smem + (i & 1) * STAGE;
+    const char* sq = smem + (it & 1) * STAGE;
     const char* sdo = sq + TILE_B;
     const char* sqt = sq + 2 * TILE_B;
     const char* sdot = sq + 3 * TILE_B;
@@ -461,7 +563,9 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
 template <typename T, int BIAS>
 static void launch_attn_bwd_t(const AttnBwdEncArgs& a, hipStream_t st) {
   const int nblk = (a.T + 127) / 128 * a.B * a.heads;
-  const int lds_dq = 2 * 3 * TILE_B + (BIAS == 1 ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int) : 0);
+  const int lds_dq = 2 * 3 * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
+                                      : BIAS == 3 ? 32 * (a.Tpad * 2 + 16) + a.Tpad * (int)sizeof(int)
+                                                  : 0);
   constexpr int LDS_DKV = 2 * (4 * TILE_B + 512);
   static unsigned long long m1 = 0, m2 = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS>), 160 * 1024, m1);
@@ -473,10 +577,12 @@ static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream
   if (dt == LA_F16) {
     if (bias == 0) launch_attn_bwd_t<f16_t, 0>(a, st);
     else if (bias == 1) launch_attn_bwd_t<f16_t, 1>(a, st);
+    else if (bias == 3) launch_attn_bwd_t<f16_t, 3>(a, st);
     else launch_attn_bwd_t<f16_t, 2>(a, st);
   } else {
     if (bias == 0) launch_attn_bwd_t<bf16_t, 0>(a, st);
     else if (bias == 1) launch_attn_bwd_t<bf16_t, 1>(a, st);
+    else if (bias == 3) launch_attn_bwd_t<bf16_t, 3>(a, st);
     else launch_attn_bwd_t<bf16_t, 2>(a, st);
   }
 }
@@ -644,7 +750,7 @@ extern "C" int la_attn_bwd_relpos(const void* qkv, const void* out16, const void
   LA_CHECK_ARG(G * G == T && (G <= 32 || G == 64), "la_attn_bwd_relpos: T == G*G with G <= 32 or G == 64 (T=%d G=%d)", T, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd_relpos: bad dtype %d", dt);
   la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale, relh, relw, drelh, drelw, G};
-  la::launch_attn_bwd(a, G == 64 ? 2 : 1, dt, reinterpret_cast<hipStream_t>(stream));
+  la::launch_attn_bwd(a, G == 64 ? 2 : G <= 16 ? 3 : 1, dt, reinterpret_cast<hipStream_t>(stream));
   LA_CHECK_LAUNCH("la_attn_bwd_relpos");
   return 0;
 }

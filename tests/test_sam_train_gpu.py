@@ -23,7 +23,7 @@ def _relpos_reference(q, k, v, rh, rw, g, scale):
     return torch.softmax(s, -1) @ v, rel_h.reshape(b * heads, t, g), rel_w.reshape(b * heads, t, g)
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 8), (1, 2, 14), (3, 1, 5), (1, 1, 64)])
+@pytest.mark.parametrize("shape", [(2, 2, 8), (1, 2, 14), (3, 1, 5), (1, 2, 16), (1, 1, 20), (1, 1, 64)])
 def test_relpos_attention_forward_lse_and_backward_match_torch(shape):
     b, heads, g = shape
     t, e = g * g, heads * 64
