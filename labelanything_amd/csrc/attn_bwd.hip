@@ -104,7 +104,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   constexpr int STAGE = 3 * TILE_B;             // K rows | V rows | K^T
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int BH = a.B * a.heads;
   int bh, qblk;
   bwd_block_map(a, bh, qblk);
   const int h = bh % a.heads, b = bh / a.heads;
@@ -390,7 +389,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   constexpr int STAGE = 4 * TILE_B + 512;       // Q rows | dO rows | Q^T | dO^T | LSE (64 floats) | D (64 floats)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int BH = a.B * a.heads;
   int bh, kblk;
   bwd_block_map(a, bh, kblk);
   const int h = bh % a.heads, b = bh / a.heads;
@@ -610,7 +608,7 @@ __device__ __forceinline__ void mfma32_gather(f32x16& acc, int ns2, FA&& fa, FB&
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
+__global__ __launch_bounds__(256, 5) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                          const float* __restrict__ drelw, const float* __restrict__ tabh,
                                                          const float* __restrict__ tabw, float* __restrict__ dtabh, float* __restrict__ dtabw,
                                                          int B, int heads, int G, int E, float gscale, int RY) {

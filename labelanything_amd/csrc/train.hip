@@ -107,6 +107,136 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The same product for long reductions (M >= 4096, 16-byte aligned operands), with the rows staged through LDS by LDS-DMA.  The
+// register-fed loop above keeps ONE 8-row fetch in flight beside 16 MFMAs (1024 cycles): every iteration waits out the rest of a
+// 2 - 4 k-cycle memory latency, and the matrix pipe is busy 30 % of the time (270000 x 128 x 256: 377 us against 113 us of fp32 MFMA
+// issue).  Here a ring of NS stages of R rows ([R][TN] of dY | [R][TK] of X, row-major fp32, filled by 1 KiB pieces of
+// global_load_lds_dwordx4: each wave stages R / 4 rows of both operands) runs NS - 1 stages ahead of the MFMAs without holding a
+// register; the fragments are 4-byte LDS reads (lane = column, half-wave = row parity).
+//   WN x WK waves over the (n, k) tile, SN x SK 32 x 32 sub-tiles per wave; the remaining 4 / (WN WK) waves split the rows of a stage
+//   (every wave adds its partial tile with atomics at the end, as the M-chunks do anyway).  Shapes: 128 x 128 (2 x 2 waves of 64 x 64),
+//   256 x 32 / 32 x 256 for one narrow side (mask_downscaling / output_upscaling: 16 channels against 256), 32 x 32 split four ways over
+//   the rows when both sides are narrow.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WN, int WK, int SN, int SK, int R, int NS>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                          float* __restrict__ dw, int ldw, int M, int N, int K, int mchunk, int tiles_k,
+                                                          float* __restrict__ db) {
+  constexpr int WM = 4 / (WN * WK), TN = WN * SN * 32, TK = WK * SK * 32, RW = R / 4;
+  constexpr int PN = RW * TN * 4 / 1024, PK = RW * TK * 4 / 1024;          // pieces per wave and stage
+  static_assert(WM * WN * WK == 4 && PN >= 1 && PK >= 1 && (RW * TN * 4) % 1024 == 0 && (RW * TK * 4) % 1024 == 0, "piece layout");
+  static_assert((R / 2) % WM == 0 && (NS - 2) * (PN + PK) < 64, "stage layout");
+  constexpr int STAGE = R * (TN + TK) * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+  const int n0 = tn * TN, k0 = tk * TK;
+  const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
+  const unsigned lds0 = lds_addr_of(smem);
+
+  f32x16 acc[SN][SK];
+#pragma unroll
+  for (int i = 0; i < SN; ++i)
+#pragma unroll
+    for (int j = 0; j < SK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float vn[SN], vk[SK];
+#pragma unroll
+  for (int i = 0; i < SN; ++i) vn[i] = n0 + (wn * SN + i) * 32 + fr < N ? 1.f : 0.f;
+#pragma unroll
+  for (int j = 0; j < SK; ++j) vk[j] = k0 + (wk * SK + j) * 32 + fr < K ? 1.f : 0.f;
+
+  // stage `st` of this workgroup's rows -> ring slot: rows clamped to M - 1, 4-column groups clamped to the last group of the matrix
+  // (N, K are multiples of 4: a group is valid or masked as a whole; masked columns / rows are multiplied by zero when they are read)
+  auto issue = [&](int st, int slot) {
+    const int m = mbeg + st * R + wave * RW;
+    const unsigned base = lds0 + slot * STAGE;
+#pragma unroll
+    for (int p = 0; p < PN; ++p) {
+      const int o = p * 1024 + lane * 16, row = o / (TN * 4), col = min(n0 + (o % (TN * 4)) / 4, N - 4);
+      dma16(dy + (size_t)min(m + row, M - 1) * ldy + col, base + wave * (RW * TN * 4) + p * 1024);
+    }
+#pragma unroll
+    for (int p = 0; p < PK; ++p) {
+      const int o = p * 1024 + lane * 16, row = o / (TK * 4), col = min(k0 + (o % (TK * 4)) / 4, K - 4);
+      dma16(x + (size_t)min(m + row, M - 1) * ldx + col, base + R * TN * 4 + wave * (RW * TK * 4) + p * 1024);
+    }
+  };
+  const bool do_db = db != nullptr && tk == 0 && wk == 0;
+  float bsum[SN];
+#pragma unroll
+  for (int i = 0; i < SN; ++i) bsum[i] = 0.f;
+
+  const int nstages = (mend - mbeg + R - 1) / R;
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st) issue(st, st);           // (stages beyond the chunk re-read clamped rows: every wave issues the same count)
+  for (int it = 0; it < nstages; ++it) {
+    dma_wait<(NS - 2) * (PN + PK)>();                          // this wave's pieces of stage `it` have landed ...
+    __syncthreads();                                           // ... so have everyone's, and everyone is done reading stage it - 1
+    issue(it + NS - 1, (it + NS - 1) % NS);
+    const float* sdy = reinterpret_cast<const float*>(smem + (it % NS) * STAGE);
+    const float* sx = sdy + R * TN;
+    const int mrow = mbeg + it * R;
+#pragma unroll
+    for (int kk = 0; kk < R / 2 / WM; ++kk) {
+      const int row = 2 * (kk * WM + wm) + fh;
+      const float vr = mrow + row < mend ? 1.f : 0.f;
+      float a[SN], b[SK];
+#pragma unroll
+      for (int i = 0; i < SN; ++i) a[i] = sdy[row * TN + (wn * SN + i) * 32 + fr] * (vr * vn[i]);
+#pragma unroll
+      for (int j = 0; j < SK; ++j) b[j] = sx[row * TK + (wk * SK + j) * 32 + fr] * vk[j];
+#pragma unroll
+      for (int i = 0; i < SN; ++i) {
+        if (do_db) bsum[i] += a[i];
+#pragma unroll
+        for (int j = 0; j < SK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  dma_wait<0>();                                               // (the look-ahead pieces of stages that do not exist)
+#pragma unroll
+  for (int i = 0; i < SN; ++i)
+#pragma unroll
+    for (int j = 0; j < SK; ++j) {
+      const int k = k0 + (wk * SK + j) * 32 + fr;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (wn * SN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (n < N) atomicAdd(&dw[(size_t)n * ldw + k], acc[i][j][r]);
+      }
+    }
+  if (do_db) {
+#pragma unroll
+    for (int i = 0; i < SN; ++i) {
+      const int n = n0 + (wn * SN + i) * 32 + fr;
+      if (n < N) atomicAdd(&db[n], bsum[i]);
+    }
+  }
+}
+
+template <int WN, int WK, int SN, int SK, int R, int NS>
+static void launch_gemm_tn_dma(const float* dy, int ldy, const float* x, int ldx, float* dw, int ldw, int M, int N, int K, float* db,
+                               int target_wgs, hipStream_t st) {
+  constexpr int TN = WN * SN * 32, TK = WK * SK * 32, LDS = NS * R * (TN + TK) * 4;
+  const int tiles_n = (N + TN - 1) / TN, tiles_k = (K + TK - 1) / TK;
+  int chunks = target_wgs / (tiles_n * tiles_k);
+  if (chunks < 1) chunks = 1;
+  int mchunk = (M + chunks - 1) / chunks;
+  if (mchunk < 8 * R) mchunk = 8 * R;                          // at least 8 stages behind every atomic epilogue
+  mchunk = (mchunk + R - 1) / R * R;
+  chunks = (M + mchunk - 1) / mchunk;
+  static unsigned long long mask = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_tn_dma_kernel<WN, WK, SN, SK, R, NS>), LDS, mask);
+  hipLaunchKernelGGL((gemm_tn_dma_kernel<WN, WK, SN, SK, R, NS>), dim3(tiles_n * tiles_k, chunks), dim3(256), LDS, st, dy, ldy, x, ldx, dw,
+                     ldw, M, N, K, mchunk, tiles_k, db);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // out[n] += sum_m dY[m][n]: the bias gradient of every linear / conv layer.  (As a product with a ones vector through the 128 x 128
 // MFMA tiles above it cost as much as the weight gradient itself: 5 ms of a 41 ms training step.)  Threads are laid out
 // (rows_par x NW) with NW = the column count rounded up to a power of two (<= 256): coalesced row reads, per-thread partial sums
@@ -754,6 +884,21 @@ extern "C" int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, 
     else hipLaunchKernelGGL((la::gemm_tn_tiny_kernel<8, 8>), dim3(blocks), dim3(256), 0, st0, dy, ldy, x, ldx, dw, ldw, (long)M, N, K);
     LA_CHECK_LAUNCH("la_gemm_tn");
     if (db) return la_colsum_acc(dy, ldy, (long)M, N, db, stream);      // (tiny outputs: the separate column-sum pass)
+    return 0;
+  }
+  const bool aligned = ((N | K | ldy | ldx) & 3) == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
+  static const char* dmaenv = la_dbg_env("LA_TN_NODMA");   // debugging: the register-fed kernel everywhere
+  if (aligned && M >= 4096 && !dmaenv) {
+    // workgroups: one resident set (2 per CU) - every workgroup ends in an atomic per output element, and with the rows prefetched
+    // through LDS a long chunk costs nothing (256 / 512 / 1024 / 2048 / 4096 workgroups on 270000 x 128 x 256: 234 / 211 / 207 / 235 /
+    // 271 us; the 32 x 32 shape on 1228800 rows: 76 / 81 / 119 / 208 / 377 us)
+    static const char* wgdma = la_dbg_env("LA_TN_DMA_WGS");
+    const int tw = wgdma ? atoi(wgdma) : 512;
+    if (N <= 32 && K <= 32) la::launch_gemm_tn_dma<1, 1, 1, 1, 32, 4>(dy, ldy, x, ldx, dw, ldw, M, N, K, db, wgdma ? tw : 256, st0);
+    else if (K <= 32) la::launch_gemm_tn_dma<4, 1, 2, 1, 32, 3>(dy, ldy, x, ldx, dw, ldw, M, N, K, db, tw, st0);
+    else if (N <= 32) la::launch_gemm_tn_dma<1, 4, 1, 2, 32, 3>(dy, ldy, x, ldx, dw, ldw, M, N, K, db, tw, st0);
+    else la::launch_gemm_tn_dma<2, 2, 2, 2, 16, 4>(dy, ldy, x, ldx, dw, ldw, M, N, K, db, tw, st0);
+    LA_CHECK_LAUNCH("la_gemm_tn");
     return 0;
   }
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;

@@ -246,10 +246,12 @@ def test_step_updates_weights_and_invalidates_the_engine():
     assert losses[-1] < losses[0]                                 # and the objective goes down on the batch it is trained on
 
 
-@pytest.mark.parametrize("mnk", [(135000, 128, 256), (900, 256, 128), (150, 256, 2048), (300000, 4, 4), (70000, 7, 3), (4099, 33, 65)])
+@pytest.mark.parametrize("mnk", [(135000, 128, 256), (900, 256, 128), (150, 256, 2048), (300000, 4, 4), (70000, 7, 3), (4099, 33, 65),
+                                 (300000, 256, 16), (300000, 16, 16), (100000, 16, 256), (50001, 132, 260), (4096, 256, 768)])
 def test_weight_gradient_gemm_tn_matches_torch(mnk):
-    """la_gemm_tn: dW += dY^T X on the 32x32x2 fp32 MFMA (row chunks folded with atomics) and, for tiny outputs over very long
-    reductions, on the VALU; accumulation into a pre-loaded dW."""
+    """la_gemm_tn: dW += dY^T X on the 32x32x2 fp32 MFMA (row chunks folded with atomics; rows staged through LDS for long aligned
+    reductions, in the 128 x 128 / 256 x 32 / 32 x 256 / 32 x 32 tile shapes) and, for tiny outputs over very long reductions, on the
+    VALU; accumulation into a pre-loaded dW, the bias gradient on the way, operands that are column slices of wider matrices."""
     from labelanything_amd import _lib as L
     m, n, k = mnk
     g = torch.Generator().manual_seed(m + n)
@@ -261,6 +263,17 @@ def test_weight_gradient_gemm_tn_matches_torch(mnk):
     torch.cuda.synchronize()
     ref = dw0.double() + dy.double().t() @ x.double()
     assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    # with the bias gradient, on column slices (row stride = the parent's width)
+    wide_dy = torch.randn(m, n + 8, generator=g).cuda()
+    wide_x = torch.randn(m, k + 4, generator=g).cuda()
+    dys, xs = wide_dy[:, 4:4 + n], wide_x[:, 4:4 + k]
+    dw, db = dw0.clone(), torch.ones(n, device="cuda")
+    L.gemm_tn(dys, xs, dw, db)
+    torch.cuda.synchronize()
+    ref = dw0.double() + dys.double().t() @ xs.double()
+    assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    refb = 1.0 + dys.double().sum(0)
+    assert float((db.double() - refb).abs().max() / refb.abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("mn", [(135000, 128), (2457600, 4), (614400, 256), (150, 2048), (6, 256), (1000, 300)])
