@@ -313,3 +313,30 @@ def test_layernorm_backward_matches_torch_autograd(rows_e, gelu):
     assert rel_err(y.detach(), yr.detach().float()) < 1e-5          # (4 channels at eps 1e-6: the fp32 variance itself is 4e-6 away from fp64)
     for mine, ref in ((x.grad, xr.grad), (gamma.grad, gr.grad), (beta.grad, br.grad)):
         assert float((mine.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 150, 150, 8, 16), (3, 1, 900, 8, 16), (3, 900, 1, 8, 16), (2, 6, 6, 8, 32), (5, 6, 6, 8, 32), (2, 6, 900, 8, 16),
+                                   (2, 900, 6, 8, 16), (2, 300, 40, 4, 64), (2, 7, 300, 2, 4), (1, 256, 256, 2, 8), (2, 520, 3, 8, 64)])
+def test_small_attention_backward_matches_torch_autograd(shape):
+    """autograd_ops.attention (la_attn_small + la_attn_small_lse + la_attn_small_bwd): both backward forms - the long side in threads, the
+    short side's gradients added up per workgroup through LDS - against torch autograd in fp64."""
+    from labelanything_amd import autograd_ops as A
+    b, nq, nk, heads, hd = shape
+    g = torch.Generator().manual_seed(nq * 7 + nk)
+    e = heads * hd
+    q = torch.randn(b * nq, e, generator=g).cuda().requires_grad_(True)
+    k = torch.randn(b * nk, e, generator=g).cuda().requires_grad_(True)
+    v = torch.randn(b * nk, e, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(b * nq, e, generator=g).cuda()
+    o = A.attention(q, k, v, b, nq, nk, heads)
+    (o * w).sum().backward()
+    qd, kd, vd = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, v))
+    q4 = qd.view(b, nq, heads, hd).transpose(1, 2)
+    k4 = kd.view(b, nk, heads, hd).transpose(1, 2)
+    v4 = vd.view(b, nk, heads, hd).transpose(1, 2)
+    ref = (torch.softmax(q4 @ k4.transpose(-1, -2) / hd ** 0.5, -1) @ v4).transpose(1, 2).reshape(b * nq, e)
+    (ref * w.double().cpu()).sum().backward()
+    assert float((o.detach().double().cpu() - ref.detach()).abs().max()) <= 2e-6 * float(ref.abs().max())
+    for name, mine, r in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        # (one key: softmax == 1, dq and dk are exactly zero in the reference - the bound is relative to the data scale then)
+        assert float((mine.double().cpu() - r).abs().max()) <= 5e-6 * max(1.0, float(r.abs().max())), name
