@@ -264,6 +264,11 @@ int la_colsum_acc(const float* dy, int ldy, long M, int N, float* out, void* str
  * dx (written), dgamma / dbeta fp32 [E] (ACCUMULATED). */
 int la_layernorm_bwd(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
                      float* dx, float* dgamma, float* dbeta, void* stream);
+/* The same with the block's skip connection folded in: dx = LayerNorm backward + add (add may be dx itself - the running fp32 gradient of
+ * the residual stream, image_encoder.py:178-197 / transformers ViTLayer: x + f(LN(x))), and an optional 16-bit copy of dx (out16, dt16 =
+ * LA_F16 / LA_BF16; NULL = none) for the next backward GEMM.  Wave-per-row form only (not the E <= 32, rows >= 65536 LayerNorm2d form). */
+int la_layernorm_bwd_res(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
+                         const float* add, float* dx, void* out16, int dt16, float* dgamma, float* dbeta, void* stream);
 
 /* y = act(x) and dx = dy * act'(x), act = LA_ACT_GELU (erf form) or LA_ACT_RELU, n contiguous fp32 elements. */
 int la_act_fwd(const float* x, float* y, long n, int kind, void* stream);

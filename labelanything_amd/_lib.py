@@ -59,7 +59,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
@@ -362,6 +362,17 @@ def layernorm_bwd(x, dy, gamma, beta, eps: float, gelu: bool, dx, dgamma, dbeta)
     rows, e = x.shape
     _check(lib().la_layernorm_bwd(_ptr(x), _ptr(dy), C.c_long(rows), C.c_int(e), _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(int(gelu)),
                                   _ptr(dx), _ptr(dgamma), _ptr(dbeta), _stream()), "la_layernorm_bwd")
+
+
+def layernorm_bwd_res(x, dy, gamma, beta, eps: float, add, dx, out16, dgamma, dbeta) -> None:
+    """dx = LayerNorm backward(x, dy) + add (add may be dx), optionally with a 16-bit copy of dx in out16."""
+    _f32c(x, dy, gamma, beta, dx, dgamma, dbeta)
+    if add is not None:
+        _f32c(add)
+    rows, e = x.shape
+    _check(lib().la_layernorm_bwd_res(_ptr(x), _ptr(dy), C.c_long(rows), C.c_int(e), _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(0),
+                                      _ptr(add), _ptr(dx), _ptr(out16), C.c_int(dt_of(out16) if out16 is not None else LA_F16), _ptr(dgamma),
+                                      _ptr(dbeta), _stream()), "la_layernorm_bwd_res")
 
 
 def act_fwd(x, y, kind: int) -> None:

@@ -608,7 +608,7 @@ __device__ __forceinline__ void mfma32_gather(f32x16& acc, int ns2, FA&& fa, FB&
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 5) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
+__global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                          const float* __restrict__ drelw, const float* __restrict__ tabh,
                                                          const float* __restrict__ tabw, float* __restrict__ dtabh, float* __restrict__ dtabw,
                                                          int B, int heads, int G, int E, float gscale, int RY) {

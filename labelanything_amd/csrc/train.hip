@@ -328,8 +328,10 @@ __device__ __forceinline__ float gelu_grad(float z) {
 template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long rows, int E,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                            int gelu, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            int gelu, float* dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, const float* add, void* out16, int dt16) {
+  // add != nullptr: dx = LN backward + add (the gradient that arrives over the block's skip connection; add may be dx itself);
+  // out16 != nullptr: a 16-bit copy of dx on the way (the operand of the next backward GEMM)
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
   float gm[VPL], bt[VPL], sg[VPL], sb[VPL];
@@ -380,7 +382,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = lane + 64 * v;
-      if (c < E) dx[r * E + c] = rstd * (dv[v] - s1 - xv[v] * s2);
+      if (c < E) {
+        float o = rstd * (dv[v] - s1 - xv[v] * s2);
+        if (add) o += add[r * E + c];
+        dx[r * E + c] = o;
+        if (out16) {
+          if (dt16 == LA_F16) reinterpret_cast<f16_t*>(out16)[r * E + c] = (f16_t)o;
+          else reinterpret_cast<bf16_t*>(out16)[r * E + c] = (bf16_t)o;
+        }
+      }
     }
   }
   // the four waves of the workgroup meet in LDS first: a quarter of the atomics (8192 waves adding to the same 2 E addresses
@@ -501,7 +511,32 @@ struct AttnBwdArgs {
   int ldq, ldk, ldv, ldo;        // dq / dk / dv use the same leading dimensions as q / k / v
   int B, Nq, Nk, heads;
   float scale;
+  int vec;                       // every pointer 16-byte aligned and every leading dimension a multiple of 4: rows move as float4
 };
+
+// one thread's head slice of a row (HDIM consecutive floats; rows of neighbouring threads are a leading dimension apart, so a 4-byte
+// access touches 64 cache lines per instruction: float4 quarters the instruction count)
+template <int HDIM> __device__ __forceinline__ void load_row(const float* p, float (&v)[HDIM], bool vec) {
+  if (vec) {
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + d);
+      v[d] = t.x; v[d + 1] = t.y; v[d + 2] = t.z; v[d + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) v[d] = p[d];
+  }
+}
+template <int HDIM> __device__ __forceinline__ void store_row(float* p, const float (&v)[HDIM], bool vec) {
+  if (vec) {
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) *reinterpret_cast<float4*>(p + d) = make_float4(v[d], v[d + 1], v[d + 2], v[d + 3]);
+  } else {
+#pragma unroll
+    for (int d = 0; d < HDIM; ++d) p[d] = v[d];
+  }
+}
 
 template <int HDIM>
 __global__ __launch_bounds__(256) void attn_lse_kernel(AttnBwdArgs a, float* __restrict__ lse) {
@@ -562,10 +597,11 @@ __global__ __launch_bounds__(AttnSmallCfg<HDIM>::QW) void attn_bwd_fewkeys_kerne
   const long bq = (long)b * a.Nq + min(qi, a.Nq - 1);
   float qv[HDIM], dov[HDIM], dqv[HDIM];
   const float lv = live ? 1.f : 0.f;           // (threads beyond Nq carry dO = 0: dS = 0 and P dO = 0, no masks further down)
+  load_row<HDIM>(a.q + bq * a.ldq + h * HDIM, qv, a.vec);
+  load_row<HDIM>(a.dout + bq * a.ldo + h * HDIM, dov, a.vec);
 #pragma unroll
   for (int d = 0; d < HDIM; ++d) {
-    qv[d] = a.q[bq * a.ldq + h * HDIM + d];
-    dov[d] = a.dout[bq * a.ldo + h * HDIM + d] * lv;
+    dov[d] *= lv;
     dqv[d] = 0.f;
     sq[tid][d] = qv[d];
     sdo[tid][d] = dov[d];
@@ -632,10 +668,7 @@ __global__ __launch_bounds__(AttnSmallCfg<HDIM>::QW) void attn_bwd_fewkeys_kerne
     }
     __syncthreads();
   }
-  if (live) {
-#pragma unroll
-    for (int d = 0; d < HDIM; ++d) a.dq[bq * a.ldq + h * HDIM + d] = dqv[d];
-  }
+  if (live) store_row<HDIM>(a.dq + bq * a.ldq + h * HDIM, dqv, a.vec);
 }
 
 template <int HDIM>
@@ -651,10 +684,10 @@ __global__ __launch_bounds__(AttnSmallCfg<HDIM>::QW) void attn_bwd_fewqueries_ke
   const float lv = live ? 1.f : 0.f;
   const size_t krow = (size_t)b * a.Nk + min(kj, a.Nk - 1);
   float kv[HDIM], vv[HDIM], dkv[HDIM], dvv[HDIM];
+  load_row<HDIM>(a.k + krow * a.ldk + h * HDIM, kv, a.vec);
+  load_row<HDIM>(a.v + krow * a.ldv + h * HDIM, vv, a.vec);
 #pragma unroll
   for (int d = 0; d < HDIM; ++d) {
-    kv[d] = a.k[krow * a.ldk + h * HDIM + d];
-    vv[d] = a.v[krow * a.ldv + h * HDIM + d];
     dkv[d] = dvv[d] = 0.f;
     sk[tid][d] = kv[d];
   }
@@ -703,11 +736,8 @@ __global__ __launch_bounds__(AttnSmallCfg<HDIM>::QW) void attn_bwd_fewqueries_ke
     __syncthreads();
   }
   if (live) {
-#pragma unroll
-    for (int d = 0; d < HDIM; ++d) {
-      a.dk[krow * a.ldk + h * HDIM + d] = dkv[d];
-      a.dv[krow * a.ldv + h * HDIM + d] = dvv[d];
-    }
+    store_row<HDIM>(a.dk + krow * a.ldk + h * HDIM, dkv, a.vec);
+    store_row<HDIM>(a.dv + krow * a.ldv + h * HDIM, dvv, a.vec);
   }
 }
 
@@ -981,7 +1011,14 @@ extern "C" int la_colsum_acc(const float* dy, int ldy, long M, int N, float* out
 
 extern "C" int la_layernorm_bwd(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
                                 float* dx, float* dgamma, float* dbeta, void* stream) {
+  return la_layernorm_bwd_res(x, dy, rows, E, gamma, beta, eps, gelu, nullptr, dx, nullptr, LA_F16, dgamma, dbeta, stream);
+}
+
+extern "C" int la_layernorm_bwd_res(const float* x, const float* dy, long rows, int E, const float* gamma, const float* beta, float eps, int gelu,
+                                    const float* add, float* dx, void* out16, int dt16, float* dgamma, float* dbeta, void* stream) {
   LA_CHECK_ARG(x && dy && gamma && beta && dx && dgamma && dbeta, "la_layernorm_bwd: null pointer");
+  LA_CHECK_ARG(dt16 == LA_F16 || dt16 == LA_BF16, "la_layernorm_bwd: bad 16-bit dtype %d", dt16);
+  LA_CHECK_ARG(!(add || out16) || !(E <= 32 && rows >= 65536), "la_layernorm_bwd_res: the narrow (E <= 32) form has no skip / 16-bit output");
   LA_CHECK_ARG(rows > 0 && E > 0 && E <= 2048, "la_layernorm_bwd: E=%d out of range (1..2048)", E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (E <= 32 && rows >= 65536) {                    // 4 / 16 / 32 channels over very many pixels (LayerNorm2d stacks): one thread per row
@@ -997,7 +1034,8 @@ extern "C" int la_layernorm_bwd(const float* x, const float* dy, long rows, int 
   long blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   const dim3 grid((unsigned)blocks), block(256);
-#define LA_LNB(V) hipLaunchKernelGGL(la::layernorm_bwd_kernel<V>, grid, block, 0, st, x, dy, rows, E, gamma, beta, eps, gelu, dx, dgamma, dbeta)
+#define LA_LNB(V) \
+  hipLaunchKernelGGL(la::layernorm_bwd_kernel<V>, grid, block, 0, st, x, dy, rows, E, gamma, beta, eps, gelu, dx, dgamma, dbeta, add, out16, dt16)
   if (E <= 64) LA_LNB(1);
   else if (E <= 128) LA_LNB(2);
   else if (E <= 256) LA_LNB(4);
@@ -1052,6 +1090,9 @@ extern "C" int la_attn_small_bwd(const float* q, int ldq, const float* k, int ld
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = lse; a.dq = dq; a.dk = dk; a.dv = dv;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.Nq = Nq; a.Nk = Nk; a.heads = heads;
   a.scale = 1.0f / sqrtf((float)hd);
+  a.vec = ((ldq | ldk | ldv | ldo | hd) & 3) == 0 &&
+          ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout) |
+            reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) & 15) == 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool fewkeys = Nk <= 256 && (Nk <= Nq || Nq > 256);
   if (fewkeys) {

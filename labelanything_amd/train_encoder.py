@@ -282,15 +282,16 @@ class HfEncoderGraph:
         tmp = torch.empty_like(d_out)
         L.cast(d_out.contiguous(), tmp, s)
         dfin.view(bn, t, e)[:, 1:].copy_(tmp.view(bn, hw, e))
+        # dres: the running fp32 gradient of the residual stream, d16 its 16-bit copy (the operand of the next backward GEMM) - both
+        # leave every LayerNorm backward together with the skip connection's share (la_layernorm_bwd_res)
         dres = torch.empty(rows, e, device=dev)
-        L.layernorm_bwd(c["x_fin"], dfin, w[pre + ".layernorm.weight"], w[pre + ".layernorm.bias"], 1e-12, False, dres,
-                        sv[pre + ".layernorm.weight"], sv[pre + ".layernorm.bias"])
         d16 = torch.empty(rows, e, device=dev, dtype=dt)
+        L.layernorm_bwd_res(c["x_fin"], dfin, w[pre + ".layernorm.weight"], w[pre + ".layernorm.bias"], 1e-12, None, dres, d16,
+                            sv[pre + ".layernorm.weight"], sv[pre + ".layernorm.bias"])
         dh = torch.empty(rows, spec.mlp, device=dev)
         dpre32 = torch.empty(rows, spec.mlp, device=dev)
         dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
         dxn = torch.empty(rows, e, device=dev)
-        dx = torch.empty(rows, e, device=dev)
         dao = torch.empty(rows, e, device=dev, dtype=dt)
         dqkv16 = torch.empty(rows, 3 * e, device=dev, dtype=dt)
         dqkv32 = torch.empty(rows, 3 * e, device=dev)
@@ -301,16 +302,14 @@ class HfEncoderGraph:
             lp = f"{pre}.encoder.layer.{i}"
             a = c["layers"][i]
             # ---- MLP: res = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------------------------------------
-            L.cast(dres, d16)
             self._linear_bwd(dres, d16, a["post"], lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
             # (the fp32 copy of d pre-activation only feeds the exact-fp32 fallbacks of the weight / bias gradient)
             need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
             L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
             self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias",
                              dx32=dxn)
-            L.layernorm_bwd(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, False, dx,
-                            sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
-            L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])
+            L.layernorm_bwd_res(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, dres, dres, d16,
+                                sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
             # ---- attention: x_mid = x_in + proj(attn(LN1(x_in))) -------------------------------------------------------------
             self._linear_bwd(dres, d16, a["ao"], lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
             L.head_transpose(a["qkv"], e, bn, heads, t, tpad, kt)
@@ -327,9 +326,8 @@ class HfEncoderGraph:
                     L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
             wqkv_t = self._wt16(att + "qkv", lambda: torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]]), dt)
             L.gemm(dqkv16, wqkv_t, out32=dxn)                                                                  # [3E, E]^T
-            L.layernorm_bwd(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, False, dx,
-                            sv[lp + ".layernorm_before.weight"], sv[lp + ".layernorm_before.bias"])
-            L.add_cast(dres, dx, rows, out32=dres, dt=L._DT[dt])
+            L.layernorm_bwd_res(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, dres, dres, d16,
+                                sv[lp + ".layernorm_before.weight"], sv[lp + ".layernorm_before.bias"])
         # ---- embeddings: res0[b, 0] = cls + pos[0]; res0[b, 1 + i] = patch_i W^T + b + pos[1 + i] --------------------------------
         emb = pre + ".embeddings."
         d0 = dres.view(bn, t, e)
@@ -469,24 +467,22 @@ class SamEncoderGraph(HfEncoderGraph):
         dres = torch.empty(rows, e, device=dev)
         L.cast(d_out.contiguous(), dres, s)
         d16 = torch.empty(rows, e, device=dev, dtype=dt)
+        L.cast(dres, d16)
         dh = torch.empty(rows, spec.mlp, device=dev)
         dpre32 = torch.empty(rows, spec.mlp, device=dev)
         dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
         dxn = torch.empty(rows, e, device=dev)
-        dx = torch.empty(rows, e, device=dev)
         for i in reversed(range(spec.depth)):
             bp = f"{pre}.blocks.{i}"
             a = c["layers"][i]
             nb, gg, t, tpad, arows = a["nb"], a["g"], a["t"], a["tpad"], a["arows"]
             # ---- MLP: res = x_mid + lin2(gelu(lin1(LN2(x_mid)))) -----------------------------------------------------------------
-            L.cast(dres, d16)
             self._linear_bwd(dres, d16, a["post"], bp + ".mlp.lin2.weight", bp + ".mlp.lin2.bias", dx32=dh)
             need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
             L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
             self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], bp + ".mlp.lin1.weight", bp + ".mlp.lin1.bias", dx32=dxn)
-            L.layernorm_bwd(a["x_mid"], dxn, w[bp + ".norm2.weight"], w[bp + ".norm2.bias"], 1e-6, False, dx, sv[bp + ".norm2.weight"],
-                            sv[bp + ".norm2.bias"])
-            L.add_cast(dres, dx, rows, out32=dres, out16=d16, dt=L._DT[dt])
+            L.layernorm_bwd_res(a["x_mid"], dxn, w[bp + ".norm2.weight"], w[bp + ".norm2.bias"], 1e-6, dres, dres, d16, sv[bp + ".norm2.weight"],
+                                sv[bp + ".norm2.bias"])
             # ---- attention: x_mid = x_in + unpartition(proj(attn(partition(LN1(x_in))))) ------------------------------------------
             if a["global"]:
                 dy16, dy32 = d16, dres
@@ -517,9 +513,8 @@ class SamEncoderGraph(HfEncoderGraph):
             dxa = torch.empty(arows, e, device=dev)
             L.gemm(dqkv16, self._wt16(bp + ".attn.qkv", lambda: w[bp + ".attn.qkv.weight"], dt), out32=dxa)
             dxn_i = dxa if a["global"] else dxa.index_select(0, self._win_index(bn, g, ws, dev))
-            L.layernorm_bwd(a["x_in"], dxn_i.contiguous(), w[bp + ".norm1.weight"], w[bp + ".norm1.bias"], 1e-6, False, dx, sv[bp + ".norm1.weight"],
-                            sv[bp + ".norm1.bias"])
-            L.add_cast(dres, dx, rows, out32=dres, dt=L._DT[dt])
+            L.layernorm_bwd_res(a["x_in"], dxn_i.contiguous(), w[bp + ".norm1.weight"], w[bp + ".norm1.bias"], 1e-6, dres, dres, d16,
+                                sv[bp + ".norm1.weight"], sv[bp + ".norm1.bias"])
         # ---- patch embedding + absolute position embedding: res0[b, i] = patch_i W^T + b + pos[i] -------------------------------------
         k = 3 * spec.patch * spec.patch
         a32 = torch.empty(rows, k, device=dev)

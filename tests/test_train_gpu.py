@@ -340,3 +340,22 @@ def test_small_attention_backward_matches_torch_autograd(shape):
     for name, mine, r in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
         # (one key: softmax == 1, dq and dk are exactly zero in the reference - the bound is relative to the data scale then)
         assert float((mine.double().cpu() - r).abs().max()) <= 5e-6 * max(1.0, float(r.abs().max())), name
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_layernorm_backward_with_skip_connection_and_16bit_copy(dt):
+    """la_layernorm_bwd_res == la_layernorm_bwd followed by the skip connection's add and a cast (in place on the running gradient)."""
+    from labelanything_amd import _lib as L
+    rows, e = 901, 768
+    g = torch.Generator().manual_seed(5)
+    x, dy, skip = (torch.randn(rows, e, generator=g).cuda() for _ in range(3))
+    gamma, beta = (1 + 0.3 * torch.randn(e, generator=g)).cuda(), torch.randn(e, generator=g).cuda()
+    dx, dg0, db0 = torch.empty_like(x), torch.zeros(e, device="cuda"), torch.zeros(e, device="cuda")
+    L.layernorm_bwd(x, dy, gamma, beta, 1e-6, False, dx, dg0, db0)
+    run, out16 = skip.clone(), torch.empty(rows, e, device="cuda", dtype=dt)
+    dg1, db1 = torch.zeros(e, device="cuda"), torch.zeros(e, device="cuda")
+    L.layernorm_bwd_res(x, dy, gamma, beta, 1e-6, run, run, out16, dg1, db1)
+    torch.cuda.synchronize()
+    assert torch.equal(run, dx + skip)
+    assert torch.equal(out16, (dx + skip).to(dt))
+    assert float((dg1 - dg0).abs().max()) <= 1e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 1e-5 * float(db0.abs().max())
