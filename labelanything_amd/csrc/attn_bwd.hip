@@ -710,6 +710,133 @@ __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same gradients for small grids (G <= 16: the 14 x 14 windows, 1200 image-heads of 196 queries per SAM-B block) as two dense
+// products per 32 queries, without the per-row workgroups above (16 800 of them per launch, each a chain of three dependent global round
+// trips: 0.5 ms for 90 MB of traffic).  With U[q][c] = drelh[q][y_q + G - 1 - c] (c < 32) | drelw[q][x_q + G - 1 - (c - 32)] (c >= 32)
+// - the terms' gradients shifted onto the table row they multiply, zero outside the grid - and Rcat = [Rh ; Rw] padded to 2 x 32 rows:
+//   dq[q][:]    += U[q][:] . Rcat           (computed transposed, dq^T = Rcat^T U^T: a lane ends up with 4-channel groups of its query)
+//   dRcat[c][:] += sum_q U[q][c] q[q][:]
+// on the exact-fp32 MFMA.  One wave = one unit of 32 consecutive queries of an image-head at a time (its drelh / drelw / q rows staged in a
+// private LDS area, no workgroup barriers in the loop); dRcat stays in 64 accumulator registers over all the units a wave walks, the
+// four waves meet in LDS at the end and the tables receive one atomic per entry and workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
+                                                                 const float* __restrict__ drelw, const float* __restrict__ tabh,
+                                                                 const float* __restrict__ tabw, float* __restrict__ dtabh,
+                                                                 float* __restrict__ dtabw, int B, int heads, int G, int E, float gscale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  const int T_ = G * G, E3 = 3 * E, NREL = 2 * G - 1, NS = (NREL + 1) >> 1;
+  float* stab = reinterpret_cast<float*>(smem);                                   // [64][64]: Rh rows (zero beyond NREL) | Rw rows
+  const int wave_lds = 2 * 32 * G * (int)sizeof(float) + 32 * 64 * (int)sizeof(T);
+  float* sdh = reinterpret_cast<float*>(smem + 64 * 64 * sizeof(float) + wave * wave_lds);    // [32][G] drelh of the unit's queries
+  float* sdw = sdh + 32 * G;
+  T* sq = reinterpret_cast<T*>(sdw + 32 * G);                                     // [32][64] q rows
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = c & 31;
+    stab[i] = r < NREL ? (c < 32 ? tabh : tabw)[r * 64 + (i & 63)] : 0.f;
+  }
+  __syncthreads();
+  f32x16 dR[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dR[i][j][r] = 0.f;
+  const int units_per = (T_ + 31) >> 5, nunits = B * heads * units_per;
+  const int ginv = 65536 / G + 1;                          // q / G == (q * ginv) >> 16 for q < 256
+  for (int unit = blockIdx.x * 4 + wave; unit < nunits; unit += gridDim.x * 4) {
+    const int bh = unit / units_per, q0 = (unit % units_per) * 32, b = bh / heads, h = bh % heads;
+    {
+      const size_t base = ((size_t)bh * T_ + q0) * G;
+      const int n = min(32, T_ - q0) * G;
+      for (int i = lane; i < 32 * G; i += 64) {
+        sdh[i] = i < n ? drelh[base + i] : 0.f;
+        sdw[i] = i < n ? drelw[base + i] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = (lane >> 3) + 8 * p;
+        uint4 v = *reinterpret_cast<const uint4*>(qkv + ((size_t)b * T_ + min(q0 + row, T_ - 1)) * E3 + h * 64 + (lane & 7) * 8);
+        if (q0 + row >= T_) v = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(sq + row * 64 + (lane & 7) * 8) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // ---- dq^T[d][q] = sum_c Rcat[c][d] U[q][c]: A = table column block, B = the lane's query --------------------------------------
+    const int q = q0 + fr, qv = min(q, T_ - 1), qy = (qv * ginv) >> 16, qx = qv - qy * G;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float* sd = half ? sdw : sdh;
+      const int pos = (half ? qx : qy) + G - 1;
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const int c = 2 * s2 + fh, k = pos - c;
+        const float bv = (k >= 0 && k < G) ? sd[fr * G + k] : 0.f;        // (c == NREL, the odd pad, has k = pos - NREL < 0 ... or a zero table row)
+        const float* tr = stab + (half * 32 + c) * 64;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[fr], bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(tr[32 + fr], bv, acc[1], 0, 0, 0);
+      }
+    }
+    if (q < T_) {
+      T* p = dqkv + ((size_t)b * T_ + q) * E3 + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          T* pp = p + dt * 32 + 8 * g4 + 4 * fh;
+          uint2 v = *reinterpret_cast<const uint2*>(pp);
+          const T* cur = reinterpret_cast<const T*>(&v);
+          uint2 o;
+          o.x = pack2<T>((float)cur[0] + acc[dt][g4 * 4 + 0], (float)cur[1] + acc[dt][g4 * 4 + 1]);
+          o.y = pack2<T>((float)cur[2] + acc[dt][g4 * 4 + 2], (float)cur[3] + acc[dt][g4 * 4 + 3]);
+          *reinterpret_cast<uint2*>(pp) = o;
+        }
+    }
+    // ---- dRcat[c][d] += sum_q U[q][c] q[q][d]: A = the lane's table row over the unit's queries, B = q rows ---------------------------
+#pragma unroll 4
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int ql = 2 * s2 + fh, qg = min(q0 + ql, T_ - 1), yq = (qg * ginv) >> 16, xq = qg - yq * G;
+      const int kh = yq + G - 1 - fr, kw = xq + G - 1 - fr;
+      const float ah = (kh >= 0 && kh < G) ? sdh[ql * G + kh] : 0.f;      // (rows beyond T are zero in the staged arrays; fr >= NREL gives k < 0)
+      const float aw = (kw >= 0 && kw < G) ? sdw[ql * G + kw] : 0.f;
+      const float b0 = (float)sq[ql * 64 + fr], b1 = (float)sq[ql * 64 + 32 + fr];
+      dR[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, b0, dR[0][0], 0, 0, 0);
+      dR[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, b1, dR[0][1], 0, 0, 0);
+      dR[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b0, dR[1][0], 0, 0, 0);
+      dR[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, b1, dR[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();                       // (the staging area is rewritten by the next unit)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // the four waves' table gradients meet in the table's own LDS area, then one atomic per entry
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) stab[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        atomicAdd(&stab[c * 64 + dt * 32 + fr], dR[ct][dt][r]);
+      }
+  __syncthreads();
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = c & 31;
+    if (r < NREL) atomicAdd(&(c < 32 ? dtabh : dtabw)[r * 64 + (i & 63)], stab[i] * gscale);
+  }
+}
+
 }  // namespace la
 
 extern "C" int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T, int Tpad, void* dst, int dt, void* stream) {
@@ -758,6 +885,20 @@ extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, co
   LA_CHECK_ARG(qkv && dqkv && drelh && drelw && tabh && tabw && dtabh && dtabw, "la_relpos_bwd: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * 64, "la_relpos_bwd: needs head_dim 64, G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_bwd: bad dtype %d", dt);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (G <= 16) {                                     // the windows: dense products over units of 32 queries
+    const int lds_rows = 64 * 64 * (int)sizeof(float) + 4 * (2 * 32 * G * (int)sizeof(float) + 32 * 64 * 2);
+    const int nunits = B * heads * ((G * G + 31) / 32);
+    const int grid_rows = nunits / 4 < 512 ? (nunits + 3) / 4 : 512;          // (256 / 512 / 768 workgroups on 100 x 12 windows: 135 / 117 / 132 us)
+    if (dt == LA_F16)
+      hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::f16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv,
+                         drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+    else
+      hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::bf16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::bf16_t*)qkv,
+                         (la::bf16_t*)dqkv, drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+    LA_CHECK_LAUNCH("la_relpos_bwd");
+    return 0;
+  }
   const int lds = (2 * G * (G + 1) + (2 * G - 1) * 64) * (int)sizeof(float) + G * 64 * 2;        // 73 KiB at G = 64: two workgroups per CU
   // rows per workgroup.  Large grids (G == 64: 4 image-heads x 64 rows per CU): as many as keep >= ~3 workgroups per CU in the launch - the
   // table atomics shrink by that factor.  Windows (G <= 32, tables of a few KiB, workgroups of 10 KiB): one row each - a row's three
@@ -766,7 +907,6 @@ extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, co
   int ry = 1;
   while (G > 32 && ry < G && (long)B * heads * ((G + 2 * ry - 1) / (2 * ry)) >= 768) ry *= 2;
   const int grid = B * heads * ((G + ry - 1) / ry);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static unsigned long long m1 = 0, m2 = 0;
   if (dt == LA_F16) {
     la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::f16_t>), 80 * 1024, m1);
