@@ -2365,6 +2365,85 @@ static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M,
   else launch_skinny_kw<T, 1>(a, lda, w, ldw, M, N, K, e, st);
 }
 
+// =================================================================================================================
+// A few hundred fp32 rows (32 < M <= 512: the decoder tokens of many prompt pairs - 240 x 2048 x 256 is the token MLP of cfg4) on the
+// exact-fp32 MFMA with 32 x 32 tiles, one per WAVE, operands straight from global memory: 512 wave tiles fill the chip where a 128 x 128
+// grid has 32 workgroups, and the row-chunked VALU kernel above spends 71 us on this shape with half its lanes idle (K = 256 is 32 lanes
+// of 8).  A lane loads float4s - k = 8 j + 4 fh .. + 3 of chunk j for its row of A and of W - and the four elements feed four MFMA steps:
+// any assignment of k to (step, half-wave) is fine as long as A and W agree.
+//   KS = 1: the four waves of a workgroup own 2 x 2 tiles, each over all of K.
+//   KS = 4 (K >= 1024): the four waves split the 8-wide k-chunks of ONE tile and meet in LDS (fixed summation order).
+// =================================================================================================================
+template <int KS>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Wt, int ldw, int M,
+                                                             int N, int K, LaGemmEpilogue e) {
+  __shared__ float part[KS == 4 ? 4 : 1][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
+  const int tm = KS == 4 ? blockIdx.y : blockIdx.y * 2 + (wave >> 1), tn = KS == 4 ? blockIdx.x : blockIdx.x * 2 + (wave & 1);
+  const bool active = tm * 32 < M && tn * 32 < N;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (active) {
+    const float* ap = A + (size_t)min(tm * 32 + fr, M - 1) * lda + 4 * fh;
+    const float* wp = Wt + (size_t)min(tn * 32 + fr, N - 1) * ldw + 4 * fh;
+    const int nchunk = K >> 3;
+    // batches of 8 chunks: 16 independent 16-byte loads in flight, then 32 MFMAs
+    for (int j0 = (KS == 4 ? wave : 0); j0 < nchunk; j0 += 8 * KS) {
+      float4 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = min(j0 + u * KS, nchunk - 1);       // (beyond K: a valid address, the products are skipped below)
+        a[u] = *reinterpret_cast<const float4*>(ap + 8 * j);
+        b[u] = *reinterpret_cast<const float4*>(wp + 8 * j);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u * KS < nchunk) {                          // wave-uniform
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (KS == 4) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+  }
+  if (!active) return;
+  const int col = tn * 32 + fr;
+  if (col >= N) return;
+  float* outT = reinterpret_cast<float*>(e.out16);
+  const float bias = e.bias ? e.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+    if (m >= M) continue;
+    float v = acc[r] + bias;
+    if (e.act == LA_ACT_GELU) v = gelu_erf(v);
+    else if (e.act == LA_ACT_RELU) v = fmaxf(v, 0.f);
+    if (e.res) v += e.res[(size_t)(e.res_mod ? m % e.res_mod : m) * e.ldr + col];
+    if (e.out32) e.out32[(size_t)m * e.ld32 + col] = v;
+    if (outT) outT[(size_t)m * e.ld16 + col] = v;
+  }
+}
+
+static void launch_f32_small(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
+  const int tm = (M + 31) / 32, tn = (N + 31) / 32;
+  if (K >= 1024)
+    hipLaunchKernelGGL(gemm_f32_small_kernel<4>, dim3(tn, tm), dim3(256), 0, st, reinterpret_cast<const float*>(A), lda,
+                       reinterpret_cast<const float*>(W), ldw, M, N, K, e);
+  else
+    hipLaunchKernelGGL(gemm_f32_small_kernel<1>, dim3((tn + 1) / 2, (tm + 1) / 2), dim3(256), 0, st, reinterpret_cast<const float*>(A), lda,
+                       reinterpret_cast<const float*>(W), ldw, M, N, K, e);
+}
+
 template <typename T>
 static int launch_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e,
                        hipStream_t st) {
@@ -2415,10 +2494,15 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
                epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // up to 512 fp32 rows (decoder tokens of many prompt pairs) still go row-chunked through the VALU kernel: an MFMA tile grid of a
-  // handful of workgroups leaves the chip idle (240 x 256 x 2048: 155 us on four 128 x 128 tiles)
+  // up to 512 fp32 rows (decoder tokens of many prompt pairs): an MFMA grid of 128 x 128 tiles is a handful of workgroups and leaves the
+  // chip idle (240 x 256 x 2048: 155 us on four tiles) - 32 x 32 wave tiles (gemm_f32_small_kernel) above 32 rows, the VALU kernel below
   const bool few_rows = M <= 32 || (dt == LA_F32 && M <= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64);
   const bool skinny = few_rows && (K % 8) == 0 && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && !epi->vt;
+  if (skinny && dt == LA_F32 && M > 32 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) {
+    la::launch_f32_small(A, lda, W, ldw, M, N, K, *epi, st);       // (K, lda, ldw are multiples of 4 here: float4 operand loads)
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
   if (skinny) {
     if (dt == LA_F32) la::launch_skinny<float>(A, lda, W, ldw, M, N, K, *epi, st);
     else if (dt == LA_F16) la::launch_skinny<la::f16_t>(A, lda, W, ldw, M, N, K, *epi, st);
