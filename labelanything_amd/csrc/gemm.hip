@@ -2366,7 +2366,7 @@ static void launch_skinny(const void* A, int lda, const void* W, int ldw, int M,
 }
 
 // =================================================================================================================
-// A few hundred fp32 rows (32 < M <= 512: the decoder tokens of many prompt pairs - 240 x 2048 x 256 is the token MLP of cfg4) on the
+// A few hundred fp32 rows (128 < M <= 512: the decoder tokens of many prompt pairs - 240 x 2048 x 256 is the token MLP of cfg4) on the
 // exact-fp32 MFMA with 32 x 32 tiles, one per WAVE, operands straight from global memory: 512 wave tiles fill the chip where a 128 x 128
 // grid has 32 workgroups, and the row-chunked VALU kernel above spends 71 us on this shape with half its lanes idle (K = 256 is 32 lanes
 // of 8).  A lane loads float4s - k = 8 j + 4 fh .. + 3 of chunk j for its row of A and of W - and the four elements feed four MFMA steps:
@@ -2495,10 +2495,15 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // up to 512 fp32 rows (decoder tokens of many prompt pairs): an MFMA grid of 128 x 128 tiles is a handful of workgroups and leaves the
-  // chip idle (240 x 256 x 2048: 155 us on four tiles) - 32 x 32 wave tiles (gemm_f32_small_kernel) above 32 rows, the VALU kernel below
+  // chip idle (240 x 256 x 2048: 155 us on four tiles) - 32 x 32 wave tiles (gemm_f32_small_kernel) above 128 rows, the VALU kernel below
   const bool few_rows = M <= 32 || (dt == LA_F32 && M <= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64);
   const bool skinny = few_rows && (K % 8) == 0 && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && !epi->vt;
-  if (skinny && dt == LA_F32 && M > 32 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) {
+  static const char* nosmall = la_dbg_env("LA_NO_F32_SMALL");   // debugging: the row-chunked VALU kernel for every few-row fp32 shape
+  // (from 129 rows: up to 128 rows - the per-image vectors of the encoder's token-mean corrections, one row per image - stay on the VALU
+  // kernel, whose lane-parallel partial sums round 4 x closer to fp64 than the MFMA's serial chain (9e-8 against 4e-7 on 52 x 768 x 1536);
+  // the corrections accumulate over every block of the encoder and a 26- and a 52-image batch must not take different kernels:
+  // tests/test_model_gpu.py::test_full_geometry_episode_properties measured 2.7e-4 on the cfg3 logits between the two)
+  if (skinny && dt == LA_F32 && M > 128 && !nosmall && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(W)) & 15) == 0) {
     la::launch_f32_small(A, lda, W, ldw, M, N, K, *epi, st);       // (K, lda, ldw are multiples of 4 here: float4 operand loads)
     LA_CHECK_LAUNCH("la_gemm");
     return 0;

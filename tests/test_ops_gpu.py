@@ -264,10 +264,10 @@ def test_bad_arguments_raise(L):
 
 
 @pytest.mark.parametrize("mnk", [(300, 200, 256), (4096, 128, 256), (1000, 32, 288), (8, 2048, 256), (20, 256, 2048), (3, 32, 256), (64, 8, 72),
-                                 (240, 2048, 256), (240, 256, 2048), (300, 40, 136), (512, 64, 1032), (33, 8, 8)])
+                                 (240, 2048, 256), (240, 256, 2048), (300, 40, 136), (512, 64, 1032), (129, 8, 8)])
 def test_gemm_fp32_exact_mfma_and_skinny(L, mnk):
-    """LA_F32: exact-fp32 MFMA (128 x 128 tiles; 32 x 32 wave tiles for 32 < M <= 512 with and without the in-workgroup K split; the VALU
-    skinny kernel for M <= 32) vs torch fp32 matmul."""
+    """LA_F32: exact-fp32 MFMA (128 x 128 tiles; 32 x 32 wave tiles for 128 < M <= 512 with and without the in-workgroup K split; the VALU
+    skinny kernel for M <= 128) vs torch fp32 matmul."""
     m, n, k = mnk
     a = rnd(m, k, seed=50)
     w = rnd(n, k, seed=51) / math.sqrt(k)
