@@ -51,6 +51,14 @@ timeout 300 python tools/blas_calibration.py > $OUT/${R}_blas_calibration.log 2>
 timeout 600 python bench.py --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg2.log > /dev/null
 timeout 600 python bench.py --workload cfg1 --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg1.log > /dev/null
 timeout 300 python tools/attn_ab.py > $OUT/${R}_attn_shapes.log 2>&1
+# training-side kernels by shape: flash-attention backward next to its forward, the fp32 weight-gradient GEMM, the rel-pos backward
+timeout 300 python tools/attn_bwd_bench.py > $OUT/${R}_attn_bwd_shapes.log 2>&1
+timeout 300 python tools/gemm_tn_bench.py > $OUT/${R}_gemm_tn_shapes.log 2>&1
+timeout 300 python tools/relpos_bwd_bench.py > $OUT/${R}_relpos_bwd_bench.log 2>&1
+timeout 600 python bench.py --workload cfg3_train --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg3_train.log > /dev/null
+timeout 600 python bench.py --workload cfg3_train --train-encoder --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg3_train_encoder.log > /dev/null
+timeout 600 python bench.py --workload cfg2_train --train-encoder --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg2_train_encoder.log > /dev/null
+timeout 600 python bench.py --workload cfg4 --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg4.log > /dev/null
 [ -x tools/probes/coissue ] && timeout 120 ./tools/probes/coissue > $OUT/${R}_coissue_probe.log 2>&1
 timeout 600 python tools/train_grad_diag.py > $OUT/${R}_train_grad_diag.log 2>&1
 timeout 900 python tools/race_screen.py 40 > $OUT/${R}_race_screen.log 2>&1
