@@ -1032,7 +1032,12 @@ extern "C" int la_layernorm_bwd_res(const float* x, const float* dy, long rows, 
     return 0;
   }
   long blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  // workgroup cap = ONE resident set: a workgroup is one wave per SIMD, and the instance's register count (54 / 86 / 158 / 295 for 4 / 8 /
+  // 16 / 32 values per lane) allows 8 / 5 / 3 / 1 of them per CU.  A partial second round of the grid-stride loop costs a quarter of the
+  // pass (46852 x 768: 1024 workgroups 217 us, 768 172 us; 270000 x 256: 1024 282 us, 2048 256 us)
+  static const char* lnb = la_dbg_env("LA_LNB_BLOCKS");    // debugging: workgroup cap
+  const long cap = lnb ? atol(lnb) : 256L * (E <= 256 ? 8 : E <= 512 ? 5 : E <= 1024 ? 3 : 1);
+  if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned)blocks), block(256);
 #define LA_LNB(V) \
   hipLaunchKernelGGL(la::layernorm_bwd_kernel<V>, grid, block, 0, st, x, dy, rows, E, gamma, beta, eps, gelu, dx, dgamma, dbeta, add, out16, dt16)
