@@ -342,3 +342,25 @@ def test_bf16_training_through_the_encoder_as_baseline_cfg3_words_it():
     before = qw.detach().clone()
     res = tr.step(batch, gt)
     assert bool(torch.isfinite(res["loss"])) and bool(torch.isfinite(tr.opt.flat).all()) and not torch.equal(before, qw.detach())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n", [901 * 3072, 8 * 1000 + 3])
+def test_gelu_forward_and_backward_on_16bit_rows_match_torch(dt, n):
+    """la_gelu_fwd16 / la_gelu_bwd16 (8 elements per thread when the size allows, element-wise otherwise) against torch's erf GELU in fp64
+    on the same 16-bit pre-activations."""
+    from labelanything_amd import _lib as L
+    g = torch.Generator().manual_seed(n % 97)
+    pre = (torch.randn(n, generator=g) * 2).to(dt).cuda()
+    dh = torch.randn(n, generator=g).cuda()
+    d32, d16 = torch.empty(n, device="cuda"), torch.empty(n, device="cuda", dtype=dt)
+    L.gelu_bwd16(pre, dh, d32, d16)
+    x = pre.double().cpu().requires_grad_(True)
+    y = torch.nn.functional.gelu(x)
+    y.backward(dh.double().cpu())
+    assert float((d32.double().cpu() - x.grad).abs().max()) <= 2e-6 * float(x.grad.abs().max())
+    assert torch.equal(d16, d32.to(dt))
+    if n % 8 == 0:
+        post = torch.empty_like(pre)
+        L.gelu_fwd16(pre, post)
+        assert torch.equal(post, y.detach().to(dt).cuda()) or float((post.double().cpu() - y.detach()).abs().max()) <= 2.0 ** -8 * float(y.abs().max())
