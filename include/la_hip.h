@@ -89,7 +89,8 @@ typedef struct LaGemmEpilogue {
   int ksplit;          /* != 0 (16-bit operands): out32 += A . W^T - the bare product ADDED with fp32 atomics, the K range cut into
                           independent chunks so that a product with few output tiles and a very long K (a weight gradient
                           dW[N, K] = dY^T X over all tokens, operands passed transposed) still fills the chip.  N % 256 == 0, K % 64 == 0;
-                          no bias / residual / activation / maps / out16. */
+                          no bias / residual / activation / out16; row map LA_MAP_NONE or LA_MAP_GROUP (several weight gradients a fixed
+                          stride apart in one flat gradient buffer - HF's query / key / value weights - from ONE launch). */
 } LaGemmEpilogue;
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.

@@ -1948,7 +1948,9 @@ __global__ __launch_bounds__(512, 2) void gemm_t256q_kernel(const T* __restrict_
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + grp * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh_;
           if (row < M) {
-            float* op = e.out32 + (size_t)row * e.ld32 + n0 + wi * 64 + fr_;
+            // (LA_MAP_GROUP: the row blocks of several weight gradients that sit a fixed stride apart in one flat gradient buffer)
+            const int drow = e.map == LA_MAP_GROUP ? (row / e.p0) * e.p1 + row % e.p0 + e.p2 : row;
+            float* op = e.out32 + (size_t)drow * e.ld32 + n0 + wi * 64 + fr_;
             unsafeAtomicAdd(op, acc[i][0][r]);
             unsafeAtomicAdd(op + 32, acc[i][1][r]);
           }
@@ -2525,9 +2527,9 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   }
   if (epi->ksplit > 0) {
     // split-K accumulate (weight gradients): out32 += A . W^T with fp32 atomics, K cut into independent chunks
-    LA_CHECK_ARG(epi->out32 && !epi->out16 && !epi->res && !epi->bias && !epi->vt && epi->act == LA_ACT_NONE && epi->map == LA_MAP_NONE &&
-                     epi->amap == LA_MAP_NONE && epi->a_kmod == 0,
-                 "la_gemm: ksplit accumulates the bare product into out32 (no bias / residual / activation / maps / second output)");
+    LA_CHECK_ARG(epi->out32 && !epi->out16 && !epi->res && !epi->bias && !epi->vt && epi->act == LA_ACT_NONE &&
+                     (epi->map == LA_MAP_NONE || (epi->map == LA_MAP_GROUP && epi->p0 > 0)) && epi->amap == LA_MAP_NONE && epi->a_kmod == 0,
+                 "la_gemm: ksplit accumulates the bare product into out32 (no bias / residual / activation / second output; row map none or LA_MAP_GROUP)");
     LA_CHECK_ARG((N % 256) == 0 && (K % 64) == 0 && K >= 128 && (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldw * 2 < (1ull << 32) &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
                  "la_gemm: ksplit needs N %% 256 == 0, K %% 64 == 0, K >= 128, 16-byte aligned operands below 4 GiB (M=%d N=%d K=%d)", M, N, K);

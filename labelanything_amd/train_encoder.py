@@ -211,6 +211,38 @@ class HfEncoderGraph:
             L.gemm_tn(dy32, x32, dw.view(n, k))
             return False
 
+    def _qkv_wgrad_fused(self, dqkv16: Tensor, x: Tensor, att: str, e: int) -> bool:
+        """The three weight gradients of HF's separate query / key / value Linears from ONE split-K product dqkv^T x.  In the flat
+        gradient buffer (FlatAdamW packs the tensors back to back in parameter order) the three [E, E] blocks sit a fixed stride
+        apart - weight, bias, weight, bias, ... - which is la_gemm's LA_MAP_GROUP row map; the bias gradients come out of the
+        transpose's column sums.  Three launches of 9 output tiles each end in three times the atomics of one launch of 27.
+        Returns False (nothing done) when the layout or the shape does not allow it."""
+        sv = self.sviews
+        gw = [sv[att + nm + ".weight"] for nm in ("query", "key", "value")]
+        gb = [sv[att + nm + ".bias"] for nm in ("query", "key", "value")]
+        r = dqkv16.shape[0]
+        if not (self.fast_wgrad and e % 256 == 0 and r >= 128 and all(g.is_contiguous() for g in gw + gb)):
+            return False
+        stride = gw[1].data_ptr() - gw[0].data_ptr()
+        if stride <= 0 or stride % (4 * e) or gw[2].data_ptr() - gw[1].data_ptr() != stride:
+            return False
+        rows_apart = stride // (4 * e)                       # in rows of E floats: E weight rows + the bias row(s) in between
+        rp = _ceil(r, 64)
+        dt = self.ctx["dt"]
+        dyt = self._tbuf("dyt", 3 * e, rp, dt)
+        xt = self._tbuf("xt", e, rp, dt)
+        cs = self._tbuf("qkv_colsum", 3, e, torch.float32)
+        cs.zero_()
+        L.transpose16(dqkv16, dyt, colsum=cs.view(-1))
+        xkey = (x.data_ptr(), tuple(x.shape), x.dtype)
+        if self._xt_key != xkey:
+            L.transpose16(x, xt)
+            self._xt_key = xkey
+        L.gemm(dyt, xt, out32=gw[0].view(e, e), ksplit=1, map=L.MAP_GROUP, p=(e, rows_apart, 0, 0, 0))
+        for j in range(3):
+            gb[j].add_(cs[j])
+        return True
+
     def _tbuf(self, name: str, a: int, b: int, dtype) -> Tensor:
         key = (name, a, b, dtype)
         t = self._tbufs.get(key)
@@ -318,7 +350,7 @@ class HfEncoderGraph:
             L.attn_bwd(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
             att = lp + ".attention.attention."
             have32 = False
-            for j, nm in enumerate(("query", "key", "value")):
+            for j, nm in enumerate(() if self._qkv_wgrad_fused(dqkv16, a["xn"], att, e) else ("query", "key", "value")):
                 if not self._wgrad(dqkv16[:, j * e:(j + 1) * e], None, a["xn"], sv[att + nm + ".weight"], db=sv[att + nm + ".bias"]):
                     if not have32:                    # (exact-fp32 fallback of the weight gradient: it needs the fp32 copy)
                         L.cast(dqkv16, dqkv32)
