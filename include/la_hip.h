@@ -191,6 +191,12 @@ int la_add_cast(const float* x, const float* y, int ymod, long rows, int D, floa
 int la_nchw_to_nhwc(const float* in, int N, int C, int HW, float* out32, void* out16, int dt, void* stream);
 int la_nhwc_to_nchw(const float* in, int N, int C, int HW, float* out, void* stream);
 
+/* Many small contiguous fp32 matrices transposed by one launch: dst[c][r] = src[r][c].  tile_table (device memory): 4 x int64 per 32 x 32
+ * tile - (src pointer, dst pointer, rows << 32 | cols, r0 << 32 | c0).  The W^T copies of every nn.Linear of the decoder for its data
+ * gradient dX = dY W (autograd of models/common.py:19-37, transformer.py, prompt_encoder.py, mask_decoder.py under experiment/run.py:247-331):
+ * once per training step instead of one launch per layer. */
+int la_transpose_many(const long long* tile_table, int ntiles, void* stream);
+
 /* F.interpolate(mode="bilinear", align_corners=False) on fp32 planes [N,h,w] -> [N,H,W] (lam.py:408-413). */
 int la_bilinear(const float* in, int N, int h, int w, int H, int W, float* out, void* stream);
 

@@ -59,7 +59,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
@@ -373,6 +373,14 @@ def layernorm_bwd_res(x, dy, gamma, beta, eps: float, add, dx, out16, dgamma, db
     _check(lib().la_layernorm_bwd_res(_ptr(x), _ptr(dy), C.c_long(rows), C.c_int(e), _ptr(gamma), _ptr(beta), C.c_float(eps), C.c_int(0),
                                       _ptr(add), _ptr(dx), _ptr(out16), C.c_int(dt_of(out16) if out16 is not None else LA_F16), _ptr(dgamma),
                                       _ptr(dbeta), _stream()), "la_layernorm_bwd_res")
+
+
+def transpose_many(tile_table: torch.Tensor) -> None:
+    """tile_table: int64 [ntiles, 4] on the device - (src, dst, rows << 32 | cols, r0 << 32 | c0) per 32 x 32 tile; dst[c][r] = src[r][c]."""
+    _dev(tile_table)
+    if tile_table.dtype != torch.int64 or tile_table.dim() != 2 or tile_table.shape[1] != 4 or not tile_table.is_contiguous():
+        raise ValueError("transpose_many needs a contiguous int64 [ntiles, 4] table")
+    _check(lib().la_transpose_many(_ptr(tile_table), C.c_int(tile_table.shape[0]), _stream()), "la_transpose_many")
 
 
 def act_fwd(x, y, kind: int) -> None:

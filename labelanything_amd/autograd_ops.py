@@ -31,6 +31,53 @@ def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class WeightTransposes:
+    """W^T copies for the data gradients dX = dY W of the nn.Linear layers, refreshed by ONE launch per training step.
+
+    A trainer whose weights keep their addresses (views of one flat parameter buffer) owns an enabled instance, installs it as
+    ``autograd_ops.WT`` and calls ``invalidate()`` at the start of every ``forward_backward`` (the weights may have changed); the first
+    request after that re-transposes every matrix seen so far with one ``la_transpose_many`` launch.  A matrix seen for the first time
+    is transposed on its own and joins the table.  The module's default instance is off: every backward transposes its own weight."""
+
+    def __init__(self, enabled: bool = False, lo: int = 0, hi: int = 0) -> None:
+        self.enabled = enabled
+        self.lo, self.hi = lo, hi    # address range of the flat parameter buffer: only matrices inside it keep their address from step to
+        self.entries = {}            # step (a reshaped / permuted weight is a fresh temporary every time); (data_ptr, rows, cols) -> W^T
+        self.table = None
+        self.fresh = False
+
+    def invalidate(self) -> None:
+        self.fresh = False
+
+    def get(self, w: Tensor) -> Tensor:
+        if not self.enabled or not (self.lo <= w.data_ptr() < self.hi):
+            wt = w.new_empty(w.shape[1], w.shape[0])
+            L.nhwc_to_nchw(w, 1, w.shape[1], w.shape[0], wt)
+            return wt
+        key = (w.data_ptr(), w.shape[0], w.shape[1])
+        wt = self.entries.get(key)
+        if wt is None:
+            wt = w.new_empty(w.shape[1], w.shape[0])
+            L.nhwc_to_nchw(w, 1, w.shape[1], w.shape[0], wt)
+            self.entries[key] = wt
+            self.table = None
+            return wt
+        if not self.fresh:
+            if self.table is None:
+                rows = []
+                for (ptr, r, c), t in self.entries.items():
+                    for r0 in range(0, r, 32):
+                        for c0 in range(0, c, 32):
+                            rows.append((ptr, t.data_ptr(), (r << 32) | c, (r0 << 32) | c0))
+                self.table = torch.tensor(rows, dtype=torch.int64).to(w.device)
+            L.transpose_many(self.table)
+            self.fresh = True
+        return wt
+
+
+WT = WeightTransposes()
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b):
@@ -48,9 +95,8 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            wt = w.new_empty(w.shape[1], w.shape[0])         # W^T in nn.Linear layout, on the transposer kernel (torch's strided copy
-            L.nhwc_to_nchw(w, 1, w.shape[1], w.shape[0], wt)  # of 85 weights was 3 ms of the training step)
-            L.gemm(dy, wt, out32=dx)                         # dY . W
+            wt = WT.get(w)                                   # W^T in nn.Linear layout (torch's strided copy of 85 weights was 3 ms of
+            L.gemm(dy, wt, out32=dx)                         # the training step; one batched launch per step under a trainer): dY . W
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if want_db:
             db = dy.new_zeros(dy.shape[1])
