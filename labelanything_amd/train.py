@@ -387,6 +387,7 @@ class LamTrainer:
         bounds.append((enc_total, sum(sizes)))
         from .parallel import BucketedGradReducer
         self.reducer = BucketedGradReducer(self.opt.grad, bounds)
+        self._sink = A.GradSink([p for _, p in named], self.opt.grad_views, self._on_grad)
         self._wt = A.WeightTransposes(enabled=True, lo=self.opt.flat.data_ptr(), hi=self.opt.flat.data_ptr() + 4 * self.opt.flat.numel())
         self._dec_index0 = n_enc                 # parameters [n_enc, ...) live in the decoder bucket
         self.crit = loss or FocalLossDevice()
@@ -416,6 +417,7 @@ class LamTrainer:
             raise RuntimeError("forward_backward after a synchronising micro-step: call apply_update() first")
         A.WT = self._wt              # the W^T copies of this trainer's weights (flat-buffer views: stable addresses), one launch per step
         self._wt.invalidate()
+        A.SINK = self._sink          # nn.Linear / LayerNorm parameter gradients are added straight into the flat gradient buffer
         with torch.cuda.device(lam._device()):
             with torch.no_grad():
                 inp, _ = lam._prepare(batch, with_post=False, eng=self.engine)
