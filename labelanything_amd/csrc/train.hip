@@ -991,6 +991,14 @@ extern "C" int la_gemm_tn_db(const float* dy, int ldy, const float* x, int ldx, 
   }
   const bool aligned = ((N | K | ldy | ldx) & 3) == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) == 0;
   static const char* dmaenv = la_dbg_env("LA_TN_NODMA");   // debugging: the register-fed kernel everywhere
+  static const char* smallenv = la_dbg_env("LA_TN_NOSMALL");   // debugging: short reductions on the register-fed kernel
+  if (aligned && M >= 256 && M < 4096 && !dmaenv && !smallenv) {
+    // a few hundred rows (the token-side layers of the decoder): one 128 x 128 tile per workgroup of the register-fed kernel walks all of
+    // them alone (23 us for 300 x 256 x 256 on four workgroups); 32 x 32 tiles with the four waves splitting the rows are 64+ workgroups
+    la::launch_gemm_tn_dma<1, 1, 1, 1, 32, 4>(dy, ldy, x, ldx, dw, ldw, M, N, K, db, 256, st0);
+    LA_CHECK_LAUNCH("la_gemm_tn");
+    return 0;
+  }
   if (aligned && M >= 4096 && !dmaenv) {
     // workgroups: one resident set (2 per CU) - every workgroup ends in an atomic per output element, and with the rows prefetched
     // through LDS a long chunk costs nothing (256 / 512 / 1024 / 2048 / 4096 workgroups on 270000 x 128 x 256: 234 / 211 / 207 / 235 /
