@@ -592,7 +592,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma4_kernel(const T* __restrict__
 }
 
 // row-panels per tile group (tile_coords); measured flat within +-2 % for 1..16 on the 256 x 128 / 128 x 128 kernels (default 8)
-// and ~2 % better at 1..4 for the 256 x 256 kernel (dflt = 2 there); LA_GEMM_GROUP_M overrides both
+// and ~2 % better at 1..4 for the 256 x 256 kernel (dflt = 2 there) - except with >= 10 column tiles (lin1: N = 3072), where 8 row
+// panels per group fetch 25 % less through the L2 (1.77 -> 1.33 M KiB of FETCH_SIZE per launch, tools/gemm_group_m.sh: with 2 row panels
+// per group an XCD streams the whole 4.7 MB weight for every pair of panels) and run 1.3 % faster; lin2 / proj (3 column tiles) fetch
+// and run worse beyond 2.  LA_GEMM_GROUP_M overrides both
 static int tile_group_m(int dflt = 8) {
   static int forced = -2;
   if (forced == -2) {
@@ -2013,7 +2016,7 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
   static const char* genv = la_dbg_env("LA_KSPLIT_GRID");      // debugging: workgroups launched (0 = one per tile)
   if (EPI == 4 && genv) grid = atoi(genv) > 0 ? atoi(genv) : ntiles;
   hipLaunchKernelGGL((gemm_t256q_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(2) | (g_gemm_variant & 0x800500), ksplit, kchunk);
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, tile_group_m(N >= 2560 ? 8 : 2) | (g_gemm_variant & 0x800500), ksplit, kchunk);
 }
 
 template <typename T, int NPL, int EPI>
