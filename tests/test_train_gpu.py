@@ -359,3 +359,25 @@ def test_layernorm_backward_with_skip_connection_and_16bit_copy(dt):
     assert torch.equal(run, dx + skip)
     assert torch.equal(out16, (dx + skip).to(dt))
     assert float((dg1 - dg0).abs().max()) <= 1e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 1e-5 * float(db0.abs().max())
+
+
+def test_weight_transposes_in_one_launch_and_the_trainer_side_cache():
+    """la_transpose_many on ragged shapes, and autograd_ops.WeightTransposes: first sight = own launch, afterwards one batched refresh per
+    invalidate(); tensors outside the registered address range are never cached."""
+    from labelanything_amd import _lib as L
+    from labelanything_amd import autograd_ops as A
+    g = torch.Generator().manual_seed(11)
+    flat = torch.randn(33 * 70 + 256 * 256 + 5, generator=g).cuda()
+    views = [flat[:33 * 70].view(33, 70), flat[33 * 70:33 * 70 + 65536].view(256, 256), flat[33 * 70 + 65536:].view(5, 1)]
+    wt = A.WeightTransposes(enabled=True, lo=flat.data_ptr(), hi=flat.data_ptr() + 4 * flat.numel())
+    first = [wt.get(v) for v in views]                       # first sight: one launch each, registered
+    for v, t in zip(views, first):
+        assert torch.equal(t, v.t().contiguous())
+    flat.mul_(-2.0)                                          # "optimizer step"
+    wt.invalidate()
+    again = [wt.get(v) for v in views]                       # one la_transpose_many launch refreshes all three
+    torch.cuda.synchronize()
+    for v, t, f in zip(views, again, first):
+        assert t.data_ptr() == f.data_ptr() and torch.equal(t, v.t().contiguous())
+    other = torch.randn(7, 9, generator=g).cuda()            # not a view of the flat buffer: transposed on its own, not cached
+    assert torch.equal(wt.get(other), other.t().contiguous()) and len(wt.entries) == 3
