@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Same-process A/B of the la_gemm main loops (la_gemm_variant 0: BK 32 persistent, 1: BK 64 quadrant phases) on the encoder shapes
+"""Same-process A/B of the la_gemm main loops (la_gemm_variant 0: BK 32 persistent, 1: BK 64 quadrant phases, 2: four waves x 512
+registers; BLAS=1 adds the vendor GEMM without epilogue as a calibration column) on the encoder shapes
 with the model's epilogues: interleaved rounds, median / min microseconds, TFLOP/s, and a bitwise comparison of the results."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +13,7 @@ if os.environ.get("SHAPES"):       # "name:m:n:k,..." - names starting with lin1
 rounds = int(os.environ.get("ROUNDS", 7))
 
 variants = [int(v, 0) for v in os.environ.get("VARIANTS", "0,1").split(",")]      # (0x201: 64-deep loop without the atomic residual epilogue - debug library)
-if any(v > 1 for v in variants):
+if any(v > 2 for v in variants):
     from tools._dbglib import use_debug_library
     use_debug_library()
 
@@ -71,6 +72,19 @@ for name, m, n, k in SHAPES:
         med = t[len(t) // 2]
         err = float((outs[v][:512].float() - ref).abs().max() / ref.abs().max())
         line += f"  v{v} {med:7.1f} us (min {t[0]:7.1f}) {2.0 * m * n * k / med / 1e6:7.1f} TF/s err {err:.1e}"
+    if os.environ.get("BLAS"):
+        tb = []
+        for r in range(rounds):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.matmul(a, w.t(), out=o16)
+            s.record()
+            for _ in range(3):
+                torch.matmul(a, w.t(), out=o16)
+            e.record()
+            torch.cuda.synchronize()
+            tb.append(s.elapsed_time(e) / 3 * 1e3)
+        tb.sort()
+        line += f"  blas {tb[len(tb) // 2]:7.1f} us {2.0 * m * n * k / tb[len(tb) // 2] / 1e6:7.1f} TF/s"
     if len(variants) > 1:
         line += f"  bitwise-equal {torch.equal(outs[variants[0]], outs[variants[1]])}"
     print(line, flush=True)
