@@ -1647,7 +1647,7 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
 template <typename T, int NPL, int EPI>
 static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
   if (NPL == 1 && (g_gemm_variant & 0xff) == 2 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0))
-    return launch_t256w<T, EPI>(A, lda, W, ldw, M, N, K, e, tile_group_m(N >= 2560 ? 8 : 2), st);
+    return launch_t256w<T, EPI>(A, lda, W, ldw, M, N, K, e, tile_group_m(N >= 2560 ? 8 : 2) | (g_gemm_variant & 0xf500), st);
   if (NPL == 1 && (g_gemm_variant & 0xff) == 1 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0))
     return launch_t256q<T, EPI>(A, lda, W, ldw, M, N, K, e, st);
   constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768 + 8 * 512) + 8 * 2048;      // ring + 2 KiB slab per wave (+ row tables): 148 / 160 KiB

@@ -22,12 +22,15 @@
 // regions.  Epilogue: epilogue_wave (gemm_shared.h) on the two 128 x 64 halves of the wave's block.
 // LDS: [A buf0 | A buf1 | W buf0 | W buf1] x 32 KiB (dynamic LDS of a kernel without static LDS starts at 0: buffers toggle by XOR 32 KiB),
 // then a 2 KiB slab and a 512 B row table per wave.
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "gemm_shared.h"
 
 namespace la {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // an operand fragment as a plain register tuple ("v" constraint)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // an operand fragment as a plain register tuple ("v" constraint)
 
 __device__ __forceinline__ u32x4 lds_read16(unsigned addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)addr);
@@ -65,34 +68,230 @@ __device__ __forceinline__ void acc_zero(f32x16& c) {
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(c) : "v"(z));
 }
 
+#ifdef LA_DEBUG
+constexpr int LA_W4_NSTAMP = 128;
+__device__ unsigned long long g_w4_stamps[4 * LA_W4_NSTAMP];      // [wave][i] = s_memtime << 8 | tag (workgroup 0 of the last stamped launch)
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 // ---- the k-tile body is written out slot by slot: one MFMA, at most one memory instruction, pinned by sched_barrier(0) ----------------
 #define LA_W4_SB __builtin_amdgcn_sched_barrier(0);
+// ABL (measurement builds only, results wrong by construction): 1 no LDS-DMA pieces in the loop, 2 no fragment reads, 4 no waits / barriers,
+// 8 no MFMAs
 #define LA_W4_MF(IB, ii, j, PAR, KS)                                                                                            \
-  MfmaA<T>::go(acc[(j) >> 1][(IB) + (ii)][(j) & 1], af[PAR][ii], wf[KS][j]); \
+  if constexpr (!(ABL & 8)) MfmaA<T>::go(acc[(j) >> 1][(IB) + (ii)][(j) & 1], af[PAR][ii], wf[KS][j]); \
   LA_W4_SB
-#define LA_W4_RW(KS, j) wf[KS][j] = lds_read16(waddr[KS] + (j) * 4096); LA_W4_SB
-#define LA_W4_RA(PAR, ii, i, KS) af[PAR][ii] = lds_read16(aaddr[KS] + (i) * 4096); LA_W4_SB
-#define LA_W4_PA0(src, i, bo) dma_piece<(i) * 1024>(src, soA0[i], dstA + (bo)); LA_W4_SB
-#define LA_W4_PA1(src, i, bo) dma_piece<8192 + (i) * 1024>(src, soA1[i], dstA + (bo)); LA_W4_SB
-#define LA_W4_PW(src, i, bo) dma_piece<(i) * 1024>(src, soW[i], dstW + (bo)); LA_W4_SB
+#define LA_W4_RW(KS, j) if constexpr (!(ABL & 2)) wf[KS][j] = lds_read16(waddr[KS] + (j) * 4096); LA_W4_SB
+#define LA_W4_RA(PAR, ii, i, KS) if constexpr (!(ABL & 2)) af[PAR][ii] = lds_read16(aaddr[KS] + (i) * 4096); LA_W4_SB
+#define LA_W4_PA0(src, i, bo) if constexpr (!(ABL & 1)) dma_piece<(i) * 1024>(src, soA0[i], dstA + (bo)); LA_W4_SB
+#define LA_W4_PA1(src, i, bo) if constexpr (!(ABL & 1)) dma_piece<8192 + (i) * 1024>(src, soA1[i], dstA + (bo)); LA_W4_SB
+#define LA_W4_PW(src, i, bo) if constexpr (!(ABL & 1)) dma_piece<(i) * 1024>(src, soW[i], dstW + (bo)); LA_W4_SB
+#define LA_W4_QA0(src, i, bo) dma_piece<(i) * 1024>(src, soA0[i], dstA + (bo));      // (prologue: never ablated)
+#define LA_W4_QA1(src, i, bo) dma_piece<8192 + (i) * 1024>(src, soA1[i], dstA + (bo));
+#define LA_W4_QW(src, i, bo) dma_piece<(i) * 1024>(src, soW[i], dstW + (bo));
+#define LA_W4_WAIT(N) if constexpr (!(ABL & 4)) { if (seam) wait_vm_lgkm0<((N) + SEAM > 63 ? 63 : (N) + SEAM)>(); else wait_vm_lgkm0<(N)>(); }
+#define LA_W4_BAR if constexpr (!(ABL & 4)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
+// ---- epilogue of an interior tile without row / column maps: the wave's 128 x 128 block through an 8 KiB fp32 slab ---------------------
+// One wave per SIMD issues one instruction every ~4-5 cycles and nothing else fills its slots: the epilogue costs what its instruction
+// COUNT costs.  epilogue_wave (a 2 KiB 16-bit slab: bias, convert, 32-bit LDS stores, unzip) is ~1500 instructions per wave here;
+// this form is ~450: the accumulators leave the AGPRs as 16-byte LDS stores of 4 rows x 1 column (no AGPR -> VGPR copy), come back as
+// 4 rows x 8 columns per lane, and bias / activation / conversion run on row segments that go out as whole 128-byte lines.
+//   round (i, jp) = rows [32 i, +32) x columns [64 jp, +64): 2 accumulator tiles = 8 KiB
+//   slab unit (16 B) of row quad q (0..7), column c (0..63) at q * 64 + (c & ~7) + ((c & 7) ^ ((c >> 3) ^ q) & 7)
+//   write: lane (fr, fh), register quad g of tile jj -> q = 2 g + fh, c = 32 jj + fr          (8 stores per round, conflict-free)
+//   read:  lane -> q = lane >> 3, column group cg = lane & 7: columns 8 cg + t, t = 0..7      (8 loads per round, conflict-free)
+// The LDS queue of a wave is in order: round r + 1 is written right behind the read instructions of round r.
 template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], int row0, int col0, const LaGemmEpilogue& e, int lane) {
+  const int fr = lane & 31, fh = lane >> 5;
+  const int rq = lane >> 3, cg = lane & 7;
+  const unsigned sl = lds_addr_of(slab);
+  // write address of (g = 0, jj = 0): + g * 2048 (two quads) + jj * 512 (four column groups)
+  const unsigned waddr = sl + (unsigned)((fh * 64 + (fr & ~7) + ((fr & 7) ^ (((fr >> 3) ^ fh) & 7))) << 4);
+  // (the swizzle term of tile jj, quad 2 g + fh: ((4 jj + (fr >> 3)) ^ (2 g + fh)) & 7 = ((fr >> 3) ^ fh) ^ (4 jj) ^ (2 g): XOR constants)
+  unsigned raddr[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) raddr[t] = sl + (unsigned)((rq * 64 + cg * 8 + (t ^ ((cg ^ rq) & 7))) << 4);
+  float bias[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    const float4 b0 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b1 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bias[jp][0] = b0.x; bias[jp][1] = b0.y; bias[jp][2] = b0.z; bias[jp][3] = b0.w;
+    bias[jp][4] = b1.x; bias[jp][5] = b1.y; bias[jp][6] = b1.z; bias[jp][7] = b1.w;
+  }
+  T* out16 = reinterpret_cast<T*>(e.out16);
+  auto wr = [&](auto ic, auto jpc) {
+    constexpr int i = decltype(ic)::value, jp = decltype(jpc)::value;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[jp][i][jj][4 * g], acc[jp][i][jj][4 * g + 1], acc[jp][i][jj][4 * g + 2], acc[jp][i][jj][4 * g + 3]};
+        // XOR constants of the swizzle: units (4 jj) ^ (2 g) inside the 8-unit group -> byte offset ((4 jj ^ 2 g) & 7) * 16
+        const unsigned a = (waddr ^ (unsigned)((((4 * jj) ^ (2 * g)) & 7) << 4)) + (unsigned)(g * 2048 + jj * 512);
+        *reinterpret_cast<__attribute__((address_space(3))) f32x4*>((uintptr_t)a) = v;
+      }
+  };
+  f32x4 rd0[8];
+  auto rd = [&](f32x4 (&r)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((uintptr_t)raddr[t]);
+  };
+  // rows 4 rq + s of block i, columns col0 + 64 jp + 8 cg + t
+  // EPI 3: the residual rows of round (i, jp) - requested RING rounds ahead of their use (HBM round trips, nothing else to hide them)
+  auto ldres = [&](int i, int jp, float4 (&res)[4][2]) {
+    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        res[s_][h] = e.res ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2]) {
+    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+    if (EPI == 3) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        float4 o0, o1;
+        o0.x = r[0][s_] + bias[jp][0] + res[s_][0].x; o0.y = r[1][s_] + bias[jp][1] + res[s_][0].y;
+        o0.z = r[2][s_] + bias[jp][2] + res[s_][0].z; o0.w = r[3][s_] + bias[jp][3] + res[s_][0].w;
+        o1.x = r[4][s_] + bias[jp][4] + res[s_][1].x; o1.y = r[5][s_] + bias[jp][5] + res[s_][1].y;
+        o1.z = r[6][s_] + bias[jp][6] + res[s_][1].z; o1.w = r[7][s_] + bias[jp][7] + res[s_][1].w;
+        float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
+        *reinterpret_cast<float4*>(op) = o0;
+        *reinterpret_cast<float4*>(op + 4) = o1;
+        if (out16) {
+          uint4 pk;
+          pk.x = pack2<T>(o0.x, o0.y); pk.y = pack2<T>(o0.z, o0.w); pk.z = pack2<T>(o1.x, o1.y); pk.w = pack2<T>(o1.z, o1.w);
+          *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
+        }
+      }
+    } else {
+      // bias (+ GELU) on row pairs (s, s + 1) of one column: adjacent registers = one packed-fp32 operand
+      f32x2 v[8][2];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]} + f32x2{bias[jp][t], bias[jp][t]};
+          if (EPI == 2) v[t][sp] = gelu_erf_pk(v[t][sp]);
+        }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        uint4 pk;
+        pk.x = pack2<T>(v[0][s_ >> 1][s_ & 1], v[1][s_ >> 1][s_ & 1]);
+        pk.y = pack2<T>(v[2][s_ >> 1][s_ & 1], v[3][s_ >> 1][s_ & 1]);
+        pk.z = pack2<T>(v[4][s_ >> 1][s_ & 1], v[5][s_ >> 1][s_ & 1]);
+        pk.w = pack2<T>(v[6][s_ >> 1][s_ & 1], v[7][s_ >> 1][s_ & 1]);
+        *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  // rounds r = 2 i + jp.  ONE fragment set: the wave must not spill here - a reload is a VMEM load behind the round's stores, i.e. an
+  // s_waitcnt vmcnt(0) that drains them (and the LDS-DMA pieces of the next tile) once per round
+  float4 res0[4][2], res1[4][2];
+  if (EPI == 3) {
+    ldres(0, 0, res0);
+    ldres(0, 1, res1);
+  }
+  wr(I0{}, I0{});
+  rd(rd0);
+  wr(I0{}, I1{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(0, 0, rd0, res0);
+  if (EPI == 3) ldres(1, 0, res0);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I1{}, I0{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(0, 1, rd0, res1);
+  if (EPI == 3) ldres(1, 1, res1);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I1{}, I1{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(1, 0, rd0, res0);
+  if (EPI == 3) ldres(2, 0, res0);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I2{}, I0{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(1, 1, rd0, res1);
+  if (EPI == 3) ldres(2, 1, res1);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I2{}, I1{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(2, 0, rd0, res0);
+  if (EPI == 3) ldres(3, 0, res0);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I3{}, I0{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(2, 1, rd0, res1);
+  if (EPI == 3) ldres(3, 1, res1);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  wr(I3{}, I1{});
+  __builtin_amdgcn_sched_barrier(0);
+  out(3, 0, rd0, res0);
+  __builtin_amdgcn_sched_barrier(0);
+  rd(rd0);
+  __builtin_amdgcn_sched_barrier(0);
+  out(3, 1, rd0, res1);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// DIRECT: every tile is interior and unmapped (M % 256 == 0, no output row map, no V^T columns): epilogue_w4 only.  The two epilogues
+// do not share a kernel: with both behind a branch hipcc spills 128 accumulator registers to scratch in front of it.
+template <typename T, int EPI, int ABL, bool DIRECT>
 __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Wt, int ldw, int M, int N,
-                                                             int K, LaGemmEpilogue e, int gm) {
+                                                             int K, LaGemmEpilogue e, int gm, int stg) {
   constexpr int BK_ = 64;
   constexpr unsigned REG = 32768;                     // one operand of one k-tile
   constexpr int SEAM = (EPI == 3) ? 47 : 32;          // epilogue stores per wave that the first two waits of a tile may leave outstanding
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef LA_DEBUG
+  const bool stamps = ((gm >> 10) & 1) && blockIdx.x == 0;      // seam timeline of workgroup 0 (la_dbg_w4_stamps)
+  int stamp_i = 0;
+  auto stamp = [&](int tag) {
+    if (stamps && stamp_i < LA_W4_NSTAMP) {
+      unsigned long long t_;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+      if (lane == 0) g_w4_stamps[wave * LA_W4_NSTAMP + stamp_i] = (t_ << 8) | (unsigned)tag;
+      ++stamp_i;
+    }
+  };
+#else
+  auto stamp = [](int) {};
+#endif
+#ifdef LA_DEBUG
+  const bool nostore = (gm >> 8) & 1;                 // measurement ablation (la_gemm_variant bit 8): the epilogue's global stores are skipped
+#else
+  constexpr bool nostore = false;
+#endif
+  gm &= 0xff;
+  // start stagger: workgroup class (blockIdx / 8) % P waits class x D x 1024 cycles, so that the epilogues (HBM bursts with the matrix
+  // pipe idle) of different CUs fall into each other's main loops instead of all at once
+  if ((stg >> 16) > 1) {
+    const int cls = (blockIdx.x >> 3) % (stg >> 16);
+    for (int i = 0; i < cls * (stg & 0xffff); ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles
+  }
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
   const int ntn = N / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
   const unsigned lds0 = lds_addr_of(smem);
-  char* slab = smem + 4 * REG + wave * 2048;
+  char* slab = smem + 4 * REG + wave * 8192;          // 8 KiB per wave: epilogue_w4's fp32 slab, or epilogue_wave's 2 KiB slab + row table
   unsigned* rtab = nullptr;
-  if (EPI == 1 && e.map != LA_MAP_NONE) rtab = reinterpret_cast<unsigned*>(smem + 4 * REG + 4 * 2048 + wave * 512);
+  if (EPI == 1 && e.map != LA_MAP_NONE) rtab = reinterpret_cast<unsigned*>(slab + 2048);
 
   // ---- per-lane fragment addresses: row * 128 + swizzled chunk; + i * 4096 selects the 32-row fragment -----------------------------
   unsigned aaddr[4], waddr[4];
@@ -147,15 +346,15 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
   {
     const T* sa = A + a_koff(e, 0);
     const T* sw = Wt;
-    LA_W4_PA0(sa, 0, 0) LA_W4_PA0(sa, 1, 0) LA_W4_PA0(sa, 2, 0) LA_W4_PA0(sa, 3, 0)
-    LA_W4_PW(sw, 0, 0) LA_W4_PW(sw, 1, 0) LA_W4_PW(sw, 2, 0) LA_W4_PW(sw, 3, 0)
-    LA_W4_PW(sw, 4, 0) LA_W4_PW(sw, 5, 0) LA_W4_PW(sw, 6, 0) LA_W4_PW(sw, 7, 0)
-    LA_W4_PA1(sa, 0, 0) LA_W4_PA1(sa, 1, 0) LA_W4_PA1(sa, 2, 0) LA_W4_PA1(sa, 3, 0)
+    LA_W4_QA0(sa, 0, 0) LA_W4_QA0(sa, 1, 0) LA_W4_QA0(sa, 2, 0) LA_W4_QA0(sa, 3, 0)
+    LA_W4_QW(sw, 0, 0) LA_W4_QW(sw, 1, 0) LA_W4_QW(sw, 2, 0) LA_W4_QW(sw, 3, 0)
+    LA_W4_QW(sw, 4, 0) LA_W4_QW(sw, 5, 0) LA_W4_QW(sw, 6, 0) LA_W4_QW(sw, 7, 0)
+    LA_W4_QA1(sa, 0, 0) LA_W4_QA1(sa, 1, 0) LA_W4_QA1(sa, 2, 0) LA_W4_QA1(sa, 3, 0)
     sa = A + a_koff(e, BK_);
     sw = Wt + BK_;
-    LA_W4_PA0(sa, 0, REG) LA_W4_PA0(sa, 1, REG) LA_W4_PA0(sa, 2, REG) LA_W4_PA0(sa, 3, REG)
-    LA_W4_PW(sw, 0, REG) LA_W4_PW(sw, 1, REG) LA_W4_PW(sw, 2, REG) LA_W4_PW(sw, 3, REG)
-    LA_W4_PW(sw, 4, REG) LA_W4_PW(sw, 5, REG) LA_W4_PW(sw, 6, REG) LA_W4_PW(sw, 7, REG)
+    LA_W4_QA0(sa, 0, REG) LA_W4_QA0(sa, 1, REG) LA_W4_QA0(sa, 2, REG) LA_W4_QA0(sa, 3, REG)
+    LA_W4_QW(sw, 0, REG) LA_W4_QW(sw, 1, REG) LA_W4_QW(sw, 2, REG) LA_W4_QW(sw, 3, REG)
+    LA_W4_QW(sw, 4, REG) LA_W4_QW(sw, 5, REG) LA_W4_QW(sw, 6, REG) LA_W4_QW(sw, 7, REG)
   }
   wait_vm_lgkm0<16>();                                // A0W(0) landed (A1(0), A0W(1) may still be out)
   __builtin_amdgcn_s_barrier();
@@ -168,6 +367,7 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
   waddr[0] ^= REG;
 
   int kt = 0;
+  stamp(1);
   bool seam = false;                                  // the previous k-tile ended in an epilogue whose stores are exactly counted
   for (;;) {
     const int next = tile + gridDim.x;
@@ -195,11 +395,9 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     LA_W4_MF(0, 0, 0, 0, 2) LA_W4_RW(3, 0) LA_W4_MF(0, 0, 1, 0, 2) LA_W4_RW(3, 1) LA_W4_MF(0, 0, 2, 0, 2) LA_W4_RW(3, 2)
     LA_W4_MF(0, 0, 3, 0, 2) LA_W4_RW(3, 3) LA_W4_MF(0, 1, 0, 0, 2) LA_W4_RA(1, 0, 0, 3) LA_W4_MF(0, 1, 1, 0, 2) LA_W4_RA(1, 1, 1, 3)
     LA_W4_MF(0, 1, 2, 0, 2) LA_W4_PA1(sa1, 3, bo1)
-    if (seam) wait_vm_lgkm0<(16 + SEAM > 63 ? 63 : 16 + SEAM)>();
-    else wait_vm_lgkm0<16>();
+    LA_W4_WAIT(16)
     LA_W4_SB LA_W4_MF(0, 1, 3, 0, 2)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    LA_W4_BAR
     LA_W4_SB
     if (prelast && more) plan(next, m0n, n0n, soA0, soA1n, soW);         // A0W(t+2) is the next tile's first k-tile
     const T* saw = A + a_koff(e, kAW * BK_);
@@ -224,11 +422,9 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     LA_W4_MF(2, 0, 0, 0, 2) LA_W4_RA(1, 0, 2, 3) LA_W4_MF(2, 0, 1, 0, 2) LA_W4_RA(1, 1, 3, 3) LA_W4_MF(2, 0, 2, 0, 2) LA_W4_PW(sww, 4, bofs)
     LA_W4_MF(2, 0, 3, 0, 2) LA_W4_MF(2, 1, 0, 0, 2) LA_W4_PW(sww, 5, bofs) LA_W4_MF(2, 1, 1, 0, 2) LA_W4_MF(2, 1, 2, 0, 2)
     LA_W4_PW(sww, 6, bofs)
-    if (seam) wait_vm_lgkm0<(15 + SEAM > 63 ? 63 : 15 + SEAM)>();
-    else wait_vm_lgkm0<15>();
+    LA_W4_WAIT(15)
     LA_W4_SB LA_W4_MF(2, 1, 3, 0, 2)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    LA_W4_BAR
     LA_W4_SB
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) aaddr[ks] ^= REG;
@@ -242,20 +438,31 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     ++kt;
     if (!last) continue;
     // ================= seam: epilogue of the finished tile =========================================================================
+    stamp(2);                                          // main loop done
     asm volatile("s_nop 15" ::: "memory");             // the last MFMA's result -> first VALU reader (12 wait states; see MfmaA)
     // (the empty asm re-defines the accumulators in the AGPR class HERE: without it hipcc hoists the 128 AGPR -> VGPR copies the epilogue
     // needs into the k-tile loop, which then spills its DMA offsets - every reload is an s_waitcnt vmcnt(0) in front of a piece)
+    const bool vtile = !DIRECT && EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[0][i][j]));
-    epilogue_wave<T, EPI>(slab, rtab, acc[0], m0 + wr * 128, n0 + wc * 128, n0, M, e, lane);
+    if constexpr (DIRECT) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[1][i][j]));
-    epilogue_wave<T, EPI>(slab, rtab, acc[1], m0 + wr * 128, n0 + wc * 128 + 64, n0, M, e, lane);
-    seam = (m0 + 256 <= M) && !(EPI == 1 && e.vt != nullptr && n0 >= e.vt_col0);
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[1][i][j]));
+      epilogue_w4<T, EPI>(slab, acc, m0 + wr * 128, n0 + wc * 128, e, lane);
+    } else {
+      epilogue_wave<T, EPI>(slab, rtab, acc[0], m0 + wr * 128, n0 + wc * 128, n0, M, e, lane, nostore);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[1][i][j]));
+      epilogue_wave<T, EPI>(slab, rtab, acc[1], m0 + wr * 128, n0 + wc * 128 + 64, n0, M, e, lane, nostore);
+    }
+    seam = (m0 + 256 <= M) && !vtile;
+    stamp(3);                                          // epilogue issued
     if (!more) break;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -268,15 +475,24 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     n0 = n0n;
     tile = next;
     kt = 0;
+    if constexpr (DIRECT) {
+      // the first fragments of the next tile again (block 7 already read them): 24 registers that are then dead across the epilogue,
+      // which needs them for its residual ring - six LDS reads per tile against spills in the epilogue
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[0][j] = lds_read16((waddr[0] ^ REG) + j * 4096);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) af[0][ii] = lds_read16((aaddr[0]) + ii * 4096);
+    }
+    stamp(1);                                          // accumulators cleared: the next tile's main loop starts
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's surplus requests must have landed before the LDS is released
 }
 
-template <typename T, int EPI>
-void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st) {
-  constexpr int LDS = 4 * 32768 + 4 * 2048 + 4 * 512;      // two k-tile buffers + 2 KiB slab per wave + row tables: 138 KiB
+template <typename T, int EPI, int ABL, bool DIRECT>
+static void launch_t256w_abl(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st) {
+  constexpr int LDS = 4 * 32768 + 4 * 8192;      // two k-tile buffers + 8 KiB slab per wave: all 160 KiB
   static unsigned long long attr_mask = 0;
-  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256w_kernel<T, EPI>), LDS, attr_mask);
+  ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256w_kernel<T, EPI, ABL, DIRECT>), LDS, attr_mask);
   static int ncu = 0;
   if (ncu == 0) {
     int dev = 0;
@@ -285,9 +501,37 @@ void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, 
     if (ncu <= 0) ncu = 256;
   }
   const int ntiles = ((M + 255) / 256) * (N / 256);
-  const int grid = ntiles < ncu ? ntiles : ncu;
-  hipLaunchKernelGGL((gemm_t256w_kernel<T, EPI>), dim3(grid), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
-                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, gm);
+  int grid = ntiles < ncu ? ntiles : ncu;
+  int stg = 0;
+  static const char* genv = la_dbg_env("LA_W4_GRID");        // debugging: workgroups launched
+  if (genv && atoi(genv) > 0 && atoi(genv) < grid) grid = atoi(genv);
+  static const char* senv = la_dbg_env("LA_W4_STAGGER");     // debugging: "P,D" = P start classes, D x 1024 cycles apart
+  if (senv) stg = (atoi(senv) << 16) | (strchr(senv, ',') ? atoi(strchr(senv, ',') + 1) : 0);
+  hipLaunchKernelGGL((gemm_t256w_kernel<T, EPI, ABL, DIRECT>), dim3(grid), dim3(256), LDS, st, reinterpret_cast<const T*>(A), lda,
+                     reinterpret_cast<const T*>(W), ldw, M, N, K, e, gm & 0x5ff, stg);
+}
+
+template <typename T, int EPI>
+void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st) {
+#ifdef LA_DEBUG
+  // la_gemm_variant bits 12-15 = ABL (EPI 1 only)
+  if (EPI == 1) {
+    switch ((gm >> 12) & 15) {
+      case 1: return launch_t256w_abl<T, 1, 1, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 2: return launch_t256w_abl<T, 1, 2, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 3: return launch_t256w_abl<T, 1, 3, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 4: return launch_t256w_abl<T, 1, 4, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 5: return launch_t256w_abl<T, 1, 5, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 7: return launch_t256w_abl<T, 1, 7, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 8: return launch_t256w_abl<T, 1, 8, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      case 14: return launch_t256w_abl<T, 1, 14, false>(A, lda, W, ldw, M, N, K, e, gm, st);
+      default: break;
+    }
+  }
+#endif
+  const bool direct = (M % 256) == 0 && e.map == LA_MAP_NONE && !e.vt && !((gm >> 8) & 1);
+  if (direct) launch_t256w_abl<T, EPI, 0, true>(A, lda, W, ldw, M, N, K, e, gm, st);
+  else launch_t256w_abl<T, EPI, 0, false>(A, lda, W, ldw, M, N, K, e, gm, st);
 }
 
 #define LA_W4_INST(T, EPI) \
@@ -296,3 +540,15 @@ LA_W4_INST(f16_t, 1) LA_W4_INST(f16_t, 2) LA_W4_INST(f16_t, 3)
 LA_W4_INST(bf16_t, 1) LA_W4_INST(bf16_t, 2) LA_W4_INST(bf16_t, 3)
 
 }  // namespace la
+
+#ifdef LA_DEBUG
+// seam timeline of workgroup 0 of the last gemm_t256w launch made with la_gemm_variant bit 10: 4 waves x 128 entries of (s_memtime << 8 | tag)
+extern "C" int la_dbg_w4_stamps(unsigned long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(la::g_w4_stamps), sizeof(unsigned long long) * 4 * la::LA_W4_NSTAMP);
+}
+extern "C" int la_dbg_w4_stamps_clear() {
+  static unsigned long long z[4 * la::LA_W4_NSTAMP] = {0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(la::g_w4_stamps), z, sizeof(z));
+}
+#endif

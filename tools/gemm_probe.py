@@ -2,11 +2,17 @@
 """Run a few launches of one GEMM / attention shape (for rocprofv3 --pmc passes)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+VARIANT = int(os.environ.get("LA_VARIANT", "-1"), 0)      # la_gemm_variant (values above 2: the measurement library)
+if VARIANT > 2:
+    from tools._dbglib import use_debug_library
+    use_debug_library()
 import torch
 from labelanything_amd import _lib as L
+if VARIANT >= 0:
+    L.gemm_variant(VARIANT)
 which = sys.argv[1] if len(sys.argv) > 1 else "lin2"
 dt = torch.float16
-shapes = {"lin2": (131072, 768, 3072), "lin1": (131072, 3072, 768), "qk": (131072, 1536, 768), "v2": (131072, 768, 768)}   # 32-image encoder batch
+shapes = {"lin2": (131072, 768, 3072), "lin1": (131072, 3072, 768), "qk": (131072, 1536, 768), "v2": (131072, 768, 768), "cube": (8192, 8192, 8192)}   # 32-image encoder batch
 if which in shapes:
     m, n, k = shapes[which]
     a = torch.randn(m, k, device="cuda").to(dt)
