@@ -66,7 +66,8 @@ EXPORTS = [
 
 
 def gemm_variant(v: int = -1) -> int:
-    """la_gemm_variant: select the main loop of the large encoder GEMMs (1 = BK 64 quadrant phases, 0 = BK 32); returns the previous one."""
+    """la_gemm_variant: select the main loop of the large encoder GEMMs - 2 (default): four waves x 512 registers (gemm_w4.hip),
+    1: eight waves in quadrant phases, 0: the BK 32 kernel.  All are bit-identical.  Returns the previous value."""
     return int(lib().la_gemm_variant(int(v)))
 
 

@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_t256p_kernel(const T* __restrict_
 // from the accumulator layout (a register is 32 consecutive columns of one row per half wave: 128-byte segments).  ksplit > 1 cuts the
 // K range into chunks of kchunk (a multiple of 64) that run as independent tiles: dW[N, K] = dY^T X over 10^4 - 10^5 tokens has
 // 9 - 36 output tiles only, the chunks are what fills the chip.
-static int g_gemm_variant = 1;       // 1: BK = 64 quadrant-phase kernel where it applies, 0: the BK = 32 persistent kernel everywhere
+static int g_gemm_variant = 2;       // see launch_t256p (0: the BK = 32 persistent kernel everywhere)
 
 #ifdef LA_DEBUG
 constexpr int LA_DBG_NSTAMP = 64;
@@ -1646,10 +1646,13 @@ static void launch_t256q(const void* A, int lda, const void* W, int ldw, int M, 
 
 template <typename T, int NPL, int EPI>
 static void launch_t256p(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, hipStream_t st) {
-  if (NPL == 1 && (g_gemm_variant & 0xff) == 2 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0))
-    return launch_t256w<T, EPI>(A, lda, W, ldw, M, N, K, e, tile_group_m(N >= 2560 ? 8 : 2) | (g_gemm_variant & 0xf500), st);
-  if (NPL == 1 && (g_gemm_variant & 0xff) == 1 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0))
-    return launch_t256q<T, EPI>(A, lda, W, ldw, M, N, K, e, st);
+  // main loop of the single-plane 64-deep shapes (la_gemm_variant): 2 (default) = the four-wave kernel (gemm_w4.hip; its own epilogue on
+  // interior unmapped tiles - lin1, lin2, proj - and epilogue_wave elsewhere: measured ahead of the eight-wave kernel on every encoder
+  // shape, profiles/r05_notes.md), 1 = the eight-wave quadrant-phase kernel
+  const int var = g_gemm_variant & 0xff;
+  const bool k64 = NPL == 1 && (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0);
+  if (k64 && var == 2) return launch_t256w<T, EPI>(A, lda, W, ldw, M, N, K, e, tile_group_m(N >= 2560 ? 8 : 2) | (g_gemm_variant & 0xf500), st);
+  if (k64 && var >= 1) return launch_t256q<T, EPI>(A, lda, W, ldw, M, N, K, e, st);
   constexpr int LDS = ((NPL == 2) ? 3 * 49152 : 4 * 32768 + 8 * 512) + 8 * 2048;      // ring + 2 KiB slab per wave (+ row tables): 148 / 160 KiB
   static unsigned long long attr_mask = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256p_kernel<T, NPL, EPI>), LDS, attr_mask);
@@ -2094,7 +2097,7 @@ extern "C" int la_gemm_variant(int v) {
 #ifdef LA_DEBUG
   if (v >= 0) la::g_gemm_variant = v;       // bit 8 no stores, bit 10 seam stamps (la_dbg_gemm_stamps), bit 23 no epilogue
 #else
-  if (v >= 0 && v <= 2) la::g_gemm_variant = v;       // the product library only knows the three bit-identical main loops
+  if (v >= 0 && v <= 2) la::g_gemm_variant = v;       // the product library only knows the bit-identical main loops
 #endif
   return prev;
 }

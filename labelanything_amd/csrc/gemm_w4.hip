@@ -90,7 +90,11 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile(
 #define LA_W4_QA0(src, i, bo) dma_piece<(i) * 1024>(src, soA0[i], dstA + (bo));      // (prologue: never ablated)
 #define LA_W4_QA1(src, i, bo) dma_piece<8192 + (i) * 1024>(src, soA1[i], dstA + (bo));
 #define LA_W4_QW(src, i, bo) dma_piece<(i) * 1024>(src, soW[i], dstW + (bo));
-#define LA_W4_WAIT(N) if constexpr (!(ABL & 4)) { if (seam) wait_vm_lgkm0<((N) + SEAM > 63 ? 63 : (N) + SEAM)>(); else wait_vm_lgkm0<(N)>(); }
+#define LA_W4_WAIT(N)                                                             \
+  if constexpr (!(ABL & 4)) {                                                     \
+    if (seam) wait_vm_lgkm0<((N) + SEAM > 63 ? 63 : (N) + SEAM)>();               \
+    else wait_vm_lgkm0<(N)>();                                                    \
+  }
 #define LA_W4_BAR if constexpr (!(ABL & 4)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
 // ---- epilogue of an interior tile without row / column maps: the wave's 128 x 128 block through an 8 KiB fp32 slab ---------------------
@@ -170,15 +174,40 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         }
       }
     } else {
-      // bias (+ GELU) on row pairs (s, s + 1) of one column: adjacent registers = one packed-fp32 operand
+      // bias (+ GELU) on row pairs (s, s + 1) of one column: adjacent registers = one packed-fp32 operand.  The GELU runs on eight
+      // pairs IN LOCKSTEP (same arithmetic as gelu_erf_pk, one polynomial step of all eight at a time): written pair by pair, hipcc
+      // emits each 13-deep dependent chain on its own with an s_nop behind every packed instruction - a third of the epilogue's
+      // instructions - and a wave that is alone on its SIMD has nothing else to put there.
       f32x2 v[8][2];
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]} + f32x2{bias[jp][t], bias[jp][t]};
-          if (EPI == 2) v[t][sp] = gelu_erf_pk(v[t][sp]);
+        for (int t = 0; t < 8; ++t) v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]} + f32x2{bias[jp][t], bias[jp][t]};
+        if (EPI == 2) {
+          f32x2 u[8], tt[8], p[8];
+#define LA_W4_STEP(expr)                          \
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) { \
+    expr;                                         \
+  }                                               \
+  __builtin_amdgcn_sched_barrier(0);
+          LA_W4_STEP(u[t] = v[t][sp] * 0.70710678118654752440f)
+          LA_W4_STEP(u[t].x = __builtin_amdgcn_fmed3f(u[t].x, -3.0f, 3.0f); u[t].y = __builtin_amdgcn_fmed3f(u[t].y, -3.0f, 3.0f))
+          LA_W4_STEP(tt[t] = u[t] * u[t])
+          LA_W4_STEP(p[t] = tt[t] * -3.753537037e-09f + 1.995845196e-07f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -4.771217391e-06f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 6.851813669e-05f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -6.692335592e-04f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 4.784903489e-03f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -2.622046508e-02f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.123065501e-01f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -3.759292066e-01f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.128377676e+00f)
+          LA_W4_STEP(tt[t] = v[t][sp] * 0.5f)
+          LA_W4_STEP(p[t] = p[t] * u[t])
+          LA_W4_STEP(v[t][sp] = tt[t] * p[t] + tt[t])
+#undef LA_W4_STEP
         }
+      }
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         uint4 pk;

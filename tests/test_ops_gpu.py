@@ -601,6 +601,84 @@ def test_gemm_persistent_256x256_epilogues(L, dt, planes):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_four_wave_kernel_bit_identical(L, dt):
+    """gemm_t256w (four waves x 512 registers, la_gemm_variant 2: the default) against gemm_t256q (variant 1): the same
+    MFMA order over k and the same epilogue arithmetic, so every output must be equal bit for bit - on interior tiles (its own
+    epilogue through the fp32 slab), on row-edge tiles, behind a window-gather A map, with V^T columns and with the scatter map."""
+    k = 768
+
+    def run_all(fn, outs):
+        res = {}
+        for v in (1, 2):
+            L.gemm_variant(v)
+            for o in outs:
+                o.fill_(3.0)
+            fn()
+            torch.cuda.synchronize()
+            res[v] = [o.clone() for o in outs]
+        L.gemm_variant(2)
+        for a_, b_ in zip(res[1], res[2]):
+            assert torch.equal(a_, b_)
+        return res[1]
+
+    try:
+        for m in (256 * 44, 256 * 43 + 100):
+            # GELU -> 16 bit (lin1)
+            n = 3072
+            a = rnd(m, k, seed=161).to(dt)
+            w = (rnd(n, k, seed=162) / math.sqrt(k)).to(dt)
+            bias = rnd(n, seed=163)
+            out = torch.zeros(m, n, device="cuda", dtype=dt)
+            got = run_all(lambda: L.gemm(a, w, bias=bias, out16=out, act=L.ACT_GELU), [out])[0]
+            assert rel_err(got, F.gelu(a.float() @ w.float().t() + bias)) < TOL16[dt]
+            # plain -> 16 bit (q | k)
+            n = 1536
+            w = (rnd(n, k, seed=164) / math.sqrt(k)).to(dt)
+            bias = rnd(n, seed=165)
+            out = torch.zeros(m, n, device="cuda", dtype=dt)
+            got = run_all(lambda: L.gemm(a, w, bias=bias, out16=out), [out])[0]
+            assert rel_err(got, a.float() @ w.float().t() + bias) < TOL16[dt]
+        # fp32 residual in place (+ 16-bit copy), long K (lin2), then behind a window-gather A map (proj of a window block)
+        m, n, kk = 256 * 40, 3072, 3072
+        a = rnd(m, kk, seed=166).to(dt)
+        w = (rnd(n, kk, seed=167) / math.sqrt(kk)).to(dt)
+        bias = rnd(n, seed=168)
+        res0 = rnd(m, n, seed=169)
+        res = res0.clone()
+        o16 = torch.zeros(m, n, device="cuda", dtype=dt)
+
+        def lin2():
+            res.copy_(res0)
+            L.gemm(a, w, bias=bias, res=res, out32=res, out16=o16)
+        got = run_all(lin2, [res, o16])
+        assert rel_err(got[0], a.float() @ w.float().t() + bias + res0) < 1e-5
+        b, h, ws = 4, 64, 14
+        nwy = -(-h // ws)
+        rows, arows = b * h * h, b * nwy * nwy * ws * ws
+        n = 3072
+        ao = rnd(arows, k, seed=170).to(dt)
+        w = (rnd(n, k, seed=171) / math.sqrt(k)).to(dt)
+        bias = rnd(n, seed=172)
+        res0 = rnd(rows, n, seed=173)
+        res = res0.clone()
+
+        def proj():
+            res.copy_(res0)
+            L.gemm(ao, w, bias=bias, res=res, out32=res, M=rows, amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, h, h))
+        run_all(proj, [res])
+        # q | k | v with V^T columns (global attention form)
+        e, heads, t, nb = 768, 12, 4096, 4
+        x = rnd(nb * t, k, seed=174).to(dt)
+        w = (rnd(3 * e, k, seed=175) / math.sqrt(k)).to(dt)
+        bias = rnd(3 * e, seed=176) * 0.1
+        qkv = torch.zeros(nb * t, 3 * e, device="cuda", dtype=dt)
+        vt = torch.zeros(nb * heads, 64, t, device="cuda", dtype=dt)
+        run_all(lambda: L.gemm(x, w, bias=bias, out16=qkv, vt=vt, vt_col0=2 * e, vt_T=t, vt_Tpad=t, vt_hd=64, vt_heads=heads), [qkv, vt])
+    finally:
+        L.gemm_variant(2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_gemm_persistent_window_scatter(L, dt):
     """qkv of a SAM window block from IMAGE-order tokens (LA_MAP_WINDOW_PART as output map in gemm_t256p_kernel): the q / k rows land in
     window order, V^T in 16-slot order, the padded positions are never written (they hold the bias, filled once by the host) - as one

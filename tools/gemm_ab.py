@@ -88,4 +88,4 @@ for name, m, n, k in SHAPES:
     if len(variants) > 1:
         line += f"  bitwise-equal {torch.equal(outs[variants[0]], outs[variants[1]])}"
     print(line, flush=True)
-L.gemm_variant(1)
+L.gemm_variant(2)

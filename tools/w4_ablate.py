@@ -35,4 +35,4 @@ for name, m, n, k in SHAPES:
         t = sorted(times[v])
         med = t[len(t) // 2]
         print(f"{name:6s} {m}x{n}x{k} abl {v:2d}: {med:8.1f} us (min {t[0]:8.1f})  {2.0 * m * n * k / med / 1e6:7.1f} TF/s-equivalent", flush=True)
-L.gemm_variant(1)
+L.gemm_variant(2)

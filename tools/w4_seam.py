@@ -51,7 +51,7 @@ for name, kind, m, n, k in SHAPES:
     L.gemm_variant(2 | 0x400 | VB)
     run()
     lib.la_dbg_w4_stamps(C.cast(buf, C.c_void_p))
-    L.gemm_variant(1)
+    L.gemm_variant(2)
     grid = min(256, int(os.environ.get("LA_W4_GRID", 256)))
     tiles_per_cu = math.ceil(math.ceil(m / 256) * (n // 256) / grid)
     print(f"== {name}: {m}x{n}x{k} {kind}  {us:.1f} us unstamped = {us / tiles_per_cu:.2f} us per tile ({tiles_per_cu} tiles per workgroup, {k // 64} k-tiles,"
