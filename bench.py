@@ -288,16 +288,29 @@ def main():
     if a.episodes is None:
         a.episodes = WORKLOADS[a.workload]["default_episodes"]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("LA_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the 1-GPU smoke test
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on the loopback address) - the
+        # reference starts its ranks the same way (`accelerate launch --multi_gpu`, /root/reference/slurm/launch_run_exe:5)
+        if a.gpus > ndev and backend != "gloo":
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {ndev} GPU(s) visible (LA_BENCH_BACKEND=gloo shares one GPU between the ranks: smoke tests only)")
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29517")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` or under torch.distributed.run "
+                         f"with --nproc-per-node N")
     torch.cuda.set_device(local % ndev)              # one rank per GPU on a real node; wraps only in the 1-GPU smoke test
     dev = torch.device("cuda", local % ndev)
     dist = None
-    backend = os.environ.get("LA_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the 1-GPU smoke test
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -124,6 +124,32 @@ def test_bench_runs_as_two_ranks_and_prints_one_line(tmp_path):
     assert abs(rec["value"] - 2 / (rec["ms_per_step"] * 1e-3)) <= 1e-2 * rec["value"]
 
 
+def test_bench_launches_its_own_ranks(tmp_path):
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run around it, WORLD_SIZE unset): bench.py starts the two ranks itself,
+    refuses more ranks than GPUs unless LA_BENCH_BACKEND=gloo, and refuses a WORLD_SIZE that contradicts --gpus."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    args = ["--steps", "2", "--warmup", "1", "--episodes", "1", "--workload", "cfg1", "--no-cpu-baseline", "--no-eager-baseline"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_episodes_per_step"] == 2
+    import torch
+    if torch.cuda.device_count() < 2:
+        env_nccl = dict(env)
+        env_nccl.pop("LA_BENCH_BACKEND")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, cwd=ROOT, env=env_nccl,
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode != 0 and "GPU(s) visible" in (res.stderr + res.stdout)
+    env_bad = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, cwd=ROOT, env=env_bad, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)
+
+
 # ---- bucketed gradient all-reduce (VERDICT r3 item 6) ---------------------------------------------------------------------------------
 def _enc_trainer(buckets: int):
     from labelanything_amd.models import Lam

@@ -33,8 +33,8 @@ timeout 600 python bench.py --workload cfg3_train --train-encoder --no-cpu-basel
 timeout 600 python bench.py --workload cfg2_train --train-encoder --no-cpu-baseline > $OUT/${R}_bench_cfg2_train_encoder.json 2>> $OUT/bench.stderr
 timeout 600 python bench.py --workload cfg5 --attn-fp8 --no-cpu-baseline > $OUT/${R}_bench_cfg5_fp8.json 2>> $OUT/bench.stderr
 # On an 8-GPU node (the driver's SCALE run; nothing here can launch it): one rank per GPU over RCCL, bucketed gradient all-reduce
-#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 8 --workload cfg3_train --train-encoder
-#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 8
+#   python bench.py --gpus 8 --workload cfg3_train --train-encoder        (bench.py starts its own ranks when WORLD_SIZE is unset)
+#   python bench.py --gpus 8
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise patch,v,proj,neck > $OUT/${R}_bench_cfg2_weight_planes.json 2>> $OUT/bench.stderr
 timeout 600 python tools/attn_fp8_report.py > $OUT/${R}_attn_fp8.log 2>&1
 timeout 600 python tools/gemm_ab.py > $OUT/${R}_gemm_ab.log 2>&1
