@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LA_HIP_LIB") or os.path.join(_HERE, "libla_hip.so")      # (override: same-box A/B of two builds, tools/)
+LIB_PATH = os.path.join(_HERE, "libla_hip.so")      # the one product library; no environment switch (tools/_dbglib.py re-points this
+#                                                     attribute for measurement builds before the first call)
 
 LA_F16, LA_BF16, LA_F32, LA_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       const size_t rc = (size_t)min(row, M - 1);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[u][i] = dy[rc * ldy + cn[i]] * (vr * vn[i]);
-        b[u][i] = x[rc * ldx + ck[i]] * (vr * vk[i]);
+        const float ta = dy[rc * ldy + cn[i]], tb = x[rc * ldx + ck[i]];
+        a[u][i] = (vr * vn[i] != 0.f) ? ta : 0.f;      // (select: 0 * Inf would poison the masked lanes)
+        b[u][i] = (vr * vk[i] != 0.f) ? tb : 0.f;
       }
     }
   };
@@ -186,9 +187,15 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const float* __restric
       const float vr = mrow + row < mend ? 1.f : 0.f;
       float a[SN], b[SK];
 #pragma unroll
-      for (int i = 0; i < SN; ++i) a[i] = sdy[row * TN + (wn * SN + i) * 32 + fr] * (vr * vn[i]);
+      for (int i = 0; i < SN; ++i) {      // select, not multiply: an Inf / NaN in a clamped row must not reach the masked lanes (0 * Inf)
+        const float t = sdy[row * TN + (wn * SN + i) * 32 + fr];
+        a[i] = (vr * vn[i] != 0.f) ? t : 0.f;
+      }
 #pragma unroll
-      for (int j = 0; j < SK; ++j) b[j] = sx[row * TK + (wk * SK + j) * 32 + fr] * vk[j];
+      for (int j = 0; j < SK; ++j) {
+        const float t = sx[row * TK + (wk * SK + j) * 32 + fr];
+        b[j] = (vk[j] != 0.f) ? t : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < SN; ++i) {
         if (do_db) bsum[i] += a[i];

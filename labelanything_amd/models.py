@@ -102,6 +102,8 @@ class Lam(nn.Module):
             self.neck = None
         self._engine: Optional[LamEngine] = None
         self._engine_key = None
+        self.weights_version = 0         # bumped by every out-of-band weight change (load_state_dict, _apply, invalidate): consumers that
+                                         # keep their own packed copies (train_encoder's private engine, W^T caches) compare it
         self._plist = None
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = False          # replay the device-side launch sequence from a HIP graph (per input plan)
@@ -139,6 +141,7 @@ class Lam(nn.Module):
         self._engine = None
         self._engine_key = None
         self._graphs = {}
+        self.weights_version += 1
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         sd = dict(state_dict)
@@ -150,11 +153,13 @@ class Lam(nn.Module):
         sd = _hf5_to_hf4(sd)
         out = super().load_state_dict(sd, strict=strict)
         self._engine = None
+        self.weights_version += 1
         return out
 
     def _apply(self, fn, *a, **kw):
         self._engine = None
         self._plist = None
+        self.weights_version = getattr(self, "weights_version", 0) + 1
         return super()._apply(fn, *a, **kw)
 
     # -- reference API --------------------------------------------------------------------------------
@@ -495,6 +500,7 @@ def init_pretrained_weights(lam: Lam, weights: Dict[str, torch.Tensor]) -> None:
                 take(src, dst)
     nn.Module.load_state_dict(lam, picked, strict=False)
     lam._engine = None
+    lam.weights_version += 1
 
 
 def build_lam(encoder: Optional[str] = "vit_b", seed: Optional[int] = None, compute_dtype=torch.float16,
@@ -589,6 +595,7 @@ class ImageEncoder(nn.Module):
         missing = [k[len("image_encoder."):] for k in res.missing_keys if k.startswith("image_encoder.")]
         unexpected = [k[len("image_encoder."):] for k in res.unexpected_keys]
         self.lam._engine = None
+        self.lam.weights_version += 1
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for ImageEncoder: missing {missing[:5]}, unexpected {unexpected[:5]}")
         return res

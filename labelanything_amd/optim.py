@@ -84,6 +84,8 @@ class FlatAdamW:
             if reducer is None:
                 sum_over_ranks(self.grad)
         if reducer is None or not all_reduce:
+            if reducer is not None:              # collectives already launched by a synchronising micro-step still write into self.grad
+                reducer.finish_all()
             bucket_bounds = [(0, self.grad.numel())]
             reducer = None
         else:

@@ -138,6 +138,16 @@ class BucketedGradReducer:
         if i in self._work and self._work[i][1] is not None:
             self._stale.add(i)
 
+    def stale_flags(self) -> List[bool]:
+        """Per bucket: its staged copy was invalidated on THIS rank (exchanged over the ranks by the caller, then ``set_stale``)."""
+        return [i in self._stale for i in range(len(self.bounds))]
+
+    def set_stale(self, flags: Sequence[bool]) -> None:
+        """The collective decision: a staged bucket that went stale on ANY rank is re-reduced in place on EVERY rank."""
+        for i, f in enumerate(flags):
+            if f and i in self._work and self._work[i][1] is not None:
+                self._stale.add(i)
+
     def finish(self, i: int) -> None:
         """Bucket i holds the sum over the ranks when the caller's stream reaches this point."""
         if i in self._done:

@@ -415,9 +415,17 @@ class LamTrainer:
         lam = self.lam
         if any(self.reducer.launched(i) for i in range(len(self.reducer.bounds))):
             raise RuntimeError("forward_backward after a synchronising micro-step: call apply_update() first")
+        prev_wt, prev_sink = A.WT, A.SINK
         A.WT = self._wt              # the W^T copies of this trainer's weights (flat-buffer views: stable addresses), one launch per step
         self._wt.invalidate()
         A.SINK = self._sink          # nn.Linear / LayerNorm parameter gradients are added straight into the flat gradient buffer
+        try:
+            return self._forward_backward(batch, gt, loss_normalizer, sync)
+        finally:                     # a backward through these operators outside this call must not see this trainer's W^T copies / sink
+            A.WT, A.SINK = prev_wt, prev_sink
+
+    def _forward_backward(self, batch, gt, loss_normalizer, sync):
+        lam = self.lam
         with torch.cuda.device(lam._device()):
             with torch.no_grad():
                 inp, _ = lam._prepare(batch, with_post=False, eng=self.engine)
@@ -472,8 +480,14 @@ class LamTrainer:
         and another none: the flags are OR-ed over the ranks first (DDP ``find_unused_parameters=True`` all-reduces its
         used-parameter bitmap the same way, experiment/run.py:123) - otherwise replicas of ``point_embeddings.*``,
         ``not_a_point_embed``, ``mask_downscaling.*`` ... would step on some ranks only and drift apart."""
-        active = any_over_ranks(self._touched, device=self.lam._device())
+        # one exchange: used-parameter flags + "my staged bucket went stale" flags.  The stale decision must be COLLECTIVE: a rank that
+        # re-reduces a bucket in place issues an all-reduce its peers would never issue (mis-paired collectives / a hang)
+        nb = len(self.reducer.bounds)
+        flags = any_over_ranks(list(self._touched) + self.reducer.stale_flags(), device=self.lam._device())
+        active = flags[:len(self._touched)]
+        self.reducer.set_stale(flags[len(self._touched):len(self._touched) + nb])
         self.opt.step(active=active, reducer=self.reducer)
+        self._wt.invalidate()
         self.reducer.begin()
         self._touched = [False] * len(self.names)
         # packed / converted weight copies of the inference engine are stale now; the trainer's own engine only serves the frozen

@@ -63,6 +63,7 @@ class HfEncoderGraph:
         self.precise = tuple(lam.precise) if precise is None else tuple(precise)
         self._eng = None
         self._eng_stale = True
+        self._seen_version = lam.weights_version      # staleness is driven by the MODEL (load_state_dict / _apply / invalidate bump it)
         self.before_backward = None        # optional callback at the head of ``backward`` (LamTrainer: launch the decoder-side gradient bucket)
         self.w: Dict[str, Tensor] = {k: v for k, v in lam.state_dict(keep_vars=True).items() if k.startswith("image_encoder.")}
         grads = {k: v for k, v in grads.items() if self.owns(k)}
@@ -93,9 +94,18 @@ class HfEncoderGraph:
         self._eng_stale = True
         self._wt_cache.clear()
 
+    def _sync_version(self) -> None:
+        """A checkpoint restore, best-weights reload, EMA swap or manual edit + ``lam.invalidate()`` reaches this graph through the
+        model's ``weights_version``: the private engine and the W^T copies are dropped exactly like after an optimizer step."""
+        v = self.lam.weights_version
+        if v != self._seen_version:
+            self._seen_version = v
+            self.weights_changed()
+
     def engine(self):
         from .engine import LamEngine
         lam = self.lam
+        self._sync_version()
         if self._eng is None:
             self._eng = LamEngine(lam.cfg, lam.state_dict(), lam._device(), lam.compute_dtype, lam.decoder_dtype, self.precise, scope="encoder")
         elif self._eng_stale:
@@ -171,6 +181,7 @@ class HfEncoderGraph:
     def _wt16(self, key: str, wt_fn, dt) -> Tensor:
         """nn.Linear weight [N, K] fp32 -> W^T [K, N] 16-bit: the 'weight' of the data-gradient GEMM dX = dY . W.  One copy per
         optimizer step (``weights_changed`` drops them): a loss-scale retry or a gradient-accumulation micro-step re-uses it."""
+        self._sync_version()
         out = self._wt_cache.get(key)
         if out is None or out.dtype != dt:
             wt = wt_fn()

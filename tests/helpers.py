@@ -28,6 +28,24 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a[fin] - b[fin]).abs().max() / b[fin].abs().max().clamp_min(1e-20))
 
 
+def pct_rel_err(a: torch.Tensor, b: torch.Tensor, q: float = 0.999, floor: float = 0.01) -> float:
+    """q-quantile of the ELEMENT-WISE relative error |a-b| / |b| over the finite entries with |b| > floor * max|b|: the second figure next
+    to the max-norm ``rel_err`` - a regression in the small-magnitude logits cannot hide under the global maximum here."""
+    a = a.detach().float().cpu().flatten()
+    b = b.detach().float().cpu().flatten()
+    fin = torch.isfinite(b) & torch.isfinite(a)
+    a, b = a[fin], b[fin]
+    if b.numel() == 0:
+        return 0.0
+    keep = b.abs() > floor * b.abs().max()
+    if not keep.any():
+        return 0.0
+    r = ((a[keep] - b[keep]).abs() / b[keep].abs()).double()
+    if r.numel() > 4_000_000:                      # torch.quantile's input limit: an even stride keeps the distribution
+        r = r[:: (r.numel() + 3_999_999) // 4_000_000]
+    return float(torch.quantile(r, q))
+
+
 def argmax_disagreement(logits: torch.Tensor, ref_argmax: torch.Tensor, ref_logits: torch.Tensor = None,
                         margin_rel: float = 0.0):
     """(#pixels whose argmax differs, #of those where the reference top-2 margin exceeds margin_rel*max|logit|)."""

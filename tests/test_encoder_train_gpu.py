@@ -364,3 +364,41 @@ def test_gelu_forward_and_backward_on_16bit_rows_match_torch(dt, n):
         post = torch.empty_like(pre)
         L.gelu_fwd16(pre, post)
         assert torch.equal(post, y.detach().to(dt).cuda()) or float((post.double().cpu() - y.detach()).abs().max()) <= 2.0 ** -8 * float(y.abs().max())
+
+
+def test_checkpoint_restore_between_steps_reaches_the_trainers_encoder():
+    """the trainer's private encoder engine and its W^T copies follow the MODEL's ``weights_version`` - a checkpoint restore
+    (``load_state_dict``) or a manual edit + ``lam.invalidate()`` after the first training step must reach the next training forward AND
+    backward exactly as a fresh trainer on the same weights sees them."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from tests.cases import CASES
+    from tests.test_train_gpu import make_gt
+    case = CASES["hf_tiny_1w1s_masks"]
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    lam = Lam(case["cfg"], seed=3).cuda()
+    tr = LamTrainer(lam, lr=1e-2, weight_decay=0.0, train_encoder=True)
+    tr.step(batch, gt)                                                   # engine packed, W^T copies cached, weights moved
+    other = Lam(case["cfg"], seed=7).cuda()
+    lam.load_state_dict(other.state_dict())                              # "restore a checkpoint"
+    tr.zero_grad()
+    la = float(tr.forward_backward(batch, gt)["loss"])
+    ga = tr.opt.grad.clone()
+    fresh = LamTrainer(other, lr=1e-2, weight_decay=0.0, train_encoder=True)
+    fresh.zero_grad()
+    lb = float(fresh.forward_backward(batch, gt)["loss"])
+    gb = fresh.opt.grad
+    assert la == lb, (la, lb)                                            # the forward ran on the restored weights (deterministic kernels)
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())  # ... and so did the backward (fp32 atomics: order only)
+    # manual edit + invalidate(): the documented out-of-band path
+    with torch.no_grad():
+        for p in lam.parameters():
+            p.mul_(1.01)
+    lam.invalidate()
+    tr.zero_grad()
+    lc = float(tr.forward_backward(batch, gt)["loss"])
+    assert lc != la
+    import labelanything_amd.autograd_ops as A
+    assert A.WT is not tr._wt and A.SINK is not tr._sink                 # the trainer's W^T copies / gradient sink do not outlive the call

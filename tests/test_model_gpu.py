@@ -8,7 +8,7 @@ is held to 1e-3 on EVERY stage below (measured 4.7e-4 .. 7.0e-4 on the worst sta
 Argmax: the fused argmax must equal torch.argmax of the logits the same launch wrote, bit for bit, and it must equal the
 REFERENCE's argmax at every pixel whose reference top-2 margin exceeds 2 x the logit tolerance (two logits that each move
 by <= tol can only swap when they were closer than 2 tol).  Random-weight models put 0.02-0.3 % of the pixels inside that
-band; their number is printed and held, per case, to 4 x the count measured on MI355X (profiles/r03_parity.log).  Context:
+band; their number is printed and held, per case, to 2 x the count measured on MI355X (profiles/r04_parity.log).  Context:
 "bit-exact" against the reference is unreachable for ANY re-ordered arithmetic on these random-weight fixtures - the fp32 CPU
 oracle itself differs from the reference on 27 of the 1 048 576 pixels of cfg2 (tests/golden/cfg2_sam_b_1024_1w1s.json,
 "argmax_ties") - so the assertion is: zero flips outside the band, and no more flips inside it than the measured error explains.
@@ -22,7 +22,7 @@ import torch
 from labelanything_amd.episodes import make_episode
 from labelanything_amd.models import Lam
 from tests.cases import CASES
-from tests.helpers import argmax_disagreement, load_golden, reference_logits, rel_err
+from tests.helpers import argmax_disagreement, load_golden, pct_rel_err, reference_logits, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ TOL = {
     torch.bfloat16: dict(emb=6.5e-3, cls=1.5e-3, low=9e-3, logits=8e-3),
 }
 # share of the pixels measured to flip inside the near-tie band, per case (profiles/r03_parity.log, default numerics); the test allows
-# 4 x that count (box-to-box the last bits of the token-mean sums are identical, so the spread is what a kernel change may move),
+# 2 x that count (box-to-box the last bits of the token-mean sums are identical, so the spread is what a kernel change may move),
 # and at least ARGMAX_FLOOR pixels for the decoder-only cases that measure zero
 ARGMAX_MEASURED = {
     torch.float16: {"sam_tiny_2w2s_all_prompts": 8.7e-4, "hf_tiny_1w1s_masks": 2.1e-4, "novit_d256_2w3s": 0.0, "novit_d512_neck_1w2s": 0.0,
@@ -40,6 +40,8 @@ ARGMAX_MEASURED = {
                      "cfg2_sam_b_1024_1w1s": 1.23e-2, "cfg1_mae_b_480_1w1s": 6.2e-3},
 }
 ARGMAX_FLOOR = 4
+# 99.9th percentile of |a - b| / |b| over the logits with |b| > 1 % of max|b| (tests/helpers.pct_rel_err)
+PCT_TOL = {torch.float16: 5e-2, torch.bfloat16: 3e-1}
 ARGMAX_MARGIN = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # 2 x the logit tolerance
 
 
@@ -67,15 +69,19 @@ def test_episode_matches_reference_fixture(name, dt):
     assert rel_err(seg, gold["low_res_logits"]) <= tol["low"]
     ref_logits = reference_logits(case, gold, batch)            # stored, or oracle post-processing of the stored low-res logits
     assert rel_err(out["logits"], ref_logits) <= tol["logits"]
+    # second figure: 99.9th percentile of the element-wise relative error over the logits above 1 % of the maximum
+    p999 = pct_rel_err(out["logits"], ref_logits)
+    print(f"[p99.9 {name} {dt}] element-wise relative error of the logits with |ref| > 1 % of max: {p999:.3e} (bound {PCT_TOL[dt]:.1e})")
+    assert p999 <= PCT_TOL[dt]
     am = out["argmax"].cpu()
     # the index kernel itself is exact: fused argmax == argmax of the logits it wrote
     assert torch.equal(out["logits"].argmax(dim=1).cpu(), am)
     # and equals the reference's argmax wherever the reference's top-2 margin is outside the tolerance band
     n_diff, n_real = argmax_disagreement(out["logits"], gold["argmax"].long(), ref_logits, margin_rel=ARGMAX_MARGIN[dt])
     assert n_real == 0, f"{n_real} of {n_diff} differing pixels have a reference margin above the tolerance band"
-    allowed = max(ARGMAX_FLOOR, int(4 * ARGMAX_MEASURED[dt][name] * am.numel()))
+    allowed = max(ARGMAX_FLOOR, int(2 * ARGMAX_MEASURED[dt][name] * am.numel()))
     print(f"[argmax {name} {dt}] {n_diff} of {am.numel()} pixels flip inside the near-tie band (allowed {allowed}), {n_real} outside it")
-    assert n_diff <= allowed, f"{n_diff} of {am.numel()} pixels flip inside the near-tie band (allowed {allowed} = 4 x measured)"
+    assert n_diff <= allowed, f"{n_diff} of {am.numel()} pixels flip inside the near-tie band (allowed {allowed} = 2 x measured)"
     assert out["logits"].shape == (b, gold["class_embeddings"].shape[1], *gold["argmax"].shape[-2:])
 
 

@@ -169,7 +169,26 @@ def _bucket_worker(rank, world, port, q):
     except RuntimeError:
         refused = True
     red3.finish_all()
-    q.put((rank, same_a, same_b, same_c, refused))
+    # (d) ADVICE r4: the staged bucket goes stale on rank 0 ONLY - the decision is exchanged (as LamTrainer.apply_update does, in the
+    # used-parameter exchange) and BOTH ranks re-reduce in place: same collective sequence on every rank, sum of the final gradients
+    from labelanything_amd.parallel import any_over_ranks
+    grad4 = base.clone()
+    red4 = BucketedGradReducer(grad4, [(0, 8192), (8192, 10_000)])
+    red4.begin()
+    red4.launch(1, staged=True)
+    if rank == 0:
+        grad4[9000:9100] += 2.5
+        red4.invalidate(1)
+    red4.launch(0)
+    local = red4.stale_flags()
+    red4.set_stale(any_over_ranks(local))
+    red4.finish_all()
+    expect4 = base.clone()
+    if rank == 0:
+        expect4[9000:9100] += 2.5
+    sum_over_ranks(expect4)
+    same_d = torch.equal(grad4, expect4) and local == [False, rank == 0] and red4.stale_flags() == [False, True]
+    q.put((rank, same_a, same_b, same_c and same_d, refused))
     dist.destroy_process_group()
 
 

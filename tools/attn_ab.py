@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """Kernel time of the encoder attention forms on the model's shapes (global rel-pos 64 x 64, plain T = 901 / 4096, 14 x 14 windows), with a
-checksum of the output: run once per library build (LA_HIP_LIB=...) for a same-box A/B (tools/attn_ab.sh)."""
+checksum of the output: run once per library build (LA_TOOLS_LIB=...) for a same-box A/B (tools/attn_ab.sh)."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from tools._dbglib import use_env_library
+use_env_library()
 from labelanything_amd import _lib as L
 
 

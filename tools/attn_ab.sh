@@ -2,7 +2,7 @@
 # tools/attn_ab.sh <out dir> <lib a> <lib b> ...: the builds alternate three times; best time per shape and build
 OUT=$1; shift
 mkdir -p $OUT
-for i in 1 2 3; do for lib in "$@"; do LA_HIP_LIB=$PWD/$lib python tools/attn_ab.py 2>/dev/null > $OUT/$(basename $lib .so).$i.log; done; done
+for i in 1 2 3; do for lib in "$@"; do LA_TOOLS_LIB=$PWD/$lib python tools/attn_ab.py 2>/dev/null > $OUT/$(basename $lib .so).$i.log; done; done
 python - $OUT "$@" <<'PY'
 import glob, os, re, sys
 out, libs = sys.argv[1], [os.path.basename(l)[:-3] for l in sys.argv[2:]]

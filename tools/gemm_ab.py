@@ -16,6 +16,9 @@ variants = [int(v, 0) for v in os.environ.get("VARIANTS", "0,1").split(",")]    
 if any(v > 2 for v in variants):
     from tools._dbglib import use_debug_library
     use_debug_library()
+else:
+    from tools._dbglib import use_env_library
+    use_env_library()
 
 
 import torch  # noqa: E402

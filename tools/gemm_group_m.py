@@ -3,6 +3,8 @@ the row panels per tile group).  Under `rocprofv3 --pmc FETCH_SIZE` the same scr
 import sys
 import torch
 sys.path.insert(0, "/root/repo")
+from tools._dbglib import use_env_library
+use_env_library()
 from labelanything_amd import _lib as L
 m = 393216
 for name, n, k, kw in (("lin1", 3072, 768, dict(act=L.ACT_GELU)), ("qkv", 2304, 768, {}), ("lin2", 768, 3072, {}), ("proj", 768, 768, {})):

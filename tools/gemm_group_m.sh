@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export LA_HIP_LIB=$R/labelanything_amd/libla_hip_dbg.so
+export LA_TOOLS_LIB=$R/labelanything_amd/libla_hip_dbg.so
 for g in 1 2 4 8 16; do
   echo "== LA_GEMM_GROUP_M=$g"
   LA_GEMM_GROUP_M=$g python $R/tools/gemm_group_m.py 2>/dev/null | grep x

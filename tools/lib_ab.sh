@@ -6,7 +6,7 @@ mkdir -p $OUT
 for i in 1 2 3; do
   for lib in "$@"; do
     n=$(basename $lib .so)
-    LA_HIP_LIB=$PWD/$lib VARIANTS=${VARIANTS:-1} ROUNDS=${ROUNDS:-9} python tools/gemm_ab.py 2>/dev/null > $OUT/$n.$i.log
+    LA_TOOLS_LIB=$PWD/$lib VARIANTS=${VARIANTS:-1} ROUNDS=${ROUNDS:-9} python tools/gemm_ab.py 2>/dev/null > $OUT/$n.$i.log
   done
 done
 python - $OUT "$@" <<'PY'

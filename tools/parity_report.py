@@ -7,7 +7,7 @@ from labelanything_amd.models import Lam
 from labelanything_amd.episodes import make_episode
 from tests.cases import CASES
 from labelanything_amd.engine import PRECISE_DEFAULT, PRECISE_FULL, PRECISE_WIDE, PRECISE_WIDE_PLANES
-from tests.helpers import load_golden, rel_err, reference_logits, argmax_disagreement
+from tests.helpers import load_golden, rel_err, reference_logits, argmax_disagreement, pct_rel_err
 
 
 def main():
@@ -63,6 +63,7 @@ def main():
             errs["fused_argmax_vs_torch"] = int((am2 != am).sum())
             ref_logits = reference_logits(case, gold, batch)
             errs["logits_vs_ref"] = rel_err(out["logits"], ref_logits)
+            errs["logits_p99.9_elementwise"] = pct_rel_err(out["logits"], ref_logits)
             n_diff, n_real = argmax_disagreement(out["logits"], ref_am, ref_logits, margin_rel=2e-3)
             errs["argmax_diff_outside_2e-3_margin"] = n_real
             ptag = "auto=" + "+".join(lam.precise) if precise == "auto" else ("none" if not precise else "+".join(precise))
