@@ -96,6 +96,11 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile(
     else wait_vm_lgkm0<(N)>();                                                    \
   }
 #define LA_W4_BAR if constexpr (!(ABL & 4)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+// how many memory instructions share one MFMA -> MFMA gap (tools/gen/w4_ktile.py; measured in profiles/r05_notes.md)
+#ifndef LA_W4_GROUP
+#define LA_W4_GROUP 1
+#endif
+#include "gemm_w4_ktile.inc"
 
 // ---- epilogue of an interior tile without row / column maps: the wave's 128 x 128 block through an 8 KiB fp32 slab ---------------------
 // One wave per SIMD issues one instruction every ~4-5 cycles and nothing else fills its slots: the epilogue costs what its instruction
@@ -411,56 +416,27 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     }
     const T* sa1 = A + a_koff(e, kA1 * BK_);
     const unsigned bo1 = bofs ^ REG;                  // A1(t+1) lands in the OTHER buffer
-    // ================= H1 ==========================================================================================================
-    // block 0 (ks 0): reads of ks 1, A1 pieces 0, 1
-    LA_W4_MF(0, 0, 0, 0, 0) LA_W4_RW(1, 0) LA_W4_MF(0, 0, 1, 0, 0) LA_W4_RW(1, 1) LA_W4_MF(0, 0, 2, 0, 0) LA_W4_RW(1, 2)
-    LA_W4_MF(0, 0, 3, 0, 0) LA_W4_RW(1, 3) LA_W4_MF(0, 1, 0, 0, 0) LA_W4_RA(1, 0, 0, 1) LA_W4_MF(0, 1, 1, 0, 0) LA_W4_RA(1, 1, 1, 1)
-    LA_W4_MF(0, 1, 2, 0, 0) LA_W4_PA1(sa1, 0, bo1) LA_W4_MF(0, 1, 3, 0, 0) LA_W4_PA1(sa1, 1, bo1)
-    // block 1 (ks 1): reads of ks 2, A1 piece 2
-    LA_W4_MF(0, 0, 0, 1, 1) LA_W4_RW(2, 0) LA_W4_MF(0, 0, 1, 1, 1) LA_W4_RW(2, 1) LA_W4_MF(0, 0, 2, 1, 1) LA_W4_RW(2, 2)
-    LA_W4_MF(0, 0, 3, 1, 1) LA_W4_RW(2, 3) LA_W4_MF(0, 1, 0, 1, 1) LA_W4_RA(0, 0, 0, 2) LA_W4_MF(0, 1, 1, 1, 1) LA_W4_RA(0, 1, 1, 2)
-    LA_W4_MF(0, 1, 2, 1, 1) LA_W4_PA1(sa1, 2, bo1) LA_W4_MF(0, 1, 3, 1, 1)
-    // block 2 (ks 2): reads of ks 3 (the last H1 reads), A1 piece 3, then wait + B1
-    LA_W4_MF(0, 0, 0, 0, 2) LA_W4_RW(3, 0) LA_W4_MF(0, 0, 1, 0, 2) LA_W4_RW(3, 1) LA_W4_MF(0, 0, 2, 0, 2) LA_W4_RW(3, 2)
-    LA_W4_MF(0, 0, 3, 0, 2) LA_W4_RW(3, 3) LA_W4_MF(0, 1, 0, 0, 2) LA_W4_RA(1, 0, 0, 3) LA_W4_MF(0, 1, 1, 0, 2) LA_W4_RA(1, 1, 1, 3)
-    LA_W4_MF(0, 1, 2, 0, 2) LA_W4_PA1(sa1, 3, bo1)
-    LA_W4_WAIT(16)
-    LA_W4_SB LA_W4_MF(0, 1, 3, 0, 2)
-    LA_W4_BAR
-    LA_W4_SB
+    // ================= the k-tile: LA_W4_BLOCK_0 .. 7 (gemm_w4_ktile.inc, generated by tools/gen/w4_ktile.py) =========================
+    // H1 blocks 0-2 (ks 0-2): reads of ks + 1 in the order of their first use (A_i0, W_0 .. W_3, A_i1), the A1 pieces; block 2 ends in wait + B1
+    LA_W4_BLOCK_0
+    LA_W4_BLOCK_1
+    LA_W4_BLOCK_2
     if (prelast && more) plan(next, m0n, n0n, soA0, soA1n, soW);         // A0W(t+2) is the next tile's first k-tile
     const T* saw = A + a_koff(e, kAW * BK_);
     const T* sww = Wt + kAW * BK_;
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) waddr[ks] ^= REG;  // (their next use is H1 of the next k-tile)
     // block 3 (ks 3): reads of H2 ks 0, A0 pieces 0, 1
-    LA_W4_MF(0, 0, 0, 1, 3) LA_W4_RA(0, 0, 2, 0) LA_W4_MF(0, 0, 1, 1, 3) LA_W4_RA(0, 1, 3, 0) LA_W4_MF(0, 0, 2, 1, 3) LA_W4_PA0(saw, 0, bofs)
-    LA_W4_MF(0, 0, 3, 1, 3) LA_W4_MF(0, 1, 0, 1, 3) LA_W4_PA0(saw, 1, bofs) LA_W4_MF(0, 1, 1, 1, 3) LA_W4_MF(0, 1, 2, 1, 3)
-    LA_W4_MF(0, 1, 3, 1, 3)
+    LA_W4_BLOCK_3
     aaddr[0] ^= REG;                                  // next use: block 7, the first fragments of k-tile t+1
-    // ================= H2 ==========================================================================================================
-    // block 4 (ks 0): reads of ks 1, A0 pieces 2, 3, W piece 0
-    LA_W4_MF(2, 0, 0, 0, 0) LA_W4_RA(1, 0, 2, 1) LA_W4_MF(2, 0, 1, 0, 0) LA_W4_RA(1, 1, 3, 1) LA_W4_MF(2, 0, 2, 0, 0) LA_W4_PA0(saw, 2, bofs)
-    LA_W4_MF(2, 0, 3, 0, 0) LA_W4_MF(2, 1, 0, 0, 0) LA_W4_PA0(saw, 3, bofs) LA_W4_MF(2, 1, 1, 0, 0) LA_W4_MF(2, 1, 2, 0, 0)
-    LA_W4_PW(sww, 0, bofs) LA_W4_MF(2, 1, 3, 0, 0)
-    // block 5 (ks 1): reads of ks 2, W pieces 1, 2, 3
-    LA_W4_MF(2, 0, 0, 1, 1) LA_W4_RA(0, 0, 2, 2) LA_W4_MF(2, 0, 1, 1, 1) LA_W4_RA(0, 1, 3, 2) LA_W4_MF(2, 0, 2, 1, 1) LA_W4_PW(sww, 1, bofs)
-    LA_W4_MF(2, 0, 3, 1, 1) LA_W4_MF(2, 1, 0, 1, 1) LA_W4_PW(sww, 2, bofs) LA_W4_MF(2, 1, 1, 1, 1) LA_W4_MF(2, 1, 2, 1, 1)
-    LA_W4_PW(sww, 3, bofs) LA_W4_MF(2, 1, 3, 1, 1)
-    // block 6 (ks 2): reads of ks 3 (the last reads of this k-tile), W pieces 4, 5, 6, then wait + B2
-    LA_W4_MF(2, 0, 0, 0, 2) LA_W4_RA(1, 0, 2, 3) LA_W4_MF(2, 0, 1, 0, 2) LA_W4_RA(1, 1, 3, 3) LA_W4_MF(2, 0, 2, 0, 2) LA_W4_PW(sww, 4, bofs)
-    LA_W4_MF(2, 0, 3, 0, 2) LA_W4_MF(2, 1, 0, 0, 2) LA_W4_PW(sww, 5, bofs) LA_W4_MF(2, 1, 1, 0, 2) LA_W4_MF(2, 1, 2, 0, 2)
-    LA_W4_PW(sww, 6, bofs)
-    LA_W4_WAIT(15)
-    LA_W4_SB LA_W4_MF(2, 1, 3, 0, 2)
-    LA_W4_BAR
-    LA_W4_SB
+    // H2 blocks 4-6 (ks 0-2): reads of ks + 1 (A_2, A_3 only), A0 pieces 2, 3, W pieces 0-6; block 6 ends in wait + B2
+    LA_W4_BLOCK_4
+    LA_W4_BLOCK_5
+    LA_W4_BLOCK_6
 #pragma unroll
     for (int ks = 1; ks < 4; ++ks) aaddr[ks] ^= REG;
     // block 7 (ks 3): the first fragments of k-tile t+1 (other buffer), W piece 7
-    LA_W4_MF(2, 0, 0, 1, 3) LA_W4_RW(0, 0) LA_W4_MF(2, 0, 1, 1, 3) LA_W4_RW(0, 1) LA_W4_MF(2, 0, 2, 1, 3) LA_W4_RW(0, 2)
-    LA_W4_MF(2, 0, 3, 1, 3) LA_W4_RW(0, 3) LA_W4_MF(2, 1, 0, 1, 3) LA_W4_RA(0, 0, 0, 0) LA_W4_MF(2, 1, 1, 1, 3) LA_W4_RA(0, 1, 1, 0)
-    LA_W4_MF(2, 1, 2, 1, 3) LA_W4_PW(sww, 7, bofs) LA_W4_MF(2, 1, 3, 1, 3)
+    LA_W4_BLOCK_7
     waddr[0] ^= REG;
     bofs ^= REG;
     seam = false;

@@ -393,6 +393,7 @@ class LamTrainer:
         self.crit = loss or FocalLossDevice()
         self.engine = lam.engine()           # host-side helpers + the frozen encoder (its packed weights never change)
         self.graph = DecoderGraph(lam, self.engine)
+        self._seen_version = lam.weights_version      # out-of-band weight changes (load_state_dict, invalidate) re-derive both: _sync_version
         self.enc_graph = None
         if self.train_encoder:
             from .train_encoder import HfEncoderGraph, SamEncoderGraph
@@ -401,6 +402,17 @@ class LamTrainer:
                                        precise=self.train_precise)
             self._anchor = torch.zeros(1, device=lam._device(), requires_grad=True)
             self._enc_idx = [i for i, k in enumerate(self.names) if graph_cls.owns(k)]
+
+    def _sync_version(self) -> None:
+        """A checkpoint restore / manual edit + ``lam.invalidate()`` since the last call: everything this trainer derived from the weights
+        is rebuilt - its engine (frozen-encoder packs, host-side helpers) and the decoder graph's cached position table (from the
+        ``positional_encoding_gaussian_matrix`` buffer); the encoder graph follows ``lam.weights_version`` itself.  The trainer's own
+        optimizer steps do not count: they move neither the frozen encoder nor the buffers."""
+        if self.lam.weights_version != self._seen_version:
+            self.engine = self.lam.engine()
+            self.graph.eng = self.engine
+            self.graph._pe.clear()
+            self._seen_version = self.lam.weights_version
 
     def _on_grad(self, i: int) -> None:
         self._touched[i] = True
@@ -415,6 +427,7 @@ class LamTrainer:
         lam = self.lam
         if any(self.reducer.launched(i) for i in range(len(self.reducer.bounds))):
             raise RuntimeError("forward_backward after a synchronising micro-step: call apply_update() first")
+        self._sync_version()
         prev_wt, prev_sink = A.WT, A.SINK
         A.WT = self._wt              # the W^T copies of this trainer's weights (flat-buffer views: stable addresses), one launch per step
         self._wt.invalidate()
@@ -493,7 +506,10 @@ class LamTrainer:
         # packed / converted weight copies of the inference engine are stale now; the trainer's own engine only serves the frozen
         # encoder and host-side helpers, so nothing of it is re-packed until the model is next used for inference; a trainable
         # encoder's private engine re-packs its encoder weights (and only those) before the next forward
+        external = self.lam.weights_version != self._seen_version      # (a restore between forward_backward and here: keep it pending)
         self.lam.invalidate()
+        if not external:
+            self._seen_version = self.lam.weights_version
         if self.enc_graph is not None:
             self.enc_graph.weights_changed()
 

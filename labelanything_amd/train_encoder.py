@@ -21,7 +21,7 @@ the flat gradient buffer (non-finite results: the step is repeated with a smalle
   SAM stack         la_relpos_terms + la_attn_fwd_relpos_lse / la_attn_bwd_relpos + la_relpos_bwd (window and global attention with the
                     decomposed rel-pos bias; gradients of rel_pos_h / rel_pos_w), windows as row gathers - see SamEncoderGraph
 Scope: 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5) and SAM ViT-B / -L; rel-pos tables of the block's own grid (training through
-get_rel_pos's resampling raises).
+get_rel_pos's resampling is applied as its fixed linear map and that map's transpose).
 """
 from __future__ import annotations
 
@@ -430,6 +430,44 @@ class SamEncoderGraph(HfEncoderGraph):
             self._tbufs[key] = t
         return t
 
+    def _rel_tables(self, bp: str, gg: int):
+        """The fp32 rel-pos tables [(2 gg - 1), hd] the backward differentiates through, the buffers ``la_relpos_bwd`` accumulates their
+        gradients into, and the step that folds those into the parameters' gradient slots.
+
+        Table length == 2 gg - 1: the parameters and their slots themselves.  Otherwise ``get_rel_pos`` (image_encoder.py:321-330)
+        resamples the table with ``F.interpolate(mode="linear")`` - a fixed linear map R [(2 gg - 1), L] per (L, gg), built once by
+        pushing the identity through the same call (as ``bicubic_matrix_t`` does for the HF position table): the backward runs on
+        R . table and adds R^T . d(R . table) to the slot (exact-fp32 MFMA products, la_gemm_tn)."""
+        w, sv = self.w, self.sviews
+        tabs, dtabs, folds = [], [], []
+        for ax in ("h", "w"):
+            key = f"{bp}.attn.rel_pos_{ax}"
+            tab = w[key].detach()
+            ln, hd = tab.shape
+            if ln == 2 * gg - 1:
+                tabs.append(tab.contiguous())
+                dtabs.append(sv[key])
+                continue
+            rkey = ("relR", ln, gg)
+            r = self._tbufs.get(rkey)
+            if r is None:                            # R [(2 gg - 1), L] and R^T [L, (2 gg - 1)], constant per geometry
+                import torch.nn.functional as F
+                eye = torch.eye(ln, dtype=torch.float32).unsqueeze(0)                                  # (1, L "channels", L)
+                rt = F.interpolate(eye, size=2 * gg - 1, mode="linear")[0].contiguous().to(tab.device)   # [L, 2 gg - 1] = R^T
+                r = (rt.t().contiguous(), rt)
+                self._tbufs[rkey] = r
+            used = torch.zeros(2 * gg - 1, hd, device=tab.device)
+            L.gemm_tn(r[1], tab.contiguous(), used)                  # used = (R^T)^T tab = R . table
+            dused = torch.zeros_like(used)
+            tabs.append(used)
+            dtabs.append(dused)
+            folds.append((r[0], dused, sv[key]))
+
+        def fold():
+            for rm, du, slot in folds:
+                L.gemm_tn(rm, du, slot)                               # slot [L, hd] += R^T . d(R . table)
+        return tabs, dtabs, fold
+
     @torch.no_grad()
     def forward(self, images: Tensor) -> Tensor:
         """(Bn, 3, S, S) fp32 on the device -> the last block's state [Bn * hw, E] fp32 NHWC rows, activations kept for ``backward``."""
@@ -455,9 +493,8 @@ class SamEncoderGraph(HfEncoderGraph):
             nb, gg = (bn, g) if is_global else (bn * nw * nw, ws)
             t = gg * gg
             arows, tpad = nb * t, _ceil(t, 64)
-            for ax in ("h", "w"):
-                if w[f"{bp}.attn.rel_pos_{ax}"].shape[0] != 2 * gg - 1:
-                    raise NotImplementedError("training through resampled rel-pos tables (get_rel_pos interpolation) is not built")
+            # (rel-pos tables whose length is not 2 gg - 1 are resampled like get_rel_pos does, image_encoder.py:321-330: the engine packs
+            # the resampled 16-bit tables the forward kernels read; the backward applies the transposed map, ``_rel_tables``)
             sv = {"x_in": res, "global": is_global, "nb": nb, "g": gg, "t": t, "tpad": tpad, "arows": arows}
             x16 = torch.empty(rows, e, device=dev, dtype=dt)
             eng.ln(res, bp + ".norm1", 1e-6, out16=x16)
@@ -546,9 +583,9 @@ class SamEncoderGraph(HfEncoderGraph):
             drelh, drelw = torch.empty_like(a["relh"]), torch.empty_like(a["relw"])
             L.attn_bwd_relpos(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, a["relh"], a["relw"], drelh, drelw, nb, heads, t,
                               tpad, gg, e, c["scale"])
-            L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, w[bp + ".attn.rel_pos_h"].detach().contiguous(),
-                         w[bp + ".attn.rel_pos_w"].detach().contiguous(), sv[bp + ".attn.rel_pos_h"], sv[bp + ".attn.rel_pos_w"], nb, heads,
-                         gg, e)
+            tabs, dtabs, fold = self._rel_tables(bp, gg)
+            L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, tabs[0], tabs[1], dtabs[0], dtabs[1], nb, heads, gg, e)
+            fold()
             if not self._wgrad(dqkv16, None, a["xa"], sv[bp + ".attn.qkv.weight"], db=sv[bp + ".attn.qkv.bias"]):
                 dq32 = self._tbuf("dqkv32", arows, 3 * e, torch.float32)
                 L.cast(dqkv16, dq32)

@@ -89,10 +89,15 @@ def _sam_cfg():
     return LamConfig(encoder="sam_tiny", image_size=224, image_embed_dim=96, embed_dim=64, spatial_convs=3, custom_preprocess=False)
 
 
-def test_sam_block_stack_gradients_of_a_linear_functional_match_oracle_autograd():
+@pytest.mark.parametrize("resampled", [False, True])
+def test_sam_block_stack_gradients_of_a_linear_functional_match_oracle_autograd(resampled):
     """SamEncoderGraph alone (patch + position embedding, one padded-window block, one global block; the neck is the trainer's business):
     L = sum(R * last_block_state(images)), every owned parameter's gradient - rel-pos tables and the position embedding included -
-    against torch autograd of the CPU oracle's fp32 encoder (pinned on the reference)."""
+    against torch autograd of the CPU oracle's fp32 encoder (pinned on the reference).
+
+    resampled: the rel-pos tables of BOTH blocks have a length other than 2 G - 1 (a checkpoint from another grid): ``get_rel_pos``
+    (image_encoder.py:307-337) resamples them linearly in the forward, and the gradient reaches the stored table through the transpose
+    of that map."""
     from labelanything_amd.models import Lam
     from labelanything_amd.train_encoder import SamEncoderGraph
     from labelanything_amd.weights import init_state_dict
@@ -102,11 +107,21 @@ def test_sam_block_stack_gradients_of_a_linear_functional_match_oracle_autograd(
     g = torch.Generator().manual_seed(224)
     images = torch.randn(2, 3, 224, 224, generator=g)
     sd = init_state_dict(cfg, 33)
+    if resampled:                                    # longer tables for the window block, shorter ones for the global block
+        tg = torch.Generator().manual_seed(5)
+        for k in [k for k in sd if "rel_pos" in k]:
+            ln, hd = sd[k].shape
+            sd[k] = 0.1 * torch.randn(ln + 8 if ".blocks.0." in k else ln - 6, hd, generator=tg)
     wref = {k: (v.clone().requires_grad_(True) if k.startswith("image_encoder.") and v.is_floating_point() else v) for k, v in sd.items()}
     _, last_ref = O.sam_encoder(wref, geometry_for(cfg), images, return_last_block=True)           # (Bn, E, g, g)
     r = torch.randn(last_ref.shape, generator=g)
     (last_ref * r).sum().backward()
-    lam = Lam(cfg, seed=33).cuda()
+    lam = Lam(cfg, seed=33)
+    if resampled:
+        for k in [k for k in sd if "rel_pos" in k]:
+            mod, leaf = k.rsplit(".", 1)
+            setattr(lam.get_submodule(mod), leaf, torch.nn.Parameter(sd[k].clone()))
+    lam = lam.cuda()
     names = [k for k, _ in lam.named_parameters() if SamEncoderGraph.owns(k)]
     assert names and not any("neck" in k for k in names)
     grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}

