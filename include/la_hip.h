@@ -423,6 +423,17 @@ int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, const float* re
                    int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, float* cspart, int csH, int csW, int dt,
                    void* stream);
 
+/* la_attn_fwd / la_attn_fwd_cs WITHOUT a V^T copy: the V tiles are staged row-major from the v columns of qkv, like the K tiles, and reach
+ * the MFMA through LDS transpose reads (ds_read_b64_tr_b16) - the q | k | v GEMM keeps its plain row-major epilogue on every column
+ * (models/image_encoder.py:225-255: ``qkv = self.qkv(x)`` has no transposed copy either).  Modes: LA_ATTN_PLAIN; LA_ATTN_RELPOS with the
+ * 16-bit tables on the 64 x 64 grid; LA_ATTN_RELPOS_WIN16 (G <= 16, Tpad >= 16 G) - with imgH > 0 the windows are addressed in IMAGE
+ * order (window_partition / window_unpartition of image_encoder.py:258-304 as address arithmetic): qkv [images * imgH * imgW, 3E] and
+ * out16 [images * imgH * imgW, E] hold the image's tokens, B = images * ceil(imgH / G) * ceil(imgW / G) windows, and a window token
+ * beyond the image is ``padrow`` (16-bit [3E]: q | k | v of a pad-after-norm token = the qkv bias, image_encoder.py:160-172); its
+ * output row does not exist.  cspart (optional) as in la_attn_fwd_cs: fp32 [B * ceil(T / 128), E], padded tokens left out. */
+int la_attn_fwd_rows(const void* qkv, void* out16, const void* tabh, const void* tabw, int B, int heads, int T, int Tpad, int G, int E,
+                     float scale, int mode, float* cspart, int imgH, int imgW, const void* padrow, int dt, void* stream);
+
 /* out[g * ldo + c] = inv * sum over the chunks j of part[(g * chunks + j) * D + c], added in index order (fp32). */
 int la_colsum_fold(const float* part, int groups, int chunks, int D, float inv, float* out, int ldo, void* stream);
 

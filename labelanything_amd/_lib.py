@@ -61,7 +61,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
 
@@ -598,6 +598,25 @@ def attn_fwd_cs(qkv, vt, out16, relh, relw, b: int, heads: int, t: int, tpad: in
     _check(lib().la_attn_fwd_cs(_ptr(qkv), _ptr(vt), _ptr(out16), _ptr(relh), _ptr(relw), _ptr(tabh), _ptr(tabw), C.c_int(b), C.c_int(heads),
                                 C.c_int(t), C.c_int(tpad), C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(mode), _ptr(cspart),
                                 C.c_int(cs_h), C.c_int(cs_w), C.c_int(dt_of(qkv)), _stream()), "la_attn_fwd_cs")
+
+
+def attn_fwd_rows(qkv, out16, b: int, heads: int, t: int, tpad: int, g: int, e: int, scale: float, mode: int, tabh=None, tabw=None,
+                  cspart=None, img_hw=None, padrow=None) -> None:
+    """Attention without a V^T copy (la_attn_fwd_rows): V tiles row-major from the v columns of qkv.  img_hw = (H, W) + padrow: SAM windows
+    addressed in image order (b = images * windows per image)."""
+    _dev(qkv)
+    if qkv.dtype not in (torch.float16, torch.bfloat16) or out16.dtype != qkv.dtype or not (qkv.is_contiguous() and out16.is_contiguous()):
+        raise ValueError("attn_fwd_rows: qkv / out16 must be contiguous 16-bit tensors of one dtype")
+    if cspart is not None:
+        need = b * ((t + 127) // 128) * e
+        if cspart.dtype != torch.float32 or cspart.numel() < need:
+            raise ValueError(f"attn_fwd_rows cspart needs {need} fp32 elements")
+    ih, iw = (0, 0) if img_hw is None else img_hw
+    if padrow is not None and (padrow.dtype != qkv.dtype or padrow.numel() != 3 * e or not padrow.is_contiguous()):
+        raise ValueError("attn_fwd_rows: padrow must be a contiguous [3E] row of the qkv dtype")
+    _check(lib().la_attn_fwd_rows(_ptr(qkv), _ptr(out16), _ptr(tabh), _ptr(tabw), C.c_int(b), C.c_int(heads), C.c_int(t), C.c_int(tpad),
+                                  C.c_int(g), C.c_int(e), C.c_float(scale), C.c_int(mode), _ptr(cspart), C.c_int(ih), C.c_int(iw), _ptr(padrow),
+                                  C.c_int(dt_of(qkv)), _stream()), "la_attn_fwd_rows")
 
 
 def colsum_fold(part, groups: int, chunks: int, d: int, inv: float, out) -> None:

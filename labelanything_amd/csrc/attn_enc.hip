@@ -131,6 +131,12 @@ struct AttnArgs {
   float* lse;         // optional [B*heads, Tpad] (row stride Tpad): log2-domain log-sum-exp of every query row (la_attn_fwd_lse: the training forward)
   float* cspart;      // optional [B * ceil(T / 128), E]: column sums of the 16-bit output rows of every 128-query block (the token means of
   int csH, csW;       // the proj operand, LamEngine mean planes); WIN16 with csH x csW = the image's token grid: padded window rows left out
+  // la_attn_fwd_rows (VROW instances): vt == nullptr, V tiles are staged ROW-MAJOR from the v columns of qkv like the K tiles and reach
+  // the MFMA through ds_read_b64_tr_b16.  WIN16 with imgH > 0: q | k | v rows and the output are in IMAGE order ([images, imgH, imgW]
+  // tokens; B = images * windows per image); a window token beyond the image reads ``padrow`` ([3E]: q | k | v of a pad-after-norm
+  // token = the qkv bias) and its output row does not exist.
+  int imgH, imgW;
+  const void* padrow;
 };
 
 // MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
@@ -141,7 +147,11 @@ struct AttnArgs {
 // sub-tiles, the V^T tile two [64 dims][64 keys] sub-tiles (same 128-byte rows, same swizzle, same DMA pieces), Q has
 // 4 NH MFMA k-slices and O^T 2 NH accumulator tiles.  (Heads that are not a multiple of 64 wide - SAM ViT-H has 80 - are
 // zero-padded to the next multiple by the host when the weights are packed.)
-template <typename T, int MODE, int NH>
+// VROW: V tiles row-major [64 keys][64 dims] from the v columns of qkv (no V^T copy anywhere): 16-byte chunk c of key row r sits at slot
+// c ^ 4 ((r >> 1) & 1), and the A operand of O^T += V^T P^T - lane (d, fh): keys 8 fh .. 8 fh + 7 of dimension d - is two transpose
+// reads: in a 16-lane group lane 4 j + c fetches the 8 bytes (row k0 + j, dims D + 4 c ..), lane p receives dimension D + p of the four
+// rows (probed on the part: tools/micro/tr_probe.hip).  A 32-lane pass covers 4 rows x 64 bytes = every bank once.
+template <typename T, int MODE, int NH, bool VROW = false>
 __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
   constexpr int HDT = 64 * NH, KS = 4 * NH, SUB = 64 * 64 * 2, KVS = KV_STAGE * NH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,11 +182,29 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   const int qc = min(q, T_ - 1);
   const float inv_scale = 1.0f / a.scale;
   const float c2 = a.scale * 1.44269504088896340736f;  // logits -> log2 domain
+  // image-order windows (MODE 5, imgH > 0): window b = (image, wy, wx); token (ty, tx) of the window is image token (wy G + ty, wx G + tx)
+  const bool img_order = MODE == 5 && VROW && a.imgH > 0;
+  int wimg = 0, wy0 = 0, wx0 = 0;
+  if (img_order) {
+    const int nwx = (a.imgW + a.G - 1) / a.G, nwy = (a.imgH + a.G - 1) / a.G;
+    wimg = b / (nwx * nwy);
+    const int w_ = b % (nwx * nwy);
+    wy0 = (w_ / nwx) * a.G;
+    wx0 = (w_ % nwx) * a.G;
+  }
+  // row of window token (ty, tx) in the image-order buffers, or -1 beyond the image
+  auto img_row = [&](int ty, int tx) -> long {
+    const int y = wy0 + ty, x = wx0 + tx;
+    return (y < a.imgH && x < a.imgW) ? ((long)wimg * a.imgH + y) * a.imgW + x : -1;
+  };
+  long qrow = (long)b * T_ + qc;                       // row of this lane's query in qkv / out
+  if (img_order) qrow = img_row(qc / a.G, qc % a.G);
+  const T* padrow = reinterpret_cast<const T*>(a.padrow);
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + fh*8 .. +8] -----------------
   uint4 qf[KS];
   {
-    const T* p = qkv + ((size_t)b * T_ + qc) * E3 + h * HDT + fh * 8;
+    const T* p = (qrow >= 0 ? qkv + (size_t)qrow * E3 : padrow) + h * HDT + fh * 8;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(p + ks * 16);
   }
@@ -187,14 +215,16 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   // scratch and exposed the whole load latency every tile.
   const T* ksrc[2];
   const T* vsrc[2];
-  int krow[2];
+  int krow[2], koff[2], voff[2];                             // (VROW: element offsets of the lane's K / V chunk inside a qkv row)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (i * 4 + wave) * 8 + (lane >> 3);        // tile row 0..63
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     krow[i] = row;
-    ksrc[i] = qkv + (size_t)b * T_ * E3 + a.E + h * HDT + chunk * 8;
-    vsrc[i] = vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
+    koff[i] = a.E + h * HDT + chunk * 8;
+    voff[i] = 2 * a.E + h * HDT + ((lane & 7) ^ (4 * ((row >> 1) & 1))) * 8;
+    ksrc[i] = qkv + (size_t)b * T_ * E3 + koff[i];
+    vsrc[i] = VROW ? qkv + (size_t)b * T_ * E3 + voff[i] : vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
   }
   const unsigned lds0 = lds_addr_of(smem);
   auto dma = [&](int j, int stage) {
@@ -202,17 +232,31 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     const unsigned sv = sk + NH * SUB;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int key;
+      int key = 0;
+      const T* kp = nullptr;
+      const T* vp = nullptr;
       if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
         const int slot = j * 64 + krow[i];
-        key = min(slot >> 4, a.G - 1) * a.G + min(slot & 15, a.G - 1);
+        const int ty = min(slot >> 4, a.G - 1), tx = min(slot & 15, a.G - 1);
+        key = ty * a.G + tx;
+        if (img_order) {
+          const long r = img_row(ty, tx);
+          const T* rp = r >= 0 ? qkv + (size_t)r * E3 : padrow;
+          kp = rp + koff[i];
+          vp = rp + voff[i];
+        }
       } else {
         key = min(j * 64 + krow[i], T_ - 1);
       }
+      if (!img_order) {
+        kp = ksrc[i] + (size_t)key * E3;
+        if (VROW) vp = vsrc[i] + (size_t)key * E3;
+      }
 #pragma unroll
-      for (int hh = 0; hh < NH; ++hh) {            // dims 64 hh .. of K, rows 64 hh .. of V^T
-        dma16(ksrc[i] + (size_t)key * E3 + hh * 64, sk + hh * SUB + (i * 4 + wave) * 1024);
-        dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
+      for (int hh = 0; hh < NH; ++hh) {            // dims 64 hh .. of K (and of the V rows), rows 64 hh .. of V^T
+        dma16(kp + hh * 64, sk + hh * SUB + (i * 4 + wave) * 1024);
+        if (VROW) dma16(vp + hh * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
+        else dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
       }
     }
   };
@@ -362,6 +406,13 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
+  // VROW: byte offsets of this lane's transpose reads inside a V stage, for the two 32-dimension blocks (+ ks * 2048, + 512 for keys 4 .. 7)
+  unsigned vtr[2] = {0u, 0u};
+  if (VROW) {
+    const int j = (lane & 15) >> 2, c = lane & 3, jb = (j >> 1) & 1, gd = (lane >> 4) & 1;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd) vtr[dd] = (unsigned)((8 * fh + j) * 128 + ((4 * (dd ^ jb) + 2 * gd + (c >> 1)) << 4) + (c & 1) * 8);
+  }
 
   dma_wait<0>();
   // MODE 4: relh[q][j] = Uh[63 - j][q], Uh[i][q] = Rh[y + i] . q; half hf covers tiles j in [32 hf, 32 hf + 32) = rows
@@ -530,7 +581,18 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
       for (int d = 0; d < 2 * NH; ++d) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(sv + (d >> 1) * SUB + swz_off((d & 1) * 32 + fr, ks * 2 + fh));
+        uint4 vf;
+        if (VROW) {
+          typedef short s16x4 __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+          const unsigned va = lds_addr_of(sv) + (d >> 1) * SUB + vtr[d & 1] + ks * 2048;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)va);
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(va + 512));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          vf = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        } else {
+          vf = *reinterpret_cast<const uint4*>(sv + (d >> 1) * SUB + swz_off((d & 1) * 32 + fr, ks * 2 + fh));
+        }
         oacc[d] = Half16<T>::mfma32(vf, pf[ks], oacc[d]);
       }
     }
@@ -546,8 +608,8 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   const float l_tot = xhalf_sum(l_run);
   const float inv_l = 1.0f / l_tot;
   if (a.lse != nullptr && q < T_ && fh == 0) a.lse[(size_t)bh * a.Tpad + q] = m_run * c2 + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
-  if (q < T_) {
-    T* op = reinterpret_cast<T*>(a.out) + ((size_t)b * T_ + q) * a.E + h * HDT;
+  if (q < T_ && qrow >= 0) {
+    T* op = reinterpret_cast<T*>(a.out) + (size_t)qrow * a.E + h * HDT;
 #pragma unroll
     for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
@@ -561,8 +623,8 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   if (a.cspart != nullptr) {
     // column sums of the block's stored rows: DPP sums over the 16-lane rows (a lane is a query), the 4 rows x 4 waves of a column
     // meet in LDS (the K / V^T stages are idle: the key loop ended with a barrier) and are added in a fixed order
-    bool valid = q < T_;
-    if (MODE == 5 && a.csH > 0) {
+    bool valid = q < T_ && qrow >= 0;
+    if (MODE == 5 && a.csH > 0 && !img_order) {
       const int nwx = (a.csW + a.G - 1) / a.G, nwy = (a.csH + a.G - 1) / a.G;
       const int w = b % (nwx * nwy);
       valid = valid && (w / nwx) * a.G + qc / a.G < a.csH && (w % nwx) * a.G + qc % a.G < a.csW;
@@ -761,20 +823,20 @@ static void launch_window(const AttnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((attn_window_kernel<T>), dim3((njobs + 3) / 4), dim3(256), lds, st, a, qtiles);
 }
 
-template <typename T, int MODE, int NH>
+template <typename T, int MODE, int NH, bool VROW = false>
 static void launch_attn_nh(const AttnArgs& a, size_t lds, hipStream_t st) {
   // raise the dynamic-LDS limit to the most any request of this variant can need (160 KiB), once per device
   static unsigned long long attr_mask = 0;
-  ensure_dyn_lds(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, NH>), 160 * 1024, attr_mask);
+  ensure_dyn_lds(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, NH, VROW>), 160 * 1024, attr_mask);
   const int nq = (a.T + 127) / 128;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, NH>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, NH, VROW>), dim3(nq * a.B * a.heads), dim3(256), lds, st, a);
 }
 
 // extra = LDS beyond the two K / V^T stages (bias tables); head_dim = E / heads is 64 or 128
-template <typename T, int MODE>
+template <typename T, int MODE, bool VROW = false>
 static void launch_attn(const AttnArgs& a, size_t extra, hipStream_t st) {
-  if (a.E == a.heads * 128) launch_attn_nh<T, MODE, 2>(a, 2 * (size_t)KV_STAGE * 2 + extra, st);
-  else launch_attn_nh<T, MODE, 1>(a, 2 * (size_t)KV_STAGE + extra, st);
+  if (a.E == a.heads * 128) launch_attn_nh<T, MODE, 2, VROW>(a, 2 * (size_t)KV_STAGE * 2 + extra, st);
+  else launch_attn_nh<T, MODE, 1, VROW>(a, 2 * (size_t)KV_STAGE + extra, st);
 }
 
 
@@ -1031,6 +1093,47 @@ extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, cons
     LA_CHECK_ARG(false, "la_attn_fwd: bad mode %d", mode);
   }
   LA_CHECK_LAUNCH("la_attn_fwd");
+  return 0;
+}
+
+// The same attention without a V^T copy: V tiles come row-major from the v columns of qkv (ds_read_b64_tr_b16 feeds the MFMA).  Modes:
+// LA_ATTN_PLAIN; LA_ATTN_RELPOS with the 16-bit tables and G == 64 (terms in-kernel); LA_ATTN_RELPOS_WIN16 (G <= 16) - with imgH > 0 the
+// windows are addressed in IMAGE order: qkv / out16 are [images * imgH * imgW] token rows, B = images * ceil(imgH / G) * ceil(imgW / G)
+// windows, padrow = [3E] 16-bit q | k | v of a padded token (the qkv bias: pad-after-norm, image_encoder.py:160-172), no window buffers.
+extern "C" int la_attn_fwd_rows(const void* qkv, void* out16, const void* tabh, const void* tabw, int B, int heads, int T, int Tpad, int G, int E,
+                                float scale, int mode, float* cspart, int imgH, int imgW, const void* padrow, int dt, void* stream) {
+  LA_CHECK_ARG(qkv && out16, "la_attn_fwd_rows: null pointer");
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_fwd_rows: needs head_dim 64 or 128 - pad other widths with zero columns (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_rows: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
+  LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_rows: bad dtype %d", dt);
+  la::AttnArgs a{qkv, nullptr, out16, nullptr, nullptr, tabh, tabw, B, heads, T, Tpad, G, E, scale, nullptr, cspart, 0, 0, 0, 0, nullptr};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (mode == LA_ATTN_PLAIN) {
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 0, true>(a, 0, st);
+    else la::launch_attn<la::bf16_t, 0, true>(a, 0, st);
+  } else if (mode == LA_ATTN_RELPOS_WIN16) {
+    LA_CHECK_ARG(tabh && tabw && G > 0 && G <= 16 && G * G == T && Tpad >= 16 * G,
+                 "la_attn_fwd_rows: WIN16 needs the tables, T == G*G, G <= 16 and Tpad >= 16*G (T=%d G=%d Tpad=%d)", T, G, Tpad);
+    if (imgH > 0) {
+      const int nw = ((imgH + G - 1) / G) * ((imgW + G - 1) / G);
+      LA_CHECK_ARG(imgW > 0 && padrow && B % nw == 0, "la_attn_fwd_rows: image-order windows need imgW, padrow and B = images * %d windows", nw);
+      a.imgH = imgH;
+      a.imgW = imgW;
+      a.padrow = padrow;
+    }
+    const size_t lds = 4 * 32 * 33 * sizeof(float);
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 5, true>(a, lds, st);
+    else la::launch_attn<la::bf16_t, 5, true>(a, lds, st);
+  } else if (mode == LA_ATTN_RELPOS) {
+    LA_CHECK_ARG(tabh && tabw && G == 64 && T == 4096, "la_attn_fwd_rows: rel-pos form needs the tables and the 64 x 64 grid (G=%d T=%d)", G, T);
+    const size_t lds = 4 * 32 * 33 * sizeof(float);
+    if (dt == LA_F16) la::launch_attn<la::f16_t, 4, true>(a, lds, st);
+    else la::launch_attn<la::bf16_t, 4, true>(a, lds, st);
+  } else {
+    LA_CHECK_ARG(false, "la_attn_fwd_rows: bad mode %d", mode);
+  }
+  LA_CHECK_LAUNCH("la_attn_fwd_rows");
   return 0;
 }
 

@@ -155,6 +155,10 @@ class LamEngine:
         # attention, csrc/twoway.hip) for the published decoder geometry; fuse_twoway=False keeps the GEMM + attention + norm chain
         self.fuse_twoway = bool(fuse_twoway) and cfg.embed_dim in (256, 512) and cfg.dec_heads == 8 and decoder_dtype == torch.float32
         self.window_scatter = bool(window_scatter)
+        # attention without V^T copies / window buffers (la_attn_fwd_rows) wherever its forms cover the block: plain attention, the 64 x 64
+        # rel-pos grid, 16-slot windows; False keeps the V^T epilogue + window scatter path (A/B, and what the other geometries still use)
+        self.attn_rows = True
+        self._last16 = None
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
         L.lib()  # fail loudly if the HIP extension is missing
@@ -263,6 +267,9 @@ class LamEngine:
         """Pack a fused qkv weight [3 ea, K] + bias.  Group "qkv": planes for all rows; group "v": a one-plane [2 ea, K] q/k weight and
         a two-plane [ea, 2 K] V weight (two launches, qkv_gemm); else one plane."""
         self.p[key[:-2] + ".b"] = bias
+        # q | k | v of a token whose LayerNorm output was zero-padded (pad-after-norm windows, image_encoder.py:160-172): the bias, as the
+        # GEMM's 16-bit epilogue would round it - the row la_attn_fwd_rows reads for window tokens beyond the image
+        self.p[key[:-2] + ".pad16"] = bias.to(self.dt).contiguous()
         if "qkv" not in self.precise and "v" in self.precise and t.shape[1] % 64 == 0 and (2 * ea) % 8 == 0:
             self.p[key + ".qk"] = t[: 2 * ea].to(self.dt).contiguous()
             self._hw(key + ".v", t[2 * ea:], "v")
@@ -275,6 +282,13 @@ class LamEngine:
         rows of the weight carry a second plane.  rowmap = (map, p): output row map of both (image-order tokens -> window order)."""
         b = self.p[key[:-2] + ".b"]
         mkw = {} if rowmap is None else {"map": rowmap[0], "p": rowmap[1]}
+        if vt is None:          # no V^T copy (la_attn_fwd_rows reads the v columns): every column through the plain row-major epilogue
+            if (key + ".qk") in self.p:
+                L.gemm(x, self.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea], **mkw)
+                L.gemm(x, self.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], a_kmod=self.kmod.get(key + ".v", 0), **mkw)
+            else:
+                self.gemm_w(x, key, bias=b, out16=qkv, **mkw)
+            return
         if (key + ".qk") in self.p:
             L.gemm(x, self.p[key + ".qk"], bias=b[: 2 * ea], out16=qkv[:, : 2 * ea], **mkw)
             L.gemm(x, self.p[key + ".v"], bias=b[2 * ea:], out16=qkv[:, 2 * ea:], vt=vt, vt_col0=0, a_kmod=self.kmod.get(key + ".v", 0),
@@ -596,6 +610,31 @@ class LamEngine:
             win16 = (not is_global) and gg <= 16      # windows: V^T / K in 16-wide padded slot order (LA_ATTN_RELPOS_WIN16)
             tpad = _ceil(16 * gg, 64) if win16 else _ceil(t, 64)
             tag = "g" if is_global else "w"
+            # No V^T copy, no window buffers (la_attn_fwd_rows): the q | k | v GEMM of EVERY block walks the image-order tokens with its plain
+            # row-major epilogue; attention stages V tiles row-major (LDS transpose reads) and, for 14 x 14 windows, addresses the image's
+            # tokens directly (tokens beyond the image are the bias row); its output is in image order, so proj is a plain GEMM as well.
+            # Measured (profiles/r05_notes.md 2): the V^T scatter cost 110 / 275 us of a 1.53 / 1.65 ms launch, the kernels are equal or faster.
+            rows_path = self.attn_rows and ((is_global and gg == 64) or win16)
+            if rows_path:
+                xin = x16
+                if not is_global:
+                    self.ln(res, bp + ".norm1", 1e-6, out16=xin, **rkw, **ckw)
+                qkv = self.buf("enc.qkv.r", (rows, 3 * ea))
+                self.qkv_gemm(xin, bp + ".qkv.w", qkv, None, ea)
+                ao = self.buf("enc.ao.r", (rows, ea))
+                fused_o = opart is not None and is_global
+                if is_global:
+                    L.attn_fwd_rows(qkv, ao, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
+                                    cspart=opart if fused_o else None)
+                else:
+                    L.attn_fwd_rows(qkv, ao, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
+                                    img_hw=(g, g), padrow=p[bp + ".qkv.pad16"])
+                if rvec is not None:
+                    self.mean_fix(bp, xpart, opart, rvec, bn, hw, o_chunks if fused_o else 0, e, ea, ao=ao)
+                self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
+                self._sam_mlp(bp, i, res, x16, rows, spec, w, rvec, rkw)
+                last16 = self._last16 if self._last16 is not None else last16
+                continue
             # Window blocks whose qkv weight is one plane (at most the V rows carry a second one): the GEMMs walk the REAL tokens in
             # image order and their epilogue scatters q / k rows and V^T slots into window order (LA_MAP_WINDOW_PART) - the padded
             # tokens (16 % of the rows at 64 x 64 / 14) are never multiplied.  Their q / k / v are the bias (pad-after-norm), constant
@@ -657,14 +696,8 @@ class LamEngine:
             else:       # window_unpartition as a row gather on the A operand: again only the real tokens are computed
                 self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res, M=rows,
                             amap=L.MAP_WINDOW_PART, p=(ws, nwy, nwy, g, g))
-            self.ln(res, bp + ".norm2", 1e-6, out16=x16, **rkw)
-            hbuf = self.buf("enc.mlp", (rows, spec.mlp))
-            self.gemm_w(x16, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
-            if i == spec.depth - 1 and not (self.cfg.use_vit_sam_neck and "neck" in self.precise) and rvec is None:
-                last16 = self.buf("enc.last16", (rows, e))
-                self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=last16)
-            else:
-                self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
+            self._sam_mlp(bp, i, res, x16, rows, spec, w, rvec, rkw)
+            last16 = self._last16 if self._last16 is not None else last16
         if rvec is not None:           # the stream leaves the block stack: fold the pending corrections in
             L.add_rowvec(res, rvec, hw)
             if not (self.cfg.use_vit_sam_neck and "neck" in self.precise):
@@ -676,6 +709,19 @@ class LamEngine:
         if want_last_block:
             return (out, None, spec.out_chans), res
         return out, None, spec.out_chans
+
+    def _sam_mlp(self, bp: str, i: int, res: Tensor, x16: Tensor, rows: int, spec, w, rvec, rkw) -> None:
+        """norm2 + lin1 (GELU) + lin2 (residual) of one SAM block; the last block may leave a 16-bit copy of the stream in ``self._last16``."""
+        e = spec.dim
+        self.ln(res, bp + ".norm2", 1e-6, out16=x16, **rkw)
+        hbuf = self.buf("enc.mlp", (rows, spec.mlp))
+        self.gemm_w(x16, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=hbuf, act=L.ACT_GELU)
+        self._last16 = None
+        if i == spec.depth - 1 and not (self.cfg.use_vit_sam_neck and "neck" in self.precise) and rvec is None:
+            self._last16 = self.buf("enc.last16", (rows, e))
+            self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=self._last16)
+        else:
+            self.gemm_w(hbuf, bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res)
 
     # ------------------------------------------------------------------------------------------------
     # HuggingFace plain ViT encoder (transformers ViTModel maths; build_encoder.py:83-100)
@@ -720,7 +766,9 @@ class LamEngine:
         hdp = self.head_pad
         ea = heads * hdp
         qkv = self.buf("hf.qkv", (rows, 3 * ea))
-        vt = self.buf("hf.vt", (bn * heads, hdp, tpad), zero=True)
+        fp8 = self.attn_fp8 and hdp == 64          # (the fp8 QK^T kernel keeps its V^T operand)
+        rows_path = self.attn_rows and not fp8     # no V^T copy: la_attn_fwd_rows
+        vt = None if rows_path else self.buf("hf.vt", (bn * heads, hdp, tpad), zero=True)
         ao = self.buf("hf.ao", (rows, ea))
         hbuf = self.buf("hf.mlp", (rows, spec.mlp))
         scale = spec.head_dim ** -0.5
@@ -737,9 +785,14 @@ class LamEngine:
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             self.ln(res, lp + ".layernorm_before", 1e-12, out16=x16, **rkw, **ckw)
-            self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
-            fused_o = opart is not None and not (self.attn_fp8 and hdp == 64)
-            if self.attn_fp8 and hdp == 64:
+            if rows_path:
+                self.qkv_gemm(x16, lp + ".qkv.w", qkv, None, ea)
+            else:
+                self.qkv_gemm(x16, lp + ".qkv.w", qkv, vt, ea, vt_T=t, vt_Tpad=tpad, vt_hd=hdp, vt_heads=heads)
+            fused_o = opart is not None and not fp8
+            if rows_path:
+                L.attn_fwd_rows(qkv, ao, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN, cspart=opart if fused_o else None)
+            elif self.attn_fp8 and hdp == 64:
                 qk8 = self.arena.get("hf.qk8", (rows, 2 * ea), torch.uint8, False)
                 L.qk_fp8(qkv, ea, qk8)
                 L.attn_fwd_fp8(qk8, vt, ao, bn, heads, t, tpad, ea, scale)

@@ -469,3 +469,24 @@ def test_attn_fp8_on_a_cfg5_episode_at_full_geometry():
     e = rel_err(out8, base)
     print(f"[attn_fp8 cfg5] logits vs the 16-bit path: {e:.3e} (bound {FP8_BOUND})")
     assert 0 < e <= FP8_BOUND, e
+
+
+@pytest.mark.parametrize("name", ["sam_tiny_2w2s_all_prompts", "hf_tiny_1w1s_masks", "cfg2_sam_b_1024_1w1s"])
+def test_attention_rows_path_matches_the_v_transposed_path(name):
+    """LamEngine.attn_rows (default): no V^T copies, no window buffers - la_attn_fwd_rows on image-order q | k | v.  The attention outputs are
+    bit-identical to the V^T path's (tests/test_ops_gpu.py); what differs is the ORDER in which the token means of the proj operand are
+    summed (image order instead of window order), i.e. fp32 rounding of the mean corrections: the logits agree to 1e-5."""
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    outs = []
+    for rows in (True, False):
+        lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+        lam.selected_rows = gold.get("selected_rows")
+        lam.engine().attn_rows = rows
+        outs.append(lam(batch)["logits"].float().clone())
+        del lam
+        torch.cuda.empty_cache()
+    err = rel_err(outs[0], outs[1])
+    print(f"[attn_rows {name}] logits, rows path vs V^T path: {err:.3e}")
+    assert err <= 1e-5

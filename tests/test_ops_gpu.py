@@ -914,3 +914,81 @@ def test_attention_column_sums(L, shape):
         bar = torch.empty(b, e, device="cuda")
         L.colsum_fold(part, b, nq, e, 1.0 / t, bar)
     assert float((bar - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max())), float((bar - want).abs().max())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [("plain", 3, 901, 0, 64), ("plain", 2, 4096, 0, 64), ("global", 2, 4096, 64, 64), ("win16", 7, 196, 14, 64),
+                                   ("win16", 5, 64, 8, 64), ("plain", 2, 300, 0, 128), ("global", 1, 4096, 64, 128), ("win16", 4, 196, 14, 128)])
+def test_attention_without_a_transposed_v_copy_is_bit_identical(L, dt, shape):
+    """la_attn_fwd_rows: V tiles staged row-major from the v columns of qkv and fed to the MFMA by LDS transpose reads - the same products
+    in the same order as la_attn_fwd on the V^T copy, so the outputs (and the per-block column sums) are equal bit for bit."""
+    kind, b, t, gg, hd = shape
+    heads = 3
+    e = heads * hd
+    gen = torch.Generator(device="cuda").manual_seed(t + hd)
+    qkv = (torch.randn(b * t, 3 * e, device="cuda", generator=gen) * 0.8).to(dt)
+    mode = {"plain": L.ATTN_PLAIN, "global": L.ATTN_RELPOS, "win16": L.ATTN_RELPOS_WIN16}[kind]
+    tpad = (16 * gg + 63) // 64 * 64 if kind == "win16" else (t + 63) // 64 * 64
+    vt = torch.zeros(b * heads, hd, tpad, dtype=dt, device="cuda")
+    if kind == "win16":
+        vt.view(b, heads, hd, tpad)[..., :16 * gg].unflatten(-1, (gg, 16))[..., :gg] = qkv[:, 2 * e:].view(b, gg, gg, heads, hd).permute(0, 3, 4, 1, 2)
+    else:
+        vt.view(b, heads, hd, tpad)[..., :t] = qkv[:, 2 * e:].view(b, t, heads, hd).permute(0, 2, 3, 1)
+    tab = dict(tabh=(torch.randn(2 * gg - 1, hd, device="cuda", generator=gen) * 0.3).to(dt),
+               tabw=(torch.randn(2 * gg - 1, hd, device="cuda", generator=gen) * 0.3).to(dt)) if kind != "plain" else {}
+    sc = hd ** -0.5
+    nq = (t + 127) // 128
+    ref = torch.empty(b * t, e, dtype=dt, device="cuda")
+    part_ref = torch.zeros(b * nq * e, device="cuda")
+    L.attn_fwd_cs(qkv, vt, ref, None, None, b, heads, t, tpad, gg, e, sc, mode, part_ref, **tab)
+    out = torch.full_like(ref, float("nan"))
+    part = torch.full((b * nq * e,), float("nan"), device="cuda")
+    L.attn_fwd_rows(qkv, out, b, heads, t, tpad, gg, e, sc, mode, cspart=part, **tab)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(part, part_ref)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(2, 64, 64, 14), (1, 20, 27, 8), (3, 14, 14, 14)])
+def test_window_attention_addressed_in_image_order(L, dt, geom):
+    """la_attn_fwd_rows, LA_ATTN_RELPOS_WIN16 with an image grid: window_partition / window_unpartition (image_encoder.py:258-304) as address
+    arithmetic.  Reference: the windows cut out explicitly - tokens beyond the image are the pad row, as pad-after-norm makes them - and run
+    through la_attn_fwd on window buffers; every real token's output must be equal bit for bit, and the column sums fold to the image's
+    token means."""
+    nimg, ih, iw, gg = geom
+    heads, hd = 2, 64
+    e = heads * hd
+    t = gg * gg
+    nwy, nwx = -(-ih // gg), -(-iw // gg)
+    b = nimg * nwy * nwx
+    gen = torch.Generator(device="cuda").manual_seed(ih * 100 + iw)
+    qkv = (torch.randn(nimg * ih * iw, 3 * e, device="cuda", generator=gen) * 0.8).to(dt)
+    padrow = (torch.randn(3 * e, device="cuda", generator=gen) * 0.5).to(dt)
+    tabh = (torch.randn(2 * gg - 1, hd, device="cuda", generator=gen) * 0.3).to(dt)
+    tabw = (torch.randn(2 * gg - 1, hd, device="cuda", generator=gen) * 0.3).to(dt)
+    # explicit windows: [image, wy, wx, ty, tx] -> image row or -1
+    yy = torch.arange(nwy, device="cuda")[:, None] * gg + torch.arange(gg, device="cuda")[None]          # [wy, ty]
+    xx = torch.arange(nwx, device="cuda")[:, None] * gg + torch.arange(gg, device="cuda")[None]          # [wx, tx]
+    inside = (yy < ih)[:, None, :, None] & (xx < iw)[None, :, None, :]                                    # [wy, wx, ty, tx]
+    row = (yy.clamp(max=ih - 1)[:, None, :, None] * iw + xx.clamp(max=iw - 1)[None, :, None, :])
+    rows = (torch.arange(nimg, device="cuda").view(nimg, 1, 1, 1, 1) * ih * iw + row[None]).reshape(-1)
+    ins = inside[None].expand(nimg, -1, -1, -1, -1).reshape(-1)
+    qkv_w = torch.where(ins[:, None], qkv[rows], padrow[None].expand(rows.numel(), -1)).contiguous()     # [b * t, 3E]
+    tpad = (16 * gg + 63) // 64 * 64
+    vt = torch.zeros(b * heads, hd, tpad, dtype=dt, device="cuda")
+    vt.view(b, heads, hd, tpad)[..., :16 * gg].unflatten(-1, (gg, 16))[..., :gg] = qkv_w[:, 2 * e:].view(b, gg, gg, heads, hd).permute(0, 3, 4, 1, 2)
+    ref_w = torch.empty(b * t, e, dtype=dt, device="cuda")
+    L.attn_fwd(qkv_w, vt, ref_w, None, None, b, heads, t, tpad, gg, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw)
+    out = torch.full((nimg * ih * iw, e), float("nan"), dtype=dt, device="cuda")
+    nq = (t + 127) // 128
+    part = torch.full((b * nq * e,), float("nan"), device="cuda")
+    L.attn_fwd_rows(qkv, out, b, heads, t, tpad, gg, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw, cspart=part, img_hw=(ih, iw),
+                    padrow=padrow)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())                                 # every image token was written
+    assert torch.equal(out[rows[ins]], ref_w[ins])
+    bar = torch.empty(nimg, e, device="cuda")
+    L.colsum_fold(part, nimg, nwy * nwx * nq, e, 1.0 / (ih * iw), bar)
+    want = out.float().view(nimg, ih * iw, e).mean(1)
+    assert float((bar - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max()))

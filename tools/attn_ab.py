@@ -51,3 +51,23 @@ for name, b, t, mode, gg in (("global_relpos 16x12 T4096", 16, 4096, L.ATTN_RELP
         continue
     fl = 4.0 * b * heads * t * t * 64
     print(f"{name:28s} {us:9.1f} us {fl / us / 1e6:7.1f} TF/s  checksum {float(out.float().abs().sum()):.6e}", flush=True)
+    if hasattr(L.lib(), "la_attn_fwd_rows"):       # the same launch without the V^T copy (V tiles row-major + LDS transpose reads)
+        out2 = torch.empty_like(out)
+        fn2 = lambda: L.attn_fwd_rows(qkv, out2, b, heads, t, tpad, gg, e, sc, mode, tabh=tabh, tabw=tabw)
+        try:
+            us2 = bench(fn2)
+            print(f"{(name + ' ROWS')[:28]:28s} {us2:9.1f} us {fl / us2 / 1e6:7.1f} TF/s  checksum {float(out2.float().abs().sum()):.6e}  equal {bool(torch.equal(out, out2))}", flush=True)
+        except Exception as ex:
+            print(name, 'rows failed:', ex)
+# SAM windows addressed in image order (96 images would be the bench's batch: 16 here): 64 x 64 tokens, 5 x 5 windows of 14 x 14
+if hasattr(L.lib(), "la_attn_fwd_rows"):
+    nimg, ih, gg = 16, 64, 14
+    nw = -(-ih // gg)
+    b, t, tpad = nimg * nw * nw, gg * gg, (16 * gg + 63) // 64 * 64
+    qkv = (torch.randn(nimg * ih * ih, 3 * e, device="cuda", generator=g) * 0.8).half()
+    padrow = (torch.randn(3 * e, device="cuda", generator=g) * 0.5).half()
+    tabh = (torch.randn(2 * gg - 1, 64, device="cuda", generator=g) * 0.3).half()
+    tabw = (torch.randn(2 * gg - 1, 64, device="cuda", generator=g) * 0.3).half()
+    out = torch.empty(nimg * ih * ih, e, dtype=torch.float16, device="cuda")
+    us = bench(lambda: L.attn_fwd_rows(qkv, out, b, heads, t, tpad, gg, e, sc, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw, img_hw=(ih, ih), padrow=padrow))
+    print(f"{'window14 image order 400x12':28s} {us:9.1f} us {4.0 * b * heads * t * t * 64 / us / 1e6:7.1f} TF/s  checksum {float(out.float().abs().sum()):.6e}", flush=True)
