@@ -439,6 +439,10 @@ int la_colsum_fold(const float* part, int groups, int chunks, int D, float inv, 
 
 /* x[r] += v[r / rows_per_group] in place (fp32 [rows, D]). */
 int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D, void* stream);
+/* The same pass (v optional: nullptr leaves x as it is) that also writes the result as LA_F16X2 operand rows split16 fp16 [rows, 2 D] =
+ * [hi | lo]: the fp32 token stream leaving the block stack becomes the A operand of the SAM neck's 1 x 1 convolution (image_encoder.py:92-108)
+ * as three fp16 MFMA products instead of the exact-fp32 MFMA, without another pass over it. */
+int la_add_rowvec_split(float* x, const float* v, long rows, int rows_per_group, int D, void* split16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,7 @@ EXPORTS = [
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
     "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
-    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
+    "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
 
@@ -547,6 +547,17 @@ def transpose16(src, dst, colsum=None) -> None:
 def qk_fp8(qkv, e: int, qk8) -> None:
     _dev(qkv)
     _check(lib().la_qk_fp8(_ptr(qkv), C.c_long(qkv.shape[0]), C.c_int(e), _ptr(qk8), C.c_int(dt_of(qkv)), _stream()), "la_qk_fp8")
+
+
+def add_rowvec_split(x, v, rows_per_group: int, split16) -> None:
+    """x[r] += v[r / rows_per_group] in place (v may be None) and split16 [rows, 2 D] fp16 = [hi | lo] planes of the result."""
+    _f32c(x)
+    if v is not None:
+        _f32c(v)
+    if split16.dtype != torch.float16 or tuple(split16.shape) != (x.shape[0], 2 * x.shape[1]) or not split16.is_contiguous():
+        raise ValueError("add_rowvec_split: split16 must be a contiguous fp16 [rows, 2 D] buffer")
+    _check(lib().la_add_rowvec_split(_ptr(x), _ptr(v), C.c_long(x.shape[0]), C.c_int(rows_per_group), C.c_int(x.shape[1]), _ptr(split16),
+                                     _stream()), "la_add_rowvec_split")
 
 
 def attn_fwd_fp8(qk8, vt, out16, b: int, heads: int, t: int, tpad: int, e: int, scale: float) -> None:

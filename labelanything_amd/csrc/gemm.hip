@@ -1692,7 +1692,11 @@ static void launch_t256(const void* A, int lda, const void* W, int ldw, int M, i
                        (!e.vt || (size_t)((M + e.vt_T - 1) / e.vt_T + 4096) * e.vt_heads * e.vt_hd * e.vt_Tpad < (1ull << 32));
   if (al && scatter) return launch_t256p<T, NPL, 1>(A, lda, W, ldw, M, N, K, e, st);
   if (al && plain && e.act == LA_ACT_GELU && !e.res && !e.out32 && e.out16 && !e.vt) return launch_t256p<T, NPL, 2>(A, lda, W, ldw, M, N, K, e, st);
-  if (al && plain && e.act == LA_ACT_NONE && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (!e.res || (e.ldr % 4) == 0)) {
+  // a residual that repeats every res_mod rows (the patch embedding's position table: one row per token of the image) stays on the
+  // persistent four-wave kernel when whole 256-row tiles sit inside one period - its direct epilogue takes the residual rows modulo
+  const bool w4_resmod = NPL == 1 && e.map == LA_MAP_NONE && e.res_mod > 0 && (e.res_mod % 256) == 0 && (M % 256) == 0 && e.res && (g_gemm_variant & 0xff) == 2 &&
+                         (K % 64) == 0 && K >= 128 && (e.a_kmod == 0 || (e.a_kmod % 64) == 0) && !((g_gemm_variant >> 8) & 1);
+  if (al && (plain || w4_resmod) && e.act == LA_ACT_NONE && e.out32 && !e.vt && (e.ld32 % 4) == 0 && (!e.res || (e.ldr % 4) == 0)) {
     // (fp32 atomics from the accumulator layout instead of the read-modify-write through the slab were measured in round 4 and are
     // slower: profiles/r04_notes.md 1)
     return launch_t256p<T, NPL, 3>(A, lda, W, ldw, M, N, K, e, st);

@@ -151,8 +151,10 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   };
   // rows 4 rq + s of block i, columns col0 + 64 jp + 8 cg + t
   // EPI 3: the residual rows of round (i, jp) - requested RING rounds ahead of their use (HBM round trips, nothing else to hide them)
+  // (res_mod: the residual repeats every res_mod rows; the host sends such a call here only when res_mod % 256 == 0 - a tile is inside one period)
+  const int rrow0 = e.res_mod > 0 ? row0 % e.res_mod : row0;
   auto ldres = [&](int i, int jp, float4 (&res)[4][2]) {
-    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+    const int row = rrow0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll

@@ -299,15 +299,21 @@ __global__ __launch_bounds__(256) void colmean16_fold_kernel(const float* __rest
   if (k == 0 && c < D) out[(size_t)g * ldo + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * inv;
 }
 
-__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, long rows, int rpg, int D) {
+// SPLIT: also leaves the sum as an LA_F16X2 operand row [hi (D) | lo (D)] (the A operand of a three-product fp16 GEMM)
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, const float* __restrict__ v, long rows, int rpg, int D,
+                                                         f16_t* __restrict__ split) {
   const int d4 = D / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows * d4; i += (long)gridDim.x * 256) {
     const long r = i / d4;
     const int c = (int)(i % d4);
     float4 a = reinterpret_cast<float4*>(x)[i];
-    const float4 b = reinterpret_cast<const float4*>(v + (r / rpg) * D)[c];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    reinterpret_cast<float4*>(x)[i] = a;
+    if (v != nullptr) {
+      const float4 b = reinterpret_cast<const float4*>(v + (r / rpg) * D)[c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      reinterpret_cast<float4*>(x)[i] = a;
+    }
+    if (SPLIT) store4_split<f16_t>(split + (size_t)r * 2 * D, D, c * 4, a.x, a.y, a.z, a.w);
   }
 }
 }  // namespace la
@@ -339,8 +345,18 @@ extern "C" int la_colsum_fold(const float* part, int groups, int chunks, int D, 
 extern "C" int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D, void* stream) {
   LA_CHECK_ARG(x && v && rows > 0 && rows_per_group > 0 && D > 0 && (D % 4) == 0, "la_add_rowvec: bad arguments");
   const long n = rows * (D / 4);
-  hipLaunchKernelGGL(la::add_rowvec_kernel, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, v, rows, rows_per_group, D);
+  hipLaunchKernelGGL(la::add_rowvec_kernel<false>, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, v, rows, rows_per_group, D, nullptr);
   LA_CHECK_LAUNCH("la_add_rowvec");
+  return 0;
+}
+
+extern "C" int la_add_rowvec_split(float* x, const float* v, long rows, int rows_per_group, int D, void* split16, void* stream) {
+  LA_CHECK_ARG(x && split16 && rows > 0 && (v == nullptr || rows_per_group > 0) && D > 0 && (D % 4) == 0, "la_add_rowvec_split: bad arguments");
+  const long n = rows * (D / 4);
+  hipLaunchKernelGGL(la::add_rowvec_kernel<true>, dim3((unsigned)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, v, rows, rows_per_group > 0 ? rows_per_group : 1, D,
+                     reinterpret_cast<la::f16_t*>(split16));
+  LA_CHECK_LAUNCH("la_add_rowvec_split");
   return 0;
 }

@@ -992,3 +992,44 @@ def test_window_attention_addressed_in_image_order(L, dt, geom):
     L.colsum_fold(part, nimg, nwy * nwx * nq, e, 1.0 / (ih * iw), bar)
     want = out.float().view(nimg, ih * iw, e).mean(1)
     assert float((bar - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("with_v", [True, False])
+def test_add_rowvec_split_leaves_the_stream_as_plane_pairs(L, with_v):
+    """la_add_rowvec_split: x[r] += v[r / rows_per_group] in place (v optional) and the result as LA_F16X2 rows [hi | lo] with hi = rn(x),
+    lo = rn(x - hi) - the A operand of the three-product fp16 GEMM (the SAM neck's 1 x 1 conv); that GEMM against [W_hi | W_hi | W_lo]
+    reproduces the exact-fp32 product to 2e-6."""
+    rows, d, rpg, n = 1024, 768, 256, 256
+    x = rnd(rows, d, seed=70) * 3.0
+    v = rnd(rows // rpg, d, seed=71) if with_v else None
+    want = x + (v.repeat_interleave(rpg, 0) if with_v else 0.0)
+    xs = torch.full((rows, 2 * d), float("nan"), device="cuda", dtype=torch.float16)
+    x_in = x.clone()
+    L.add_rowvec_split(x_in, v, rpg, xs)
+    torch.cuda.synchronize()
+    assert torch.equal(x_in, want)
+    hi = want.to(torch.float16)
+    assert torch.equal(xs[:, :d], hi) and torch.equal(xs[:, d:], (want - hi.float()).to(torch.float16))
+    w = rnd(n, d, seed=72) / math.sqrt(d)
+    whi = w.to(torch.float16)
+    ws = torch.cat([whi, whi, (w - whi.float()).to(torch.float16)], dim=1).contiguous()
+    out = torch.empty(rows, n, device="cuda")
+    L.gemm(xs, ws, out32=out, a_kmod=2 * d)
+    ref = (want.double() @ w.double().t()).float()
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_gemm_residual_that_repeats_every_res_mod_rows_on_the_four_wave_kernel(L):
+    """The patch embedding's GEMM (residual = the position table, one row per token of the image: res_mod) stays on the persistent
+    four-wave kernel when whole 256-row tiles sit inside one period; compared with the exact product."""
+    m, n, k, period = 2048, 512, 768, 512
+    a = (rnd(m, k, seed=80) * 0.5).half()
+    w = (rnd(n, k, seed=81) / math.sqrt(k)).half()
+    bias = rnd(n, seed=82)
+    pos = rnd(period, n, seed=83)
+    out = torch.empty(m, n, device="cuda")
+    L.gemm(a, w, bias=bias, res=pos, res_mod=period, out32=out)
+    torch.cuda.synchronize()
+    ref = (a.double() @ w.double().t() + bias.double() + pos.double().repeat(m // period, 1)).float()
+    assert rel_err(out, ref) < 2e-6
