@@ -402,3 +402,66 @@ def test_checkpoint_restore_between_steps_reaches_the_trainers_encoder():
     assert lc != la
     import labelanything_amd.autograd_ops as A
     assert A.WT is not tr._wt and A.SINK is not tr._sink                 # the trainer's W^T copies / gradient sink do not outlive the call
+
+
+def test_decoder_graph_behind_the_trainable_encoder_is_exact_at_its_own_embeddings():
+    """Why the end-to-end fixture bounds of the trainable-encoder steps are loose, without the looseness: the decoder of these
+    random-weight models has ReLU kinks on a handful of token-side units, so its gradients are DISCONTINUOUS in the embeddings - the CPU
+    oracle alone, with the encoder output perturbed by 3e-4 of its largest entry, moves a decoder-side gradient norm by 1e-3 for one noise
+    seed and by 1e-1 for the next (tools/train_kink_study.py, profiles/r05_train_kink_study.log).  Evaluated AT THE SAME embeddings there is
+    nothing loose: with the HIP encoder's own output handed to the oracle's autograd as the embeddings,
+      * every decoder-side gradient (LAM neck, prompt encoder, mask decoder) agrees to 4e-4 of the largest gradient entry, and
+      * the gradient the decoder graph hands to the encoder backward (d loss / d embeddings) agrees to 1e-3;
+    the encoder's own backward is held to 1e-2 (measured 1e-3) by the linear-functional tests above."""
+    from labelanything_amd.episodes import make_episode
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    from labelanything_amd.weights import init_state_dict
+    from oracle import lam_oracle as O, loss_oracle as LO
+    from tests.cases import TRAIN_ENC_CASE as case, geometry_for
+    from tests.test_train_gpu import make_gt
+    batch = make_episode(**case["episode"])
+    gt = make_gt(batch, batch["flag_examples"].shape[2], seed=3)
+    lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+    tr = LamTrainer(lam, train_encoder=True)
+    seen = {}
+    fwd, bwd = tr.enc_graph.forward, tr.enc_graph.backward
+
+    def spy_forward(images):
+        out = fwd(images)
+        seen["e"] = out.detach().clone()
+        return out
+
+    def spy_backward(g):
+        seen["g"] = g.detach().clone()
+        return bwd(g)
+
+    tr.enc_graph.forward, tr.enc_graph.backward = spy_forward, spy_backward
+    tr.zero_grad()
+    res = tr.forward_backward(batch, gt)
+    torch.cuda.synchronize()
+    im = batch["images"]
+    b, n = im.shape[:2]
+    gg = im.shape[-1] // lam.cfg.encoder_spec.patch
+    e = seen["e"].float().cpu().view(b * n, gg, gg, -1).permute(0, 3, 1, 2).contiguous().requires_grad_(True)     # (Bn, E, g, g) pre-neck
+    w = {k: (v.clone().requires_grad_("image_encoder" not in k and "gaussian" not in k) if v.is_floating_point() else v)
+         for k, v in init_state_dict(case["cfg"], case["weight_seed"]).items()}
+    b2 = {k: v for k, v in batch.items() if k != "images"}
+    b2["embeddings"] = e.view(b, n, *e.shape[1:])
+    out = O.lam_forward(w, geometry_for(case["cfg"]), b2)
+    loss, _ = LO.focal_objective(out["logits"], gt)
+    loss.backward()
+    assert abs(float(res["loss"]) - float(loss.detach())) <= 2e-6 * max(1.0, abs(float(loss.detach())))
+    ref_g = {k: v.grad for k, v in w.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    gmax = max(float(v.abs().max()) for v in ref_g.values())
+    worst = 0.0
+    for k, gv in zip(tr.names, tr.opt.grad_views):
+        if k in ref_g and not k.startswith("image_encoder."):
+            err = float((gv.cpu() - ref_g[k]).abs().max()) / max(float(ref_g[k].abs().max()), 1e-2 * gmax)
+            worst = max(worst, err)
+            assert err <= 4e-4, (k, err)
+    de_ref = e.grad.permute(0, 2, 3, 1).reshape(b * n * gg * gg, -1)
+    de = seen["g"].float().cpu()
+    derr = float((de - de_ref).abs().max()) / float(de_ref.abs().max())
+    print(f"decoder graph at the HIP encoder's own embeddings: worst decoder-side gradient error {worst:.2e}, d loss / d embeddings {derr:.2e}")
+    assert derr <= 1e-3

@@ -180,9 +180,12 @@ def test_steps_with_trainable_sam_encoder_match_the_reference_fixture():
     top = sorted(zip(rel_n.tolist(), keys, gn.tolist(), gold["grad_norm"].tolist()), reverse=True)[:8]
     print("trainable-SAM fixture: worst gradient-norm errors", [(k, f"{e:.2e}", f"{a:.3e} vs {b:.3e}") for e, k, a, b in top], "max norm", float(gold["grad_norm"].max()))
     # Encoder tensors are held to the 16-bit backward's own level.  The decoder-side tensors sit BEHIND the encoder: their gradients are
-    # exact for the embeddings they are given (tests/test_train_gpu.py::test_decoder_graph_is_exact_behind_an_encoder), but a random-weight
-    # decoder amplifies the encoder forward's 16-bit operand error (1e-3 on the logits) by up to two orders of magnitude - measured
-    # 1.0e-1 on mask_downscaling.0.weight here, 2 - 6e-2 on hf_tiny - hence the looser bound on that side.
+    # exact for the embeddings they are given (test_encoder_train_gpu.py::test_decoder_graph_behind_the_trainable_encoder_is_exact_at_its_own_embeddings:
+    # 4e-4, and d loss / d embeddings to 1e-3), but they are DISCONTINUOUS in those embeddings - ReLU kinks on a handful of token-side
+    # units of this random-weight decoder: the CPU oracle alone moves a decoder-side gradient norm by 1e-3 or by 1e-1 from one noise
+    # seed to the next at a 3e-4 perturbation of the encoder output (tools/train_kink_study.py, profiles/r05_train_kink_study.log), and
+    # the error here does not shrink with the forward error (1.5e-2 at 9.3e-4, 1.0e-1 at 5.9e-4: profiles/r05_train_amplification.log).
+    # The bound below is therefore a smoke bound at the level of the largest jump observed; the tight statements are the decomposition tests.
     enc = torch.tensor([k.startswith("image_encoder.") for k in keys])
     assert float(rel_n[enc].max()) <= 3e-2, float(rel_n[enc].max())
     assert float(rel_n[~enc].max()) <= 2e-1, float(rel_n[~enc].max())
