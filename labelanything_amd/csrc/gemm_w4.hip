@@ -113,7 +113,7 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile(
 //   read:  lane -> q = lane >> 3, column group cg = lane & 7: columns 8 cg + t, t = 0..7      (8 loads per round, conflict-free)
 // The LDS queue of a wave is in order: round r + 1 is written right behind the read instructions of round r.
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], int row0, int col0, const LaGemmEpilogue& e, int lane) {
+__device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], int row0, int col0, const LaGemmEpilogue& e, int lane, int M) {
   const int fr = lane & 31, fh = lane >> 5;
   const int rq = lane >> 3, cg = lane & 7;
   const unsigned sl = lds_addr_of(slab);
@@ -159,7 +159,8 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        res[s_][h] = e.res ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        res[s_][h] = (e.res && row0 + i * 32 + rq * 4 + s_ < M) ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);      // (rows beyond M: the last, ragged row tile)
   };
   auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2]) {
     const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
@@ -171,6 +172,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         o0.z = r[2][s_] + bias[jp][2] + res[s_][0].z; o0.w = r[3][s_] + bias[jp][3] + res[s_][0].w;
         o1.x = r[4][s_] + bias[jp][4] + res[s_][1].x; o1.y = r[5][s_] + bias[jp][5] + res[s_][1].y;
         o1.z = r[6][s_] + bias[jp][6] + res[s_][1].z; o1.w = r[7][s_] + bias[jp][7] + res[s_][1].w;
+        if (row + s_ >= M) continue;
         float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
         *reinterpret_cast<float4*>(op) = o0;
         *reinterpret_cast<float4*>(op + 4) = o1;
@@ -222,7 +224,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         pk.y = pack2<T>(v[2][s_ >> 1][s_ & 1], v[3][s_ >> 1][s_ & 1]);
         pk.z = pack2<T>(v[4][s_ >> 1][s_ & 1], v[5][s_ >> 1][s_ & 1]);
         pk.w = pack2<T>(v[6][s_ >> 1][s_ & 1], v[7][s_ >> 1][s_ & 1]);
-        *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
+        if (row + s_ < M) *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
       }
     }
   };
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[1][i][j]));
-      epilogue_w4<T, EPI>(slab, acc, m0 + wr * 128, n0 + wc * 128, e, lane);
+      epilogue_w4<T, EPI>(slab, acc, m0 + wr * 128, n0 + wc * 128, e, lane, M);
     } else {
       epilogue_wave<T, EPI>(slab, rtab, acc[0], m0 + wr * 128, n0 + wc * 128, n0, M, e, lane, nostore);
 #pragma unroll
@@ -536,7 +538,9 @@ void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, 
     }
   }
 #endif
-  const bool direct = (M % 256) == 0 && e.map == LA_MAP_NONE && !e.vt && !((gm >> 8) & 1);
+  // (a ragged last row tile - M % 256 != 0: the HF encoders' 57664 = 225.25 tiles - stays on the direct epilogue: its loads and stores are
+  // predicated on the row; a residual modulo res_mod needs whole tiles inside a period and is only sent here with M % 256 == 0)
+  const bool direct = e.map == LA_MAP_NONE && !e.vt && !((gm >> 8) & 1);
   if (direct) launch_t256w_abl<T, EPI, 0, true>(A, lda, W, ldw, M, N, K, e, gm, st);
   else launch_t256w_abl<T, EPI, 0, false>(A, lda, W, ldw, M, N, K, e, gm, st);
 }

@@ -41,7 +41,7 @@ ARGMAX_MEASURED = {
 }
 ARGMAX_FLOOR = 4
 # 99.9th percentile of |a - b| / |b| over the logits with |b| > 1 % of max|b| (tests/helpers.pct_rel_err)
-PCT_TOL = {torch.float16: 5e-2, torch.bfloat16: 3e-1}
+PCT_TOL = {torch.float16: 4e-2, torch.bfloat16: 3e-1}      # 2 x the worst measured (1.9e-2 cfg2, 1.5e-1 sam_tiny bf16: profiles/r05_parity.log)
 ARGMAX_MARGIN = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # 2 x the logit tolerance
 
 
