@@ -31,7 +31,10 @@ struct LnArgs {
                       // of the qkv operand come out of the pass that writes it (la_colsum_fold adds the chunks in a fixed order)
 };
 constexpr int CM_CHUNK = 128;      // rows per partial of la_colmean16 / la_attn_fwd_cs
-constexpr int LN_CS_ROWS = 32;     // rows per partial of the LayerNorm's column sums (la_layernorm_g): 64 images x 901 rows in 128-row shares
+#ifndef LA_LN_CS_ROWS
+#define LA_LN_CS_ROWS 32
+#endif
+constexpr int LN_CS_ROWS = LA_LN_CS_ROWS;     // rows per partial of the LayerNorm's column sums (la_layernorm_g): 64 images x 901 rows in 128-row shares
                                    // were 512 workgroups on 256 CUs - 2.7 TB/s instead of 4.6
 
 template <typename T>
