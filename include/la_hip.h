@@ -338,11 +338,13 @@ int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, float* lse, in
                     int dt, void* stream);
 
 /* dst[(b * heads + h) * 64 + d][t] = src[b * T + t][col0 + h * 64 + d] (16-bit), zero for T <= t < Tpad: the token-contiguous operand
- * copies of la_attn_fwd (V^T) and la_attn_bwd (K^T, Q^T, dO^T). */
+ * copy of la_attn_fwd's V^T form (the backward kernels and la_attn_fwd_rows need none). */
 int la_head_transpose(const void* src, int ld, int col0, int B, int heads, int T, int Tpad, void* dst, int dt, void* stream);
 
 /* Gradient of O = softmax(Q K^T scale) V per (image, head) (transformers ViTSelfAttention.forward under build_encoder.py:83-100):
- * qkv [B*T, 3E] (q | k | v), out16 = O, dout16 = dO [B*T, E]; kt / qt / dot = la_head_transpose of K, Q, dO; lse from la_attn_fwd_lse;
+ * qkv [B*T, 3E] (q | k | v), out16 = O, dout16 = dO [B*T, E]; kt / qt / dot: UNUSED since round 5 (may be NULL) - the kernels read K^T,
+ * Q^T and dO^T out of the row-major tiles with LDS transpose reads (ds_read_b64_tr_b16), the la_head_transpose copies of rounds 3 - 4
+ * are gone; lse from la_attn_fwd_lse;
  * dvec fp32 [B*heads, Tpad] workspace (need not be initialised: receives rowsum(dO * O), and 0 in [T, Tpad), where lse is set to
  * +1e30 as well); dqkv [B*T, 3E] receives dq | dk | dv.  All 16-bit
  * tensors share dt; dO may be pre-scaled (loss scaling), dq / dk / dv then carry the same factor. */

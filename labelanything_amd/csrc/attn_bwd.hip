@@ -66,6 +66,44 @@ __device__ __forceinline__ void stage_rows(const T* base, size_t ld, int row0, i
   }
 }
 
+// Tiles that are read BOTH ways - by rows (ds_read_b128: the A operand of S / dP) and transposed (ds_read_b64_tr_b16: the A operand of the
+// product that reduces over the tile's 64 tokens, K^T / Q^T / dO^T of rounds 3 - 4's la_head_transpose copies) - use the chunk swizzle
+// swzp(r) = 4 ((r >> 1) & 1) + ((r >> 2) & 3): a bit permutation of the row-read swizzle (r >> 1) & 7 (so the 16-lane groups of a
+// ds_read_b128 still hit 16 different 16-byte slots), whose bit 2 separates rows r and r + 2 - a 32-lane pass of the transpose read
+// (4 token rows x 64 bytes) covers every bank once.
+__device__ __forceinline__ int swzp(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int swzp_off(int row, int chunk) { return row * 128 + ((chunk ^ swzp(row)) << 4); }
+template <typename T>
+__device__ __forceinline__ void stage_rows_p(const T* base, size_t ld, int row0, int maxrow, unsigned lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ swzp(row);
+    dma16(base + (size_t)min(row0 + row, maxrow) * ld + chunk * 8, lds_tile + (i * 4 + wave) * 1024);
+  }
+}
+// byte offsets of this lane's two transpose reads of a tile [64 tokens][64 dims] for dimension block dd (32 dims): tokens 8 fh + 4 h + j
+// of every 16-token step (+ ks * 2048), see attn_enc.hip VROW: in a 16-lane group lane 4 j + c fetches (token row j, dims D + 4 c ..)
+__device__ __forceinline__ void tr_offsets(int lane, unsigned (&tro)[2][2]) {
+  const int fh = lane >> 5, j = (lane & 15) >> 2, c = lane & 3, gd = (lane >> 4) & 1;
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 8 * fh + 4 * h + j;
+      tro[dd][h] = (unsigned)(row * 128 + (((4 * dd + 2 * gd + (c >> 1)) ^ swzp(row)) << 4) + (c & 1) * 8);
+    }
+}
+// A operand (32 dims of block dd x tokens 16 ks .. 16 ks + 15) of a product that reduces over the tile's tokens
+__device__ __forceinline__ uint4 tr_frag(unsigned tile_lds, const unsigned (&tro)[2][2], int dd, int ks) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(tile_lds + tro[dd][0] + ks * 2048));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(tile_lds + tro[dd][1] + ks * 2048));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
 // accumulator tile pair (rows = 64 reduction tokens of one lane's column) -> the four B-operand k-slices, as in the forward kernel
 template <typename T>
 __device__ __forceinline__ void to_b_frags(const f32x16 (&s)[2], uint4 (&pf)[4]) {
@@ -101,7 +139,7 @@ template <typename T> __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
 template <typename T, int BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 3 * TILE_B;             // K rows | V rows | K^T
+  constexpr int STAGE = 2 * TILE_B;             // K rows (read by rows and transposed) | V rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   int bh, qblk;
@@ -138,13 +176,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   const unsigned lds0 = lds_addr_of(smem);
   const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * 64;
   const T* vbase = kbase + a.E;
-  const T* ktb = reinterpret_cast<const T*>(a.kt) + (size_t)bh * 64 * a.Tpad;
   auto dma = [&](int j, int stage) {
     const unsigned s0 = lds0 + stage * STAGE;
-    stage_rows<T>(kbase, E3, j * 64, T_ - 1, s0, wave, lane);
+    stage_rows_p<T>(kbase, E3, j * 64, T_ - 1, s0, wave, lane);
     stage_rows<T>(vbase, E3, j * 64, T_ - 1, s0 + TILE_B, wave, lane);
-    stage_rows<T>(ktb + j * 64, a.Tpad, 0, 63, s0 + 2 * TILE_B, wave, lane);
   };
+  unsigned tro[2][2];
+  tr_offsets(lane, tro);
 
   f32x16 acc[2];
 #pragma unroll
@@ -253,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     }
     const char* sk = smem + (it & 1) * STAGE;
     const char* sv = sk + TILE_B;
-    const char* skt = sk + 2 * TILE_B;
+    const unsigned sk_lds = lds0 + (it & 1) * STAGE;
     f32x16 s[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -275,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swzp_off(t * 32 + fr, ks * 2 + fh));
         const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(t * 32 + fr, ks * 2 + fh));
         s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
         dp[t] = Half16<T>::mfma32(vf, dof[ks], dp[t]);
@@ -319,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        const uint4 ktf = *reinterpret_cast<const uint4*>(skt + swz_off(d * 32 + fr, ks * 2 + fh));
+        const uint4 ktf = tr_frag(sk_lds, tro, d, ks);        // K^T[32 d .. + 32][keys 16 ks .. + 16] out of the row-major K tile
         acc[d] = Half16<T>::mfma32(ktf, dsf[ks], acc[d]);
       }
     if (BIAS == 3) {
@@ -386,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 template <typename T, bool BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 4 * TILE_B + 512;       // Q rows | dO rows | Q^T | dO^T | LSE (64 floats) | D (64 floats)
+  constexpr int STAGE = 2 * TILE_B + 512;       // Q rows | dO rows (both read by rows and transposed) | LSE (64 floats) | D (64 floats)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   int bh, kblk;
@@ -412,20 +450,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   const unsigned lds0 = lds_addr_of(smem);
   const T* qbase = qkv + (size_t)b * T_ * E3 + h * 64;
   const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * 64;
-  const T* qtb = reinterpret_cast<const T*>(a.qt) + (size_t)bh * 64 * a.Tpad;
-  const T* dotb = reinterpret_cast<const T*>(a.dot) + (size_t)bh * 64 * a.Tpad;
   const float* lseb = a.lse + (size_t)bh * a.Tpad;
   const float* dvb = a.dvec + (size_t)bh * a.Tpad;
   auto dma = [&](int i, int stage) {
     const unsigned s0 = lds0 + stage * STAGE;
-    stage_rows<T>(qbase, E3, i * 64, T_ - 1, s0, wave, lane);
-    stage_rows<T>(dobase, a.E, i * 64, T_ - 1, s0 + TILE_B, wave, lane);
-    stage_rows<T>(qtb + i * 64, a.Tpad, 0, 63, s0 + 2 * TILE_B, wave, lane);
-    stage_rows<T>(dotb + i * 64, a.Tpad, 0, 63, s0 + 3 * TILE_B, wave, lane);
+    stage_rows_p<T>(qbase, E3, i * 64, T_ - 1, s0, wave, lane);
+    stage_rows_p<T>(dobase, a.E, i * 64, T_ - 1, s0 + TILE_B, wave, lane);
     // the 64 LSE / D values of the query tile: 16 lanes x 16 bytes each (wave 0: LSE, wave 1: D); every wave issues the same
     // NUMBER of pieces per tile only matters for counted waits - this kernel waits for all of them (dma_wait<0>)
-    if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 4 * TILE_B + wave * 256);
+    if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 2 * TILE_B + wave * 256);
   };
+  unsigned tro[2][2];
+  tr_offsets(lane, tro);
 
   f32x16 dv[2], dk[2];
 #pragma unroll
@@ -450,9 +486,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
     }
     const char* sq = smem + (it & 1) * STAGE;
     const char* sdo = sq + TILE_B;
-    const char* sqt = sq + 2 * TILE_B;
-    const char* sdot = sq + 3 * TILE_B;
-    const float* slse = reinterpret_cast<const float*>(sq + 4 * TILE_B);
+    const unsigned sq_lds = lds0 + (it & 1) * STAGE, sdo_lds = sq_lds + TILE_B;
+    const float* slse = reinterpret_cast<const float*>(sq + 2 * TILE_B);
     const float* sdv = slse + 64;
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -461,8 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
       for (int r = 0; r < 16; ++r) s[t][r] = dp[t][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const uint4 qf = *reinterpret_cast<const uint4*>(sq + swz_off(t * 32 + fr, ks * 2 + fh));
-        const uint4 df = *reinterpret_cast<const uint4*>(sdo + swz_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 qf = *reinterpret_cast<const uint4*>(sq + swzp_off(t * 32 + fr, ks * 2 + fh));
+        const uint4 df = *reinterpret_cast<const uint4*>(sdo + swzp_off(t * 32 + fr, ks * 2 + fh));
         s[t] = Half16<T>::mfma32(qf, kf[ks], s[t]);          // S[i][j]: lane = key j, registers = queries
         dp[t] = Half16<T>::mfma32(df, vf[ks], dp[t]);        // dP[i][j]
       }
@@ -494,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        const uint4 dotf = *reinterpret_cast<const uint4*>(sdot + swz_off(d * 32 + fr, ks * 2 + fh));
-        const uint4 qtf = *reinterpret_cast<const uint4*>(sqt + swz_off(d * 32 + fr, ks * 2 + fh));
+        const uint4 dotf = tr_frag(sdo_lds, tro, d, ks);      // dO^T / Q^T[32 d .. + 32][queries 16 ks .. + 16] out of the row-major tiles
+        const uint4 qtf = tr_frag(sq_lds, tro, d, ks);
         dv[d] = Half16<T>::mfma32(dotf, pf[ks], dv[d]);      // dV^T[d][j] += dO^T[d][i] P[i][j]
         dk[d] = Half16<T>::mfma32(qtf, dsf[ks], dk[d]);      // dK^T[d][j] += Q^T[d][i] dS[i][j]
       }
@@ -561,10 +596,10 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
 template <typename T, int BIAS>
 static void launch_attn_bwd_t(const AttnBwdEncArgs& a, hipStream_t st) {
   const int nblk = (a.T + 127) / 128 * a.B * a.heads;
-  const int lds_dq = 2 * 3 * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
+  const int lds_dq = 2 * 2 * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
                                       : BIAS == 3 ? 32 * (a.Tpad * 2 + 16) + a.Tpad * (int)sizeof(int)
                                                   : 0);
-  constexpr int LDS_DKV = 2 * (4 * TILE_B + 512);
+  constexpr int LDS_DKV = 2 * (2 * TILE_B + 512);
   static unsigned long long m1 = 0, m2 = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS>), 160 * 1024, m1);
   ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0)>), LDS_DKV, m2);
@@ -856,7 +891,7 @@ extern "C" int la_head_transpose(const void* src, int ld, int col0, int B, int h
 
 extern "C" int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
                            float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream) {
-  LA_CHECK_ARG(qkv && out16 && dout16 && kt && qt && dot && lse && dvec && dqkv, "la_attn_bwd: null pointer");
+  LA_CHECK_ARG(qkv && out16 && dout16 && lse && dvec && dqkv, "la_attn_bwd: null pointer");      // (kt / qt / dot: unused since round 5)
   LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd: bad dtype %d", dt);
@@ -869,7 +904,7 @@ extern "C" int la_attn_bwd(const void* qkv, const void* out16, const void* dout1
 extern "C" int la_attn_bwd_relpos(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot,
                                   float* lse, float* dvec, void* dqkv, const float* relh, const float* relw, float* drelh, float* drelw, int B,
                                   int heads, int T, int Tpad, int G, int E, float scale, int dt, void* stream) {
-  LA_CHECK_ARG(qkv && out16 && dout16 && kt && qt && dot && lse && dvec && dqkv && relh && relw && drelh && drelw, "la_attn_bwd_relpos: null pointer");
+  LA_CHECK_ARG(qkv && out16 && dout16 && lse && dvec && dqkv && relh && relw && drelh && drelw, "la_attn_bwd_relpos: null pointer");
   LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd_relpos: needs head_dim 64 (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd_relpos: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(G * G == T && (G <= 32 || G == 64), "la_attn_bwd_relpos: T == G*G with G <= 32 or G == 64 (T=%d G=%d)", T, G);

@@ -338,8 +338,6 @@ class HfEncoderGraph:
         dao = torch.empty(rows, e, device=dev, dtype=dt)
         dqkv16 = torch.empty(rows, 3 * e, device=dev, dtype=dt)
         dqkv32 = torch.empty(rows, 3 * e, device=dev)
-        kt = torch.empty(bn * heads, 64, tpad, device=dev, dtype=dt)
-        qt, dot = torch.empty_like(kt), torch.empty_like(kt)
         dvec = torch.zeros(bn * heads, tpad, device=dev)
         for i in reversed(range(spec.depth)):
             lp = f"{pre}.encoder.layer.{i}"
@@ -355,10 +353,8 @@ class HfEncoderGraph:
                                 sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
             # ---- attention: x_mid = x_in + proj(attn(LN1(x_in))) -------------------------------------------------------------
             self._linear_bwd(dres, d16, a["ao"], lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
-            L.head_transpose(a["qkv"], e, bn, heads, t, tpad, kt)
-            L.head_transpose(a["qkv"], 0, bn, heads, t, tpad, qt)
-            L.head_transpose(dao, 0, bn, heads, t, tpad, dot)
-            L.attn_bwd(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
+            # (no K^T / Q^T / dO^T copies: the backward kernels read those operands out of the row-major tiles with LDS transpose reads)
+            L.attn_bwd(a["qkv"], a["ao"], dao, None, None, None, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
             att = lp + ".attention.attention."
             have32 = False
             for j, nm in enumerate(() if self._qkv_wgrad_fused(dqkv16, a["xn"], att, e) else ("query", "key", "value")):
@@ -573,15 +569,10 @@ class SamEncoderGraph(HfEncoderGraph):
                 dy32 = None
             dao = torch.empty(arows, e, device=dev, dtype=dt)
             self._linear_bwd(dy32, dy16, a["ao"], bp + ".attn.proj.weight", bp + ".attn.proj.bias", dx16=dao)
-            kt = torch.empty(nb * heads, 64, tpad, device=dev, dtype=dt)
-            qt, dot = torch.empty_like(kt), torch.empty_like(kt)
-            L.head_transpose(a["qkv"], e, nb, heads, t, tpad, kt)
-            L.head_transpose(a["qkv"], 0, nb, heads, t, tpad, qt)
-            L.head_transpose(dao, 0, nb, heads, t, tpad, dot)
             dvec = torch.empty(nb * heads, tpad, device=dev)
             dqkv16 = torch.empty(arows, 3 * e, device=dev, dtype=dt)
             drelh, drelw = torch.empty_like(a["relh"]), torch.empty_like(a["relw"])
-            L.attn_bwd_relpos(a["qkv"], a["ao"], dao, kt, qt, dot, a["lse"], dvec, dqkv16, a["relh"], a["relw"], drelh, drelw, nb, heads, t,
+            L.attn_bwd_relpos(a["qkv"], a["ao"], dao, None, None, None, a["lse"], dvec, dqkv16, a["relh"], a["relw"], drelh, drelw, nb, heads, t,
                               tpad, gg, e, c["scale"])
             tabs, dtabs, fold = self._rel_tables(bp, gg)
             L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, tabs[0], tabs[1], dtabs[0], dtabs[1], nb, heads, gg, e)
