@@ -421,10 +421,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // BIAS: the rel-pos terms of (query register, key lane) are read straight from the fp32 term arrays (a fixed register = one query row:
 // the 64 keys of the wave read inside one <= 256-byte row of relh / relw)
-template <typename T, bool BIAS>
+// BIAS 0: none.  1: the two terms of a score read from global memory (odd G: rows of 64 queries are not 16-byte aligned).  2: staged in LDS.
+template <typename T, int BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE_B + 512;       // Q rows | dO rows (both read by rows and transposed) | LSE (64 floats) | D (64 floats)
+  // Q rows | dO rows (both read by rows and transposed) | LSE (64 floats) | D (64 floats) | BIAS: the rel-pos terms of the tile's 64
+  // queries - relw rows [64][G] fp32 (16 KiB at G = 64) and relh: [64][G] for G <= 32, the 4-column group that holds this workgroup's
+  // two key rows [64][4] for G = 64 (a workgroup = 128 keys = two key rows) - staged by LDS-DMA like the tiles (round 4 read two terms per
+  // score from global memory: 64 vector-memory instructions per tile and wave)
+  constexpr int BIAS_B = BIAS == 2 ? 16384 + 1024 : 0;      // G = 64: relw 16 KiB + relh 1 KiB; G <= 32: relw <= 8 KiB, relh <= 8 KiB behind it
+  constexpr int STAGE = 2 * TILE_B + 512 + BIAS_B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   int bh, kblk;
@@ -447,6 +453,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   const int G = BIAS ? a.G : 1;
   const int kh_l = kc / G, kw_l = kc % G;
   const float inv_c = 1.0f / a.scale;
+  // staged bias terms need 16-byte aligned rows of 64 queries: (bh T + 64 i) G % 4 == 0 - every even G (the 14 x 14 windows, 64 x 64)
+  constexpr bool stage_bias = BIAS == 2;
+  const int relh_cols = G == 64 ? 4 : G;                                       // staged relh row length
+  const int relh_c0 = G == 64 ? ((2 * kblk) & ~3) : 0;                          // first staged relh column
+  const long rel_total = (long)a.B * a.heads * T_ * G;                          // floats in relh / relw
+  const int relh_at = G == 64 ? 16384 : 8192;                                   // byte offset of the staged relh block behind relw
   const unsigned lds0 = lds_addr_of(smem);
   const T* qbase = qkv + (size_t)b * T_ * E3 + h * 64;
   const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * 64;
@@ -459,6 +471,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
     // the 64 LSE / D values of the query tile: 16 lanes x 16 bytes each (wave 0: LSE, wave 1: D); every wave issues the same
     // NUMBER of pieces per tile only matters for counted waits - this kernel waits for all of them (dma_wait<0>)
     if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 2 * TILE_B + wave * 256);
+    if (stage_bias) {
+      const long row0 = (long)bh * T_ + i * 64;                // (rows beyond T: whatever follows in the array - their probabilities are 0)
+      const unsigned sb = s0 + 2 * TILE_B + 512;
+      const int npw = (64 * G * 4 + 1023) >> 10;               // 1 KiB pieces of the relw block [64][G] (contiguous rows)
+      for (int pc = wave; pc < npw; pc += 4) {
+        const long off = min(row0 * G + pc * 256 + lane * 4, rel_total - 4);
+        dma16(a.relw + off, sb + pc * 1024);
+      }
+      if (G == 64) {
+        if (wave == 3) dma16(a.relh + min((row0 + lane) * 64 + relh_c0, rel_total - 4), sb + relh_at);      // lane = query: 4 columns
+      } else {
+        for (int pc = wave; pc < npw; pc += 4) {
+          const long off = min(row0 * G + pc * 256 + lane * 4, rel_total - 4);
+          dma16(a.relh + off, sb + relh_at + pc * 1024);
+        }
+      }
+    }
   };
   unsigned tro[2][2];
   tr_offsets(lane, tro);
@@ -489,6 +518,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
     const unsigned sq_lds = lds0 + (it & 1) * STAGE, sdo_lds = sq_lds + TILE_B;
     const float* slse = reinterpret_cast<const float*>(sq + 2 * TILE_B);
     const float* sdv = slse + 64;
+    const float* srw = reinterpret_cast<const float*>(sq + 2 * TILE_B + 512);
+    const float* srh = srw + relh_at / 4;
     f32x16 s[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -514,8 +545,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
         for (int k = 0; k < 4; ++k) {
           const int r = g4 * 4 + k;
           if (BIAS) {
-            const size_t row = ((size_t)bh * T_ + min(i * 64 + t * 32 + 8 * g4 + 4 * fh + k, T_ - 1)) * G;
-            s[t][r] += (a.relh[row + kh_l] + a.relw[row + kw_l]) * inv_c;
+            const int ql = t * 32 + 8 * g4 + 4 * fh + k;                         // the register's query inside the tile
+            if (stage_bias) {
+              s[t][r] += (srh[ql * relh_cols + kh_l - relh_c0] + srw[ql * G + kw_l]) * inv_c;
+            } else {
+              const size_t row = ((size_t)bh * T_ + min(i * 64 + ql, T_ - 1)) * G;
+              s[t][r] += (a.relh[row + kh_l] + a.relw[row + kw_l]) * inv_c;
+            }
           }
           const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -lv[k]));    // rows beyond T carry LSE = +BIG: p = 0
           s[t][r] = p;
@@ -599,12 +635,18 @@ static void launch_attn_bwd_t(const AttnBwdEncArgs& a, hipStream_t st) {
   const int lds_dq = 2 * 2 * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
                                       : BIAS == 3 ? 32 * (a.Tpad * 2 + 16) + a.Tpad * (int)sizeof(int)
                                                   : 0);
-  constexpr int LDS_DKV = 2 * (2 * TILE_B + 512);
-  static unsigned long long m1 = 0, m2 = 0;
+  static unsigned long long m1 = 0, m2 = 0, m3 = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS>), 160 * 1024, m1);
-  ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0)>), LDS_DKV, m2);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, BIAS>), dim3(nblk), dim3(256), lds_dq, st, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, (BIAS != 0)>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+  if (BIAS != 0 && (a.G & 1) == 0) {           // staged bias terms: even G (16-byte aligned rows of 64 queries)
+    constexpr int LDS_DKV = 2 * (2 * TILE_B + 512 + 16384 + 1024);      // 67 KiB: two workgroups per CU
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, 2>), LDS_DKV, m3);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 2>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+  } else {
+    constexpr int LDS_DKV = 2 * (2 * TILE_B + 512);
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0)>), LDS_DKV, m2);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0)>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+  }
 }
 static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream_t st) {
   if (dt == LA_F16) {
