@@ -136,10 +136,13 @@ template <typename T> __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
 // 16-bit parts: exact to 2^-22), and d relh | d relw = E^T dS^T accumulates beside dQ^T from the same dS^T fragments.
 // BIAS 2: G == 64 - a 64-key tile is exactly one key row: relh[q][tile] is one scalar per tile, relw[q][0..63] lives in the 32 score
 // registers' positions for the whole kernel, d relw accumulates in 32 more registers and d relh[q][tile] is one store per tile.
-template <typename T, int BIAS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
+// NH = head width / 64 (1 or 2): a 128-wide head (SAM ViT-H's 80 zero-padded by the packed weights, engine.py head_pad) is two 64-wide
+// halves everywhere - NH K tiles + NH V tiles per stage, 4 NH k-slices of S^T / dP^T, 2 NH accumulator tiles of dQ^T - on one wave per SIMD.
+template <typename T, int BIAS, int NH>
+__global__ __launch_bounds__(256, (NH == 1 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 2 * TILE_B;             // K rows (read by rows and transposed) | V rows
+  constexpr int STAGE = 2 * NH * TILE_B;        // K rows (read by rows and transposed; NH tiles of 64 dims) | V rows
+  constexpr int HDT = 64 * NH, KS = 4 * NH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   int bh, qblk;
@@ -150,15 +153,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   const int q = qblk * 128 + wave * 32 + fr, qc = min(q, T_ - 1);
   const float c2 = a.scale * 1.44269504088896340736f;
 
-  uint4 qf[4], dof[4];
+  uint4 qf[KS], dof[KS];
   float dsum = 0.f;
   {
     const size_t row = (size_t)b * T_ + qc;
-    const T* pq = qkv + row * E3 + h * 64 + fh * 8;
-    const T* pd = reinterpret_cast<const T*>(a.dout) + row * a.E + h * 64 + fh * 8;
-    const T* po = reinterpret_cast<const T*>(a.out) + row * a.E + h * 64 + fh * 8;
+    const T* pq = qkv + row * E3 + h * HDT + fh * 8;
+    const T* pd = reinterpret_cast<const T*>(a.dout) + row * a.E + h * HDT + fh * 8;
+    const T* po = reinterpret_cast<const T*>(a.out) + row * a.E + h * HDT + fh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       qf[ks] = *reinterpret_cast<const uint4*>(pq + ks * 16);
       dof[ks] = *reinterpret_cast<const uint4*>(pd + ks * 16);
       dsum += dot8<T>(dof[ks], *reinterpret_cast<const uint4*>(po + ks * 16));
@@ -174,19 +177,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
   }
 
   const unsigned lds0 = lds_addr_of(smem);
-  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * 64;
+  const T* kbase = qkv + (size_t)b * T_ * E3 + a.E + h * HDT;
   const T* vbase = kbase + a.E;
   auto dma = [&](int j, int stage) {
     const unsigned s0 = lds0 + stage * STAGE;
-    stage_rows_p<T>(kbase, E3, j * 64, T_ - 1, s0, wave, lane);
-    stage_rows<T>(vbase, E3, j * 64, T_ - 1, s0 + TILE_B, wave, lane);
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      stage_rows_p<T>(kbase + hh * 64, E3, j * 64, T_ - 1, s0 + hh * TILE_B, wave, lane);
+      stage_rows<T>(vbase + hh * 64, E3, j * 64, T_ - 1, s0 + (NH + hh) * TILE_B, wave, lane);
+    }
   };
   unsigned tro[2][2];
   tr_offsets(lane, tro);
 
-  f32x16 acc[2];
+  f32x16 acc[2 * NH];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
       continue;
     }
     const char* sk = smem + (it & 1) * STAGE;
-    const char* sv = sk + TILE_B;
+    const char* sv = sk + NH * TILE_B;
     const unsigned sk_lds = lds0 + (it & 1) * STAGE;
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -312,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(sk + swzp_off(t * 32 + fr, ks * 2 + fh));
-        const uint4 vf = *reinterpret_cast<const uint4*>(sv + swz_off(t * 32 + fr, ks * 2 + fh));
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(sk + (ks >> 2) * TILE_B + swzp_off(t * 32 + fr, (ks & 3) * 2 + fh));
+        const uint4 vf = *reinterpret_cast<const uint4*>(sv + (ks >> 2) * TILE_B + swz_off(t * 32 + fr, (ks & 3) * 2 + fh));
         s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
         dp[t] = Half16<T>::mfma32(vf, dof[ks], dp[t]);
       }
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const uint4 ktf = tr_frag(sk_lds, tro, d, ks);        // K^T[32 d .. + 32][keys 16 ks .. + 16] out of the row-major K tile
+      for (int d = 0; d < 2 * NH; ++d) {
+        const uint4 ktf = tr_frag(sk_lds + (d >> 1) * TILE_B, tro, d & 1, ks);      // K^T[32 d .. + 32][keys 16 ks .. + 16] out of the row-major K tiles
         acc[d] = Half16<T>::mfma32(ktf, dsf[ks], acc[d]);
       }
     if (BIAS == 3) {
@@ -371,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
     __syncthreads();
   }
   if (q < T_) {
-    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + q) * E3 + h * 64;
+    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + q) * E3 + h * HDT;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint2 v;
@@ -422,15 +428,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdEncArgs a) {
 // BIAS: the rel-pos terms of (query register, key lane) are read straight from the fp32 term arrays (a fixed register = one query row:
 // the 64 keys of the wave read inside one <= 256-byte row of relh / relw)
 // BIAS 0: none.  1: the two terms of a score read from global memory (odd G: rows of 64 queries are not 16-byte aligned).  2: staged in LDS.
-template <typename T, int BIAS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
+template <typename T, int BIAS, int NH>
+__global__ __launch_bounds__(256, (NH == 1 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Q rows | dO rows (both read by rows and transposed) | LSE (64 floats) | D (64 floats) | BIAS: the rel-pos terms of the tile's 64
   // queries - relw rows [64][G] fp32 (16 KiB at G = 64) and relh: [64][G] for G <= 32, the 4-column group that holds this workgroup's
   // two key rows [64][4] for G = 64 (a workgroup = 128 keys = two key rows) - staged by LDS-DMA like the tiles (round 4 read two terms per
   // score from global memory: 64 vector-memory instructions per tile and wave)
   constexpr int BIAS_B = BIAS == 2 ? 16384 + 1024 : 0;      // G = 64: relw 16 KiB + relh 1 KiB; G <= 32: relw <= 8 KiB, relh <= 8 KiB behind it
-  constexpr int STAGE = 2 * TILE_B + 512 + BIAS_B;
+  constexpr int STAGE = 2 * NH * TILE_B + 512 + BIAS_B;      // (NH tiles of 64 dims each for Q and for dO)
+  constexpr int HDT = 64 * NH, KS = 4 * NH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   int bh, kblk;
@@ -441,11 +448,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   const int key = kblk * 128 + wave * 32 + fr, kc = min(key, T_ - 1);
   const float c2 = a.scale * 1.44269504088896340736f;
 
-  uint4 kf[4], vf[4];
+  uint4 kf[KS], vf[KS];
   {
-    const T* pk = qkv + ((size_t)b * T_ + kc) * E3 + a.E + h * 64 + fh * 8;
+    const T* pk = qkv + ((size_t)b * T_ + kc) * E3 + a.E + h * HDT + fh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       kf[ks] = *reinterpret_cast<const uint4*>(pk + ks * 16);
       vf[ks] = *reinterpret_cast<const uint4*>(pk + a.E + ks * 16);
     }
@@ -460,20 +467,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   const long rel_total = (long)a.B * a.heads * T_ * G;                          // floats in relh / relw
   const int relh_at = G == 64 ? 16384 : 8192;                                   // byte offset of the staged relh block behind relw
   const unsigned lds0 = lds_addr_of(smem);
-  const T* qbase = qkv + (size_t)b * T_ * E3 + h * 64;
-  const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * 64;
+  const T* qbase = qkv + (size_t)b * T_ * E3 + h * HDT;
+  const T* dobase = reinterpret_cast<const T*>(a.dout) + (size_t)b * T_ * a.E + h * HDT;
   const float* lseb = a.lse + (size_t)bh * a.Tpad;
   const float* dvb = a.dvec + (size_t)bh * a.Tpad;
   auto dma = [&](int i, int stage) {
     const unsigned s0 = lds0 + stage * STAGE;
-    stage_rows_p<T>(qbase, E3, i * 64, T_ - 1, s0, wave, lane);
-    stage_rows_p<T>(dobase, a.E, i * 64, T_ - 1, s0 + TILE_B, wave, lane);
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      stage_rows_p<T>(qbase + hh * 64, E3, i * 64, T_ - 1, s0 + hh * TILE_B, wave, lane);
+      stage_rows_p<T>(dobase + hh * 64, a.E, i * 64, T_ - 1, s0 + (NH + hh) * TILE_B, wave, lane);
+    }
     // the 64 LSE / D values of the query tile: 16 lanes x 16 bytes each (wave 0: LSE, wave 1: D); every wave issues the same
     // NUMBER of pieces per tile only matters for counted waits - this kernel waits for all of them (dma_wait<0>)
-    if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 2 * TILE_B + wave * 256);
+    if (wave < 2 && lane < 16) dma16((wave == 0 ? lseb : dvb) + i * 64 + lane * 4, s0 + 2 * NH * TILE_B + wave * 256);
     if (stage_bias) {
       const long row0 = (long)bh * T_ + i * 64;                // (rows beyond T: whatever follows in the array - their probabilities are 0)
-      const unsigned sb = s0 + 2 * TILE_B + 512;
+      const unsigned sb = s0 + 2 * NH * TILE_B + 512;
       const int npw = (64 * G * 4 + 1023) >> 10;               // 1 KiB pieces of the relw block [64][G] (contiguous rows)
       for (int pc = wave; pc < npw; pc += 4) {
         const long off = min(row0 * G + pc * 256 + lane * 4, rel_total - 4);
@@ -492,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
   unsigned tro[2][2];
   tr_offsets(lane, tro);
 
-  f32x16 dv[2], dk[2];
+  f32x16 dv[2 * NH], dk[2 * NH];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[d][r] = dk[d][r] = 0.f;
 
@@ -514,11 +524,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
       continue;
     }
     const char* sq = smem + (it & 1) * STAGE;
-    const char* sdo = sq + TILE_B;
-    const unsigned sq_lds = lds0 + (it & 1) * STAGE, sdo_lds = sq_lds + TILE_B;
-    const float* slse = reinterpret_cast<const float*>(sq + 2 * TILE_B);
+    const char* sdo = sq + NH * TILE_B;
+    const unsigned sq_lds = lds0 + (it & 1) * STAGE, sdo_lds = sq_lds + NH * TILE_B;
+    const float* slse = reinterpret_cast<const float*>(sq + 2 * NH * TILE_B);
     const float* sdv = slse + 64;
-    const float* srw = reinterpret_cast<const float*>(sq + 2 * TILE_B + 512);
+    const float* srw = reinterpret_cast<const float*>(sq + 2 * NH * TILE_B + 512);
     const float* srh = srw + relh_at / 4;
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -526,9 +536,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = dp[t][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint4 qf = *reinterpret_cast<const uint4*>(sq + swzp_off(t * 32 + fr, ks * 2 + fh));
-        const uint4 df = *reinterpret_cast<const uint4*>(sdo + swzp_off(t * 32 + fr, ks * 2 + fh));
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 qf = *reinterpret_cast<const uint4*>(sq + (ks >> 2) * TILE_B + swzp_off(t * 32 + fr, (ks & 3) * 2 + fh));
+        const uint4 df = *reinterpret_cast<const uint4*>(sdo + (ks >> 2) * TILE_B + swzp_off(t * 32 + fr, (ks & 3) * 2 + fh));
         s[t] = Half16<T>::mfma32(qf, kf[ks], s[t]);          // S[i][j]: lane = key j, registers = queries
         dp[t] = Half16<T>::mfma32(df, vf[ks], dp[t]);        // dP[i][j]
       }
@@ -564,9 +574,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const uint4 dotf = tr_frag(sdo_lds, tro, d, ks);      // dO^T / Q^T[32 d .. + 32][queries 16 ks .. + 16] out of the row-major tiles
-        const uint4 qtf = tr_frag(sq_lds, tro, d, ks);
+      for (int d = 0; d < 2 * NH; ++d) {
+        const uint4 dotf = tr_frag(sdo_lds + (d >> 1) * TILE_B, tro, d & 1, ks);      // dO^T / Q^T[32 d .. + 32][queries 16 ks .. + 16] out of the row-major tiles
+        const uint4 qtf = tr_frag(sq_lds + (d >> 1) * TILE_B, tro, d & 1, ks);
         dv[d] = Half16<T>::mfma32(dotf, pf[ks], dv[d]);      // dV^T[d][j] += dO^T[d][i] P[i][j]
         dk[d] = Half16<T>::mfma32(qtf, dsf[ks], dk[d]);      // dK^T[d][j] += Q^T[d][i] dS[i][j]
       }
@@ -574,9 +584,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdEncArgs a) 
     __syncthreads();
   }
   if (key < T_) {
-    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + key) * E3 + a.E + h * 64;
+    T* op = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * T_ + key) * E3 + a.E + h * HDT;
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         uint2 vk, vv;
@@ -629,24 +639,29 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
 }
 
 // launch both backward kernels (dq first: it writes D); bias 0 plain, 1 rel-pos G <= 32, 2 rel-pos G == 64
+template <typename T, int BIAS, int NH>
+static void launch_attn_bwd_nh(const AttnBwdEncArgs& a, hipStream_t st) {
+  const int nblk = (a.T + 127) / 128 * a.B * a.heads;
+  const int lds_dq = 2 * 2 * NH * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
+                                           : BIAS == 3 ? 32 * (a.Tpad * 2 + 16) + a.Tpad * (int)sizeof(int)
+                                                       : 0);
+  static unsigned long long m1 = 0, m2 = 0, m3 = 0;
+  ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS, NH>), 160 * 1024, m1);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, BIAS, NH>), dim3(nblk), dim3(256), lds_dq, st, a);
+  if (BIAS != 0 && (a.G & 1) == 0) {           // staged bias terms: even G (16-byte aligned rows of 64 queries)
+    constexpr int LDS_DKV = 2 * (2 * NH * TILE_B + 512 + 16384 + 1024);      // 67 KiB: two workgroups per CU (wide heads: 99 KiB, one)
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, 2, NH>), LDS_DKV, m3);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 2, NH>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+  } else {
+    constexpr int LDS_DKV = 2 * (2 * NH * TILE_B + 512);
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0), NH>), LDS_DKV, m2);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0), NH>), dim3(nblk), dim3(256), LDS_DKV, st, a);
+  }
+}
 template <typename T, int BIAS>
 static void launch_attn_bwd_t(const AttnBwdEncArgs& a, hipStream_t st) {
-  const int nblk = (a.T + 127) / 128 * a.B * a.heads;
-  const int lds_dq = 2 * 2 * TILE_B + (BIAS == 1   ? 4 * 4 * 32 * (a.G + 1) * (int)sizeof(float) + a.Tpad * (int)sizeof(int)
-                                      : BIAS == 3 ? 32 * (a.Tpad * 2 + 16) + a.Tpad * (int)sizeof(int)
-                                                  : 0);
-  static unsigned long long m1 = 0, m2 = 0, m3 = 0;
-  ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<T, BIAS>), 160 * 1024, m1);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, BIAS>), dim3(nblk), dim3(256), lds_dq, st, a);
-  if (BIAS != 0 && (a.G & 1) == 0) {           // staged bias terms: even G (16-byte aligned rows of 64 queries)
-    constexpr int LDS_DKV = 2 * (2 * TILE_B + 512 + 16384 + 1024);      // 67 KiB: two workgroups per CU
-    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, 2>), LDS_DKV, m3);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 2>), dim3(nblk), dim3(256), LDS_DKV, st, a);
-  } else {
-    constexpr int LDS_DKV = 2 * (2 * TILE_B + 512);
-    ensure_dyn_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0)>), LDS_DKV, m2);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, (BIAS != 0 ? 1 : 0)>), dim3(nblk), dim3(256), LDS_DKV, st, a);
-  }
+  if (a.E == a.heads * 128) launch_attn_bwd_nh<T, BIAS, 2>(a, st);
+  else launch_attn_bwd_nh<T, BIAS, 1>(a, st);
 }
 static void launch_attn_bwd(const AttnBwdEncArgs& a, int bias, int dt, hipStream_t st) {
   if (dt == LA_F16) {
@@ -688,7 +703,10 @@ template <typename T>
 __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                          const float* __restrict__ drelw, const float* __restrict__ tabh,
                                                          const float* __restrict__ tabw, float* __restrict__ dtabh, float* __restrict__ dtabw,
-                                                         int B, int heads, int G, int E, float gscale, int RY) {
+                                                         int B, int heads, int G, int E, float gscale, int RY, int c0) {
+  // (heads wider than 64 - zero-padded 80 -> 128: SAM ViT-H - are walked in 64-column blocks: every output column is its own problem; HDs =
+  // the head stride of the qkv rows AND the row stride of the fp32 tables, c0 = this launch's first column inside the head)
+  const int HDs = E / heads;
   // Four small products per query row on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: A lane (fr, fh) = A[row fr][k fh], B lane = B[k fh][col fr],
   // accumulator register r / lane = row (r & 3) + 8 (r >> 2) + 4 fh / column fr), operands gathered from LDS with the index arithmetic of
   // the decomposition (the vector-ALU form of round 4's first version spent 7.8 ms per SAM-B training step in these loops):
@@ -719,7 +737,7 @@ __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict_
   for (int y = yc * RY; y < min(G, yc * RY + RY); ++y) {
     const size_t row0 = (size_t)b * T_ + (size_t)y * G;
     __syncthreads();                                   // the previous row's readers are done (first row: the zero fill has landed)
-    for (int i = tid; i < G * 64; i += 256) sq[i] = qkv[(row0 + i / 64) * E3 + h * 64 + (i & 63)];
+    for (int i = tid; i < G * 64; i += 256) sq[i] = qkv[(row0 + i / 64) * E3 + h * HDs + c0 + (i & 63)];
     for (int i = tid; i < G * G; i += 256) {
       sdh[(i / G) * GS + i % G] = drelh[((size_t)bh * T_ + (size_t)y * G) * G + i];
       sdw[(i / G) * GS + i % G] = drelw[((size_t)bh * T_ + (size_t)y * G) * G + i];
@@ -733,15 +751,15 @@ __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict_
       const int x = ta * 32 + fr;
       mfma32_gather(acc, GP / 2,
                     [&](int s2) { const int kh = 2 * s2 + fh; return (x < G && kh < G) ? sdh[x * GS + kh] : 0.f; },
-                    [&](int s2) { const int kh = 2 * s2 + fh; return kh < G ? tabh[(size_t)(y - kh + G - 1) * 64 + dcol] : 0.f; });
+                    [&](int s2) { const int kh = 2 * s2 + fh; return kh < G ? tabh[(size_t)(y - kh + G - 1) * HDs + c0 + dcol] : 0.f; });
       mfma32_gather(acc, RP / 2,
                     [&](int s2) { const int r = 2 * s2 + fh, kw = x + G - 1 - r; return (x < G && r < NREL && kw >= 0 && kw < G) ? sdw[x * GS + kw] : 0.f; },
-                    [&](int s2) { const int r = 2 * s2 + fh; return r < NREL ? tabw[(size_t)r * 64 + dcol] : 0.f; });
+                    [&](int s2) { const int r = 2 * s2 + fh; return r < NREL ? tabw[(size_t)r * HDs + c0 + dcol] : 0.f; });
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int xo = ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
         if (xo < G) {
-          T* p = dqkv + (row0 + xo) * E3 + h * 64 + dcol;
+          T* p = dqkv + (row0 + xo) * E3 + h * HDs + c0 + dcol;
           *p = (T)((float)*p + acc[r]);
         }
       }
@@ -772,7 +790,7 @@ __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict_
   }
   __syncthreads();
   // (gscale is a plain multiplier: the caller's buffers carry the loss scale like every other gradient of the backward pass)
-  for (int i = tid; i < NREL * 64; i += 256) atomicAdd(&dtabh[i], sah[i] * gscale);
+  for (int i = tid; i < NREL * 64; i += 256) atomicAdd(&dtabh[(size_t)(i >> 6) * HDs + c0 + (i & 63)], sah[i] * gscale);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int t = wave + 4 * ti;
@@ -781,7 +799,7 @@ __global__ __launch_bounds__(256, 3) void relpos_bwd_kernel(const T* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ro = tr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (ro < NREL) atomicAdd(&dtabw[(size_t)ro * 64 + tc], accw[ti][r] * gscale);
+        if (ro < NREL) atomicAdd(&dtabw[(size_t)ro * HDs + c0 + tc], accw[ti][r] * gscale);
       }
     }
   }
@@ -802,7 +820,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, const float* __restrict__ drelh,
                                                                  const float* __restrict__ drelw, const float* __restrict__ tabh,
                                                                  const float* __restrict__ tabw, float* __restrict__ dtabh,
-                                                                 float* __restrict__ dtabw, int B, int heads, int G, int E, float gscale) {
+                                                                 float* __restrict__ dtabw, int B, int heads, int G, int E, float gscale, int c0) {
+  const int HDs = E / heads;                          // (head stride = table row stride; c0: see relpos_bwd_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 31, fh = lane >> 5;
   const int T_ = G * G, E3 = 3 * E, NREL = 2 * G - 1, NS = (NREL + 1) >> 1;
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __rest
   T* sq = reinterpret_cast<T*>(sdw + 32 * G);                                     // [32][64] q rows
   for (int i = tid; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = c & 31;
-    stab[i] = r < NREL ? (c < 32 ? tabh : tabw)[r * 64 + (i & 63)] : 0.f;
+    stab[i] = r < NREL ? (c < 32 ? tabh : tabw)[r * HDs + c0 + (i & 63)] : 0.f;
   }
   __syncthreads();
   f32x16 dR[2][2];
@@ -837,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __rest
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int row = (lane >> 3) + 8 * p;
-        uint4 v = *reinterpret_cast<const uint4*>(qkv + ((size_t)b * T_ + min(q0 + row, T_ - 1)) * E3 + h * 64 + (lane & 7) * 8);
+        uint4 v = *reinterpret_cast<const uint4*>(qkv + ((size_t)b * T_ + min(q0 + row, T_ - 1)) * E3 + h * HDs + c0 + (lane & 7) * 8);
         if (q0 + row >= T_) v = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(sq + row * 64 + (lane & 7) * 8) = v;
       }
@@ -864,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __rest
       }
     }
     if (q < T_) {
-      T* p = dqkv + ((size_t)b * T_ + q) * E3 + h * 64;
+      T* p = dqkv + ((size_t)b * T_ + q) * E3 + h * HDs + c0;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -910,7 +929,7 @@ __global__ __launch_bounds__(256, 2) void relpos_bwd_rows_kernel(const T* __rest
   __syncthreads();
   for (int i = tid; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = c & 31;
-    if (r < NREL) atomicAdd(&(c < 32 ? dtabh : dtabw)[r * 64 + (i & 63)], stab[i] * gscale);
+    if (r < NREL) atomicAdd(&(c < 32 ? dtabh : dtabw)[r * HDs + c0 + (i & 63)], stab[i] * gscale);
   }
 }
 
@@ -934,7 +953,8 @@ extern "C" int la_head_transpose(const void* src, int ld, int col0, int B, int h
 extern "C" int la_attn_bwd(const void* qkv, const void* out16, const void* dout16, const void* kt, const void* qt, const void* dot, float* lse,
                            float* dvec, void* dqkv, int B, int heads, int T, int Tpad, int E, float scale, int dt, void* stream) {
   LA_CHECK_ARG(qkv && out16 && dout16 && lse && dvec && dqkv, "la_attn_bwd: null pointer");      // (kt / qt / dot: unused since round 5)
-  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_bwd: needs head_dim 64 or 128 - other widths zero-padded (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd: bad dtype %d", dt);
   la::AttnBwdEncArgs a{qkv, dout16, out16, kt, qt, dot, lse, dvec, dqkv, B, heads, T, Tpad, E, scale, nullptr, nullptr, nullptr, nullptr, 0};
@@ -947,7 +967,8 @@ extern "C" int la_attn_bwd_relpos(const void* qkv, const void* out16, const void
                                   float* lse, float* dvec, void* dqkv, const float* relh, const float* relw, float* drelh, float* drelw, int B,
                                   int heads, int T, int Tpad, int G, int E, float scale, int dt, void* stream) {
   LA_CHECK_ARG(qkv && out16 && dout16 && lse && dvec && dqkv && relh && relw && drelh && drelw, "la_attn_bwd_relpos: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_bwd_relpos: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_bwd_relpos: needs head_dim 64 or 128 - other widths zero-padded (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_bwd_relpos: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(G * G == T && (G <= 32 || G == 64), "la_attn_bwd_relpos: T == G*G with G <= 32 or G == 64 (T=%d G=%d)", T, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_bwd_relpos: bad dtype %d", dt);
@@ -960,19 +981,23 @@ extern "C" int la_attn_bwd_relpos(const void* qkv, const void* out16, const void
 extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, const float* drelw, const float* tabh, const float* tabw,
                              float* dtabh, float* dtabw, int B, int heads, int G, int E, float gscale, int dt, void* stream) {
   LA_CHECK_ARG(qkv && dqkv && drelh && drelw && tabh && tabw && dtabh && dtabw, "la_relpos_bwd: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && E == heads * 64, "la_relpos_bwd: needs head_dim 64, G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
+  LA_CHECK_ARG(B > 0 && heads > 0 && G > 0 && G <= 64 && (E == heads * 64 || E == heads * 128),
+               "la_relpos_bwd: needs head_dim 64 or 128 (tables [(2 G - 1), head_dim] fp32), G <= 64 (E=%d heads=%d G=%d)", E, heads, G);
+  const int hdw = E / heads;
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_relpos_bwd: bad dtype %d", dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (G <= 16) {                                     // the windows: dense products over units of 32 queries
     const int lds_rows = 64 * 64 * (int)sizeof(float) + 4 * (2 * 32 * G * (int)sizeof(float) + 32 * 64 * 2);
     const int nunits = B * heads * ((G * G + 31) / 32);
     const int grid_rows = nunits / 4 < 512 ? (nunits + 3) / 4 : 512;          // (256 / 512 / 768 workgroups on 100 x 12 windows: 135 / 117 / 132 us)
-    if (dt == LA_F16)
-      hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::f16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv,
-                         drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
-    else
-      hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::bf16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::bf16_t*)qkv,
-                         (la::bf16_t*)dqkv, drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale);
+    for (int c0 = 0; c0 < hdw; c0 += 64) {
+      if (dt == LA_F16)
+        hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::f16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv,
+                           drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, c0);
+      else
+        hipLaunchKernelGGL(la::relpos_bwd_rows_kernel<la::bf16_t>, dim3(grid_rows), dim3(256), lds_rows, st, (const la::bf16_t*)qkv,
+                           (la::bf16_t*)dqkv, drelh, drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, c0);
+    }
     LA_CHECK_LAUNCH("la_relpos_bwd");
     return 0;
   }
@@ -985,14 +1010,16 @@ extern "C" int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, co
   while (G > 32 && ry < G && (long)B * heads * ((G + 2 * ry - 1) / (2 * ry)) >= 768) ry *= 2;
   const int grid = B * heads * ((G + ry - 1) / ry);
   static unsigned long long m1 = 0, m2 = 0;
-  if (dt == LA_F16) {
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::f16_t>), 80 * 1024, m1);
-    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(grid), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
-                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry);
-  } else {
-    la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::bf16_t>), 80 * 1024, m2);
-    hipLaunchKernelGGL(la::relpos_bwd_kernel<la::bf16_t>, dim3(grid), dim3(256), lds, st, (const la::bf16_t*)qkv, (la::bf16_t*)dqkv, drelh,
-                       drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry);
+  for (int c0 = 0; c0 < hdw; c0 += 64) {
+    if (dt == LA_F16) {
+      la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::f16_t>), 80 * 1024, m1);
+      hipLaunchKernelGGL(la::relpos_bwd_kernel<la::f16_t>, dim3(grid), dim3(256), lds, st, (const la::f16_t*)qkv, (la::f16_t*)dqkv, drelh,
+                         drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry, c0);
+    } else {
+      la::ensure_dyn_lds(reinterpret_cast<const void*>(la::relpos_bwd_kernel<la::bf16_t>), 80 * 1024, m2);
+      hipLaunchKernelGGL(la::relpos_bwd_kernel<la::bf16_t>, dim3(grid), dim3(256), lds, st, (const la::bf16_t*)qkv, (la::bf16_t*)dqkv, drelh,
+                         drelw, tabh, tabw, dtabh, dtabw, B, heads, G, E, gscale, ry, c0);
+    }
   }
   LA_CHECK_LAUNCH("la_relpos_bwd");
   return 0;

@@ -1140,7 +1140,8 @@ extern "C" int la_attn_fwd_rows(const void* qkv, void* out16, const void* tabh, 
 extern "C" int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, float* lse, int B, int heads, int T, int Tpad, int E, float scale,
                                int dt, void* stream) {
   LA_CHECK_ARG(qkv && vt && out16 && lse, "la_attn_fwd_lse: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_fwd_lse: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_fwd_lse: needs head_dim 64 or 128 - other widths zero-padded (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_lse: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_lse: bad dtype %d", dt);
   la::AttnArgs a{qkv, vt, out16, nullptr, nullptr, nullptr, nullptr, B, heads, T, Tpad, 0, E, scale, lse};
@@ -1154,7 +1155,8 @@ extern "C" int la_attn_fwd_lse(const void* qkv, const void* vt, void* out16, flo
 extern "C" int la_attn_fwd_relpos_lse(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, float* lse, int B, int heads,
                                       int T, int Tpad, int G, int E, float scale, int dt, void* stream) {
   LA_CHECK_ARG(qkv && vt && out16 && relh && relw && lse, "la_attn_fwd_relpos_lse: null pointer");
-  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && E == heads * 64, "la_attn_fwd_relpos_lse: needs head_dim 64 (E=%d heads=%d)", E, heads);
+  LA_CHECK_ARG(B > 0 && heads > 0 && T > 0 && (E == heads * 64 || E == heads * 128),
+               "la_attn_fwd_relpos_lse: needs head_dim 64 or 128 - other widths zero-padded (E=%d heads=%d)", E, heads);
   LA_CHECK_ARG(Tpad >= T && (Tpad % 64) == 0, "la_attn_fwd_relpos_lse: Tpad=%d must be a multiple of 64 covering T=%d", Tpad, T);
   LA_CHECK_ARG(G > 0 && G <= 64 && G * G == T, "la_attn_fwd_relpos_lse: rel-pos needs T == G*G, G <= 64 (T=%d G=%d)", T, G);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16, "la_attn_fwd_relpos_lse: bad dtype %d", dt);

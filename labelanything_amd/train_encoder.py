@@ -20,8 +20,12 @@ the flat gradient buffer (non-finite results: the step is repeated with a smalle
   LayerNorm, GELU  la_layernorm_bwd, la_gelu_bwd16
   SAM stack         la_relpos_terms + la_attn_fwd_relpos_lse / la_attn_bwd_relpos + la_relpos_bwd (window and global attention with the
                     decomposed rel-pos bias; gradients of rel_pos_h / rel_pos_w), windows as row gathers - see SamEncoderGraph
-Scope: 64-wide heads - ViT-MAE-B / -L, DINO, IN21k (cfg3, cfg5) and SAM ViT-B / -L; rel-pos tables of the block's own grid (training through
-get_rel_pos's resampling is applied as its fixed linear map and that map's transpose).
+Heads: 64 wide (ViT-MAE-B / -L, DINO, IN21k - cfg3, cfg5 -, SAM ViT-B / -L) natively; other widths up to 128 run ZERO-PADDED to 64 / 128
+columns per head exactly as in the inference engine (``LamEngine.head_pad``: SAM ViT-H's 80 -> 128, build_encoder.py:9-28; 32-wide test
+encoders -> 64): the packed q | k | v weights emit padded heads, the attention kernels (forward and backward, NH = 1 or 2 halves of 64) see
+E_attn = heads * padded width, the padded columns of q, k, v, O and of every gradient are exactly zero, and the weight / bias / rel-pos
+table gradients are computed on the padded shapes and folded back onto the parameters' own rows and columns.  Rel-pos tables of another
+grid: get_rel_pos's resampling is applied as its fixed linear map and that map's transpose.
 """
 from __future__ import annotations
 
@@ -55,8 +59,9 @@ class HfEncoderGraph:
         if spec is None or spec.kind != self.KIND:
             raise NotImplementedError(f"{type(self).__name__} is the backward of the {self.KIND!r} encoder stack (HfEncoderGraph: ViT-MAE / DINO / "
                                       "IN21k; SamEncoderGraph: the SAM ViTDet stack)")
-        if spec.head_dim != 64:
-            raise NotImplementedError(f"encoder backward needs 64-wide heads (got {spec.head_dim})")
+        self.hdp = 64 * ((spec.head_dim + 63) // 64)          # head width the attention kernels run (zero-padded columns beyond head_dim)
+        if self.hdp > 128:
+            raise NotImplementedError(f"encoder backward: heads wider than 128 are not built (got {spec.head_dim})")
         self.lam, self.spec, self.grads = lam, spec, grads
         # private engine: the encoder's packed weights under the TRAINING numerics (precise), re-packed after every optimizer step;
         # the caller's ``lam.precise`` / inference engine are not touched
@@ -144,19 +149,21 @@ class HfEncoderGraph:
                map=L.MAP_GROUP, p=(hw, t, 1, 0, 0), **akw)
         scale = spec.head_dim ** -0.5
         layers: List[dict] = []
-        vt = torch.zeros(bn * heads, 64, tpad, device=dev, dtype=dt)
+        hdp = self.hdp
+        ea, nh = heads * hdp, hdp // 64             # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
+        vt = torch.zeros(bn * heads, hdp, tpad, device=dev, dtype=dt)
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             sv = {"x_in": res}                       # (the stream is never updated in place: every residual GEMM writes a new buffer,
             x16 = torch.empty(rows, e, device=dev, dtype=dt)      # which is also the activation the backward keeps)
             sv["xn"] = x16                           # the weight gradients take the 16-bit LayerNorm output the GEMMs saw
             eng.ln(res, lp + ".layernorm_before", 1e-12, out16=x16)
-            sv["qkv"] = torch.empty(rows, 3 * e, device=dev, dtype=dt)
-            self._qkv_plain(eng, x16, lp + ".qkv.w", sv["qkv"], e)
-            L.head_transpose(sv["qkv"], 2 * e, bn, heads, t, tpad, vt)
-            sv["ao"] = torch.empty(rows, e, device=dev, dtype=dt)
+            sv["qkv"] = torch.empty(rows, 3 * ea, device=dev, dtype=dt)
+            self._qkv_plain(eng, x16, lp + ".qkv.w", sv["qkv"], ea)
+            L.head_transpose(sv["qkv"], 2 * ea, bn, heads * nh, t, tpad, vt)        # (a 128-wide head = two 64-row blocks of V^T)
+            sv["ao"] = torch.empty(rows, ea, device=dev, dtype=dt)
             sv["lse"] = torch.full((bn * heads, tpad), 1e30, device=dev)
-            L.attn_fwd_lse(sv["qkv"], vt, sv["ao"], sv["lse"], bn, heads, t, tpad, e, scale)
+            L.attn_fwd_lse(sv["qkv"], vt, sv["ao"], sv["lse"], bn, heads, t, tpad, ea, scale)
             x_mid = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["ao"], lp + ".o.w", bias=w[lp + ".attention.output.dense.bias"], res=res, out32=x_mid)
             sv["x_mid"] = x_mid
@@ -173,7 +180,7 @@ class HfEncoderGraph:
         fin = torch.empty(rows, e, device=dev)
         eng.ln(res, pre + ".layernorm", 1e-12, out32=fin)
         out = fin.view(bn, t, e)[:, 1:].reshape(bn * hw, e).contiguous()
-        self.ctx = dict(images=images, layers=layers, x_fin=res, bn=bn, g=g, hw=hw, t=t, rows=rows, tpad=tpad, e=e, heads=heads,
+        self.ctx = dict(images=images, layers=layers, x_fin=res, bn=bn, g=g, hw=hw, t=t, rows=rows, tpad=tpad, e=e, ea=ea, heads=heads,
                         scale=scale, dt=dt)
         return out
 
@@ -262,15 +269,56 @@ class HfEncoderGraph:
             self._tbufs[key] = t
         return t
 
-    def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x, wname: str, bname: str, dx32=None, dx16=None) -> None:
-        """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K]); x: the layer's input, any dtype."""
+    def _linear_bwd(self, dy32: Tensor, dy16: Tensor, x, wname: str, bname: str, dx32=None, dx16=None, pad_in: bool = False,
+                    pad_out: int = 0) -> None:
+        """dW += dY^T X, db += colsum(dY), dX = dY W for one nn.Linear (weight ``wname`` [N, K]); x: the layer's input, any dtype.
+        pad_in: x carries zero-padded heads (the attention output); pad_out = number of head blocks of dY that are zero-padded (q | k | v)."""
         wt = self.w[wname]
-        if not self._wgrad(dy16, dy32, x, self.sviews[wname], db=self.sviews[bname]):
+        if pad_in or pad_out:
+            wt_fn = lambda: self._pad_weight(wt, pad_in, pad_out)           # noqa: E731
+            n, k = dy16.shape[1], x.shape[1]
+            dwp = self._tbuf("dw_pad", n, k, torch.float32)
+            dbp = self._tbuf("db_pad", 1, n, torch.float32).view(n)
+            dwp.zero_()
+            dbp.zero_()
+        else:
+            wt_fn = lambda: wt                                              # noqa: E731
+            dwp, dbp = self.sviews[wname], self.sviews[bname]
+        if not self._wgrad(dy16, dy32, x, dwp, db=dbp):
             if dy32 is None:
                 dy32 = self._tbuf("dy32b", dy16.shape[0], dy16.shape[1], torch.float32)
                 L.cast(dy16.contiguous(), dy32)
-            L.colsum_acc(dy32, self.sviews[bname])
-        L.gemm(dy16, self._wt16(wname, lambda: wt, dy16.dtype), out32=dx32, out16=dx16)
+            L.colsum_acc(dy32, dbp)
+        if pad_in or pad_out:
+            self._fold_padded(dwp, dbp, self.sviews[wname], self.sviews[bname], pad_in, pad_out)
+        L.gemm(dy16, self._wt16(wname, wt_fn, dy16.dtype), out32=dx32, out16=dx16)
+
+    # ---- zero-padded heads (head_dim not a multiple of 64) -----------------------------------------------------------------------
+    def _pad_weight(self, wt: Tensor, pad_in: bool, pad_out: int) -> Tensor:
+        """The nn.Linear weight as the padded-head GEMMs see it: zero rows appended to each of the ``pad_out`` head blocks of the output
+        dimension (q | k | v producers), zero columns to each head block of the input dimension (``pad_in``: the attention-output consumer)."""
+        from .engine import LamEngine
+        hd, hdp, heads = self.spec.head_dim, self.hdp, self.spec.heads
+        wt = wt.detach().reshape(wt.shape[0], -1)
+        if pad_out:
+            wt = LamEngine._pad_heads_out(wt, pad_out, hd, hdp)
+        if pad_in:
+            wt = LamEngine._pad_heads_in(wt, heads, hd, hdp)
+        return wt
+
+    def _fold_padded(self, dwp: Tensor, dbp: Optional[Tensor], dw: Tensor, db: Optional[Tensor], pad_in: bool, pad_out: int) -> None:
+        """Gradients computed on the padded shapes -> the parameters' own rows / columns (the padded ones multiply zeros: dropped)."""
+        hd, hdp, heads = self.spec.head_dim, self.hdp, self.spec.heads
+        g = dwp
+        if pad_out:
+            g = g.view(pad_out, hdp, -1)[:, :hd].reshape(pad_out * hd, -1)
+            if dbp is not None:
+                db.view(-1).add_(dbp.view(pad_out, hdp)[:, :hd].reshape(-1))
+        elif dbp is not None:
+            db.view(-1).add_(dbp.view(-1))
+        if pad_in:
+            g = g.view(g.shape[0], heads, hdp)[:, :, :hd].reshape(g.shape[0], heads * hd)
+        dw.view(g.shape).add_(g)
 
     @torch.no_grad()
     def backward(self, d_out: Tensor) -> None:
@@ -320,6 +368,7 @@ class HfEncoderGraph:
         spec, w, sv = self.spec, self.w, self.sviews
         pre = "image_encoder"
         bn, t, hw, rows, tpad, e, heads, dt = c["bn"], c["t"], c["hw"], c["rows"], c["tpad"], c["e"], c["heads"], c["dt"]
+        ea, padded = c["ea"], c["ea"] != c["e"]
         dev = d_out.device
         dfin = torch.zeros(rows, e, device=dev)
         tmp = torch.empty_like(d_out)
@@ -335,9 +384,9 @@ class HfEncoderGraph:
         dpre32 = torch.empty(rows, spec.mlp, device=dev)
         dpre16 = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
         dxn = torch.empty(rows, e, device=dev)
-        dao = torch.empty(rows, e, device=dev, dtype=dt)
-        dqkv16 = torch.empty(rows, 3 * e, device=dev, dtype=dt)
-        dqkv32 = torch.empty(rows, 3 * e, device=dev)
+        dao = torch.empty(rows, ea, device=dev, dtype=dt)
+        dqkv16 = torch.empty(rows, 3 * ea, device=dev, dtype=dt)
+        dqkv32 = torch.empty(rows, 3 * ea, device=dev)
         dvec = torch.zeros(bn * heads, tpad, device=dev)
         for i in reversed(range(spec.depth)):
             lp = f"{pre}.encoder.layer.{i}"
@@ -352,18 +401,30 @@ class HfEncoderGraph:
             L.layernorm_bwd_res(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, dres, dres, d16,
                                 sv[lp + ".layernorm_after.weight"], sv[lp + ".layernorm_after.bias"])
             # ---- attention: x_mid = x_in + proj(attn(LN1(x_in))) -------------------------------------------------------------
-            self._linear_bwd(dres, d16, a["ao"], lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao)
+            self._linear_bwd(dres, d16, a["ao"], lp + ".attention.output.dense.weight", lp + ".attention.output.dense.bias", dx16=dao,
+                             pad_in=padded)
             # (no K^T / Q^T / dO^T copies: the backward kernels read those operands out of the row-major tiles with LDS transpose reads)
-            L.attn_bwd(a["qkv"], a["ao"], dao, None, None, None, a["lse"], dvec, dqkv16, bn, heads, t, tpad, e, c["scale"])
+            L.attn_bwd(a["qkv"], a["ao"], dao, None, None, None, a["lse"], dvec, dqkv16, bn, heads, t, tpad, ea, c["scale"])
             att = lp + ".attention.attention."
             have32 = False
-            for j, nm in enumerate(() if self._qkv_wgrad_fused(dqkv16, a["xn"], att, e) else ("query", "key", "value")):
-                if not self._wgrad(dqkv16[:, j * e:(j + 1) * e], None, a["xn"], sv[att + nm + ".weight"], db=sv[att + nm + ".bias"]):
+            fused = not padded and self._qkv_wgrad_fused(dqkv16, a["xn"], att, e)
+            for j, nm in enumerate(() if fused else ("query", "key", "value")):
+                if padded:
+                    dwp = self._tbuf("dw_pad_qkv", ea, e, torch.float32)
+                    dbp = self._tbuf("db_pad_qkv", 1, ea, torch.float32).view(ea)
+                    dwp.zero_()
+                    dbp.zero_()
+                else:
+                    dwp, dbp = sv[att + nm + ".weight"], sv[att + nm + ".bias"]
+                if not self._wgrad(dqkv16[:, j * ea:(j + 1) * ea], None, a["xn"], dwp, db=dbp):
                     if not have32:                    # (exact-fp32 fallback of the weight gradient: it needs the fp32 copy)
                         L.cast(dqkv16, dqkv32)
                         have32 = True
-                    L.colsum_acc(dqkv32[:, j * e:(j + 1) * e], sv[att + nm + ".bias"])
-            wqkv_t = self._wt16(att + "qkv", lambda: torch.cat([w[att + "query.weight"], w[att + "key.weight"], w[att + "value.weight"]]), dt)
+                    L.colsum_acc(dqkv32[:, j * ea:(j + 1) * ea], dbp)
+                if padded:
+                    self._fold_padded(dwp, dbp, sv[att + nm + ".weight"], sv[att + nm + ".bias"], False, heads)
+            wqkv_t = self._wt16(att + "qkv", lambda: torch.cat([self._pad_weight(w[att + nm + ".weight"], False, heads if padded else 0)
+                                                                for nm in ("query", "key", "value")]), dt)
             L.gemm(dqkv16, wqkv_t, out32=dxn)                                                                  # [3E, E]^T
             L.layernorm_bwd_res(a["x_in"], dxn, w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"], 1e-12, dres, dres, d16,
                                 sv[lp + ".layernorm_before.weight"], sv[lp + ".layernorm_before.bias"])
@@ -435,14 +496,26 @@ class SamEncoderGraph(HfEncoderGraph):
         pushing the identity through the same call (as ``bicubic_matrix_t`` does for the HF position table): the backward runs on
         R . table and adds R^T . d(R . table) to the slot (exact-fp32 MFMA products, la_gemm_tn)."""
         w, sv = self.w, self.sviews
-        tabs, dtabs, folds = [], [], []
+        tabs, dtabs, folds, unpads = [], [], [], []
+        hdp = self.hdp
+
+        def padded(tab: Tensor, slot: Tensor):
+            """Zero-padded heads: the kernels walk tables [(2 gg - 1), hdp]; the gradient's first head_dim columns are the table's."""
+            if tab.shape[1] == hdp:
+                return tab, slot
+            tp = torch.nn.functional.pad(tab, (0, hdp - tab.shape[1])).contiguous()
+            dp = torch.zeros_like(tp)
+            unpads.append((dp, slot))
+            return tp, dp
+
         for ax in ("h", "w"):
             key = f"{bp}.attn.rel_pos_{ax}"
             tab = w[key].detach()
             ln, hd = tab.shape
             if ln == 2 * gg - 1:
-                tabs.append(tab.contiguous())
-                dtabs.append(sv[key])
+                tp, dp = padded(tab.contiguous(), sv[key])
+                tabs.append(tp)
+                dtabs.append(dp)
                 continue
             rkey = ("relR", ln, gg)
             r = self._tbufs.get(rkey)
@@ -455,11 +528,14 @@ class SamEncoderGraph(HfEncoderGraph):
             used = torch.zeros(2 * gg - 1, hd, device=tab.device)
             L.gemm_tn(r[1], tab.contiguous(), used)                  # used = (R^T)^T tab = R . table
             dused = torch.zeros_like(used)
-            tabs.append(used)
-            dtabs.append(dused)
+            tp, dp = padded(used, dused)
+            tabs.append(tp)
+            dtabs.append(dp)
             folds.append((r[0], dused, sv[key]))
 
         def fold():
+            for dp, slot in unpads:
+                slot.add_(dp[:, : slot.shape[1]])
             for rm, du, slot in folds:
                 L.gemm_tn(rm, du, slot)                               # slot [L, hd] += R^T . d(R . table)
         return tabs, dtabs, fold
@@ -481,6 +557,8 @@ class SamEncoderGraph(HfEncoderGraph):
         res = torch.empty(rows, e, device=dev)
         L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
         scale = spec.head_dim ** -0.5
+        hdp = self.hdp
+        ea, nh = heads * hdp, hdp // 64             # (zero-padded heads: see HfEncoderGraph.forward)
         nw = (g + ws - 1) // ws
         layers: List[dict] = []
         for i in range(spec.depth):
@@ -500,16 +578,16 @@ class SamEncoderGraph(HfEncoderGraph):
                 xa = torch.zeros(arows, e, device=dev, dtype=dt)
                 xa.index_copy_(0, self._win_index(bn, g, ws, dev), x16)
             sv["xa"] = xa
-            sv["qkv"] = torch.empty(arows, 3 * e, device=dev, dtype=dt)
-            self._qkv_plain(eng, xa, bp + ".qkv.w", sv["qkv"], e)
+            sv["qkv"] = torch.empty(arows, 3 * ea, device=dev, dtype=dt)
+            self._qkv_plain(eng, xa, bp + ".qkv.w", sv["qkv"], ea)
             sv["relh"] = torch.empty(nb * heads, t, gg, device=dev)
             sv["relw"] = torch.empty(nb * heads, t, gg, device=dev)
-            L.relpos_terms(sv["qkv"], nb, heads, gg, e, p[bp + ".tabh"], p[bp + ".tabw"], sv["relh"], sv["relw"])
-            vt = torch.zeros(nb * heads, 64, tpad, device=dev, dtype=dt)
-            L.head_transpose(sv["qkv"], 2 * e, nb, heads, t, tpad, vt)
-            sv["ao"] = torch.empty(arows, e, device=dev, dtype=dt)
+            L.relpos_terms(sv["qkv"], nb, heads, gg, ea, p[bp + ".tabh"], p[bp + ".tabw"], sv["relh"], sv["relw"])
+            vt = torch.zeros(nb * heads, hdp, tpad, device=dev, dtype=dt)
+            L.head_transpose(sv["qkv"], 2 * ea, nb, heads * nh, t, tpad, vt)
+            sv["ao"] = torch.empty(arows, ea, device=dev, dtype=dt)
             sv["lse"] = torch.empty(nb * heads, tpad, device=dev)
-            L.attn_fwd_relpos_lse(sv["qkv"], vt, sv["ao"], sv["relh"], sv["relw"], sv["lse"], nb, heads, t, tpad, gg, e, scale)
+            L.attn_fwd_relpos_lse(sv["qkv"], vt, sv["ao"], sv["relh"], sv["relw"], sv["lse"], nb, heads, t, tpad, gg, ea, scale)
             x_mid = torch.empty(rows, e, device=dev)
             if is_global:
                 eng.gemm_w(sv["ao"], bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=x_mid)
@@ -528,7 +606,7 @@ class SamEncoderGraph(HfEncoderGraph):
             res = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["post"], bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=x_mid, out32=res)
             layers.append(sv)
-        self.ctx = dict(images=images, layers=layers, bn=bn, g=g, hw=hw, rows=rows, e=e, heads=heads, scale=scale, dt=dt, ws=ws)
+        self.ctx = dict(images=images, layers=layers, bn=bn, g=g, hw=hw, rows=rows, e=e, ea=ea, heads=heads, scale=scale, dt=dt, ws=ws)
         return res
 
     def _backward_scaled(self, d_out: Tensor, s: float) -> None:
@@ -539,6 +617,7 @@ class SamEncoderGraph(HfEncoderGraph):
         spec, w, sv = self.spec, self.w, self.sviews
         pre = "image_encoder"
         bn, g, hw, rows, e, heads, dt, ws = c["bn"], c["g"], c["hw"], c["rows"], c["e"], c["heads"], c["dt"], c["ws"]
+        ea, padded = c["ea"], c["ea"] != c["e"]
         dev = d_out.device
         dres = torch.empty(rows, e, device=dev)
         L.cast(d_out.contiguous(), dres, s)
@@ -567,22 +646,18 @@ class SamEncoderGraph(HfEncoderGraph):
                 dy16 = torch.zeros(arows, e, device=dev, dtype=dt)
                 dy16.index_copy_(0, widx, d16)
                 dy32 = None
-            dao = torch.empty(arows, e, device=dev, dtype=dt)
-            self._linear_bwd(dy32, dy16, a["ao"], bp + ".attn.proj.weight", bp + ".attn.proj.bias", dx16=dao)
+            dao = torch.empty(arows, ea, device=dev, dtype=dt)
+            self._linear_bwd(dy32, dy16, a["ao"], bp + ".attn.proj.weight", bp + ".attn.proj.bias", dx16=dao, pad_in=padded)
             dvec = torch.empty(nb * heads, tpad, device=dev)
-            dqkv16 = torch.empty(arows, 3 * e, device=dev, dtype=dt)
+            dqkv16 = torch.empty(arows, 3 * ea, device=dev, dtype=dt)
             drelh, drelw = torch.empty_like(a["relh"]), torch.empty_like(a["relw"])
             L.attn_bwd_relpos(a["qkv"], a["ao"], dao, None, None, None, a["lse"], dvec, dqkv16, a["relh"], a["relw"], drelh, drelw, nb, heads, t,
-                              tpad, gg, e, c["scale"])
+                              tpad, gg, ea, c["scale"])
             tabs, dtabs, fold = self._rel_tables(bp, gg)
-            L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, tabs[0], tabs[1], dtabs[0], dtabs[1], nb, heads, gg, e)
+            L.relpos_bwd(a["qkv"], dqkv16, drelh, drelw, tabs[0], tabs[1], dtabs[0], dtabs[1], nb, heads, gg, ea)
             fold()
-            if not self._wgrad(dqkv16, None, a["xa"], sv[bp + ".attn.qkv.weight"], db=sv[bp + ".attn.qkv.bias"]):
-                dq32 = self._tbuf("dqkv32", arows, 3 * e, torch.float32)
-                L.cast(dqkv16, dq32)
-                L.colsum_acc(dq32, sv[bp + ".attn.qkv.bias"])
             dxa = torch.empty(arows, e, device=dev)
-            L.gemm(dqkv16, self._wt16(bp + ".attn.qkv", lambda: w[bp + ".attn.qkv.weight"], dt), out32=dxa)
+            self._linear_bwd(None, dqkv16, a["xa"], bp + ".attn.qkv.weight", bp + ".attn.qkv.bias", dx32=dxa, pad_out=3 * heads if padded else 0)
             dxn_i = dxa if a["global"] else dxa.index_select(0, self._win_index(bn, g, ws, dev))
             L.layernorm_bwd_res(a["x_in"], dxn_i.contiguous(), w[bp + ".norm1.weight"], w[bp + ".norm1.bias"], 1e-6, dres, dres, d16,
                                 sv[bp + ".norm1.weight"], sv[bp + ".norm1.bias"])

@@ -14,6 +14,9 @@ register_encoder("sam_tiny", EncoderSpec("sam", dim=128, depth=2, heads=2, mlp=5
 register_encoder("hf_tiny", EncoderSpec("hf", dim=128, depth=2, heads=2, mlp=512, img_size=224))
 # 8x8 patches (facebook/dino-vitb8 style) and a wide SAM stack (ViT-L style: 1024 wide, 16 heads, 14x14 windows)
 register_encoder("hf_tiny_p8", EncoderSpec("hf", dim=128, depth=2, heads=2, mlp=512, patch=8, img_size=224))
+# heads that are not 64 wide: SAM ViT-H style 80-wide heads (zero-padded to 128 by the packed weights) and 32-wide HF heads (-> 64)
+register_encoder("sam_hd80_tiny", EncoderSpec("sam", dim=160, depth=2, heads=2, mlp=320, img_size=224, global_idx=(1,), window=8, out_chans=96))
+register_encoder("hf_hd32_tiny", EncoderSpec("hf", dim=128, depth=2, heads=4, mlp=512, img_size=224))
 register_encoder("sam_wide", EncoderSpec("sam", dim=1024, depth=2, heads=16, mlp=4096, img_size=448,
                                          global_idx=(1,), window=14, out_chans=256))
 
