@@ -103,7 +103,7 @@ class KernelTimer:
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
                  "attn_small_bwd", "bilinear_bwd", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
                  "attn_fwd_lse", "attn_bwd", "head_transpose", "cast", "gelu_bwd16", "axpy", "transpose16", "colmean16", "layernorm_g", "add_rowvec", "add_rowvec_split", "qk_fp8", "attn_fwd_fp8", "attn_fwd_cs", "colsum_fold", "gelu_fwd16",
-                 "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows"]
+                 "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows", "gemm_tn16"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -128,7 +128,7 @@ class KernelTimer:
                                                               + 4 * (kw.get("res") is not None and kw.get("res_mod", 0) == 0))
                     if kw.get("vt") is not None:
                         nbytes += esz * m * (n - kw.get("vt_col0", 0))
-                elif _n == "gemm_tn":
+                elif _n in ("gemm_tn", "gemm_tn16"):
                     flops = issued = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
                 elif _n == "attn_fwd":
                     b, heads, t = a[5], a[6], a[7]
@@ -148,13 +148,13 @@ class KernelTimer:
                 if _n in ("attn_small_bwd", "attn_small", "attn_small_lse", "layernorm_bwd", "colsum_acc", "add_cast", "act_bwd", "act_fwd") and self.by_shape:
                     shp = [x for x in a if isinstance(x, int)][:4]
                     tag = f"{_n}{[tuple(a[0].shape)] + shp}"
-                if _n == "gemm_tn" and self.by_shape:
-                    tag = f"gemm_tn[{a[0].shape[0]}x{a[0].shape[1]}x{a[1].shape[1]}]"
+                if _n in ("gemm_tn", "gemm_tn16") and self.by_shape:
+                    tag = f"{_n}[{a[0].shape[0]}x{a[0].shape[1]}x{a[1].shape[1]}]"
                 if _n == "attn_fwd" and self.by_shape:
                     tag = f"attn_fwd[{a[5]}x{a[6]}x{a[7]}]"
                 if _n == "attn_fwd_rows" and self.by_shape:
                     tag = f"attn_fwd_rows[{a[2]}x{a[3]}x{a[4]}]"
-                self.records.append((tag, flops, s, e, nbytes, issued if _n in ("gemm", "gemm_tn") else flops))
+                self.records.append((tag, flops, s, e, nbytes, issued if _n in ("gemm", "gemm_tn", "gemm_tn16") else flops))
             setattr(L, n, wrapped)
         return self
 

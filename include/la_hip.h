@@ -367,7 +367,8 @@ int la_attn_bwd_relpos(const void* qkv, const void* out16, const void* dout16, c
 
 /* Backward of the rel-pos terms themselves (relh[q][kh] = q . Rh[qy - kh + G - 1], relw[q][kw] = q . Rw[qx - kw + G - 1], q unscaled;
  * image_encoder.py:340-376): dq rows of dqkv += the terms' share (read-modify-write of the 16-bit rows la_attn_bwd_relpos wrote);
- * dtabh / dtabw fp32 [(2G - 1), 64] += gscale * table gradients (atomics over images, heads and rows).  tabh / tabw fp32 [(2G - 1), 64]. */
+ * dtabh / dtabw fp32 [(2G - 1), hd] += gscale * table gradients (atomics over images, heads and rows).  tabh / tabw fp32 [(2G - 1), hd];
+ * hd = E / heads = 64 or 128 (other head widths zero-padded by the caller, like the forward). */
 int la_relpos_bwd(const void* qkv, void* dqkv, const float* drelh, const float* drelw, const float* tabh, const float* tabw, float* dtabh,
                   float* dtabw, int B, int heads, int G, int E, float gscale, int dt, void* stream);
 
@@ -378,6 +379,15 @@ int la_cast(const void* src, int src_dt, void* dst, int dst_dt, long n, float sc
  * a split-K weight-gradient la_gemm (LaGemmEpilogue.ksplit).  colsum != NULL (fp32 [C]): colsum[c] += sum_r dst[c][r] (atomics) - the
  * bias gradient db = colsum(dY) of an nn.Linear from the same pass over dY that prepares its weight gradient. */
 int la_transpose16(const void* src, int src_dt, int ld, int R, int C, void* dst, int dst_dt, int Rp, float* colsum, void* stream);
+
+/* dW[N, K] += dY[R, N]^T . X[R, K] on the 16-bit MFMA from ROW-major 16-bit operands (no transposed copies: both MFMA operands are read out of
+ * the row-major LDS tiles with ds_read_b64_tr_b16), split over R with fp32 atomics; db != NULL (fp32 [N]): db[n] += sum_r dY[r][n] from the
+ * same pass.  The weight / bias gradient of nn.Linear when the backbone trains (models/common.py:19-37, image_encoder.py:200-255,
+ * transformers ViT layers under build_encoder.py:83-100; lam.py:321-347).  N % 256 == 0, K % 256 == 0, ldy / ldx in elements (% 8 == 0).
+ * gsize > 0: output row n is written to dW row (n / gsize) * gstride + n % gsize (HF's separate query / key / value weights, a fixed
+ * number of rows apart in the flat gradient buffer, from ONE product - la_gemm's LA_MAP_GROUP). */
+int la_gemm_tn16(const void* dy, int ldy, const void* x, int ldx, float* dw, int lddw, int R, int N, int K, int gsize, int gstride,
+                 float* db, int dt, void* stream);
 
 /* y += a * x, n contiguous fp32 elements (loss-scaled encoder gradients folded into the flat gradient buffer). */
 int la_axpy(const float* x, float* y, long n, float a, void* stream);

@@ -60,7 +60,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_gemm_tn", "la_gemm_tn16", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
@@ -350,6 +350,25 @@ def gemm_tn(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[to
             raise ValueError("gemm_tn: db must hold N elements")
     _check(lib().la_gemm_tn_db(_ptr(dy), C.c_int(dy.stride(0)), _ptr(x), C.c_int(x.stride(0)), _ptr(dw), C.c_int(k), C.c_int(m), C.c_int(n),
                                C.c_int(k), _ptr(db), _stream()), "la_gemm_tn")
+
+
+def gemm_tn16(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor] = None, gsize: int = 0, gstride: int = 0) -> None:
+    """dw[N,K] += dy[R,N]^T @ x[R,K] from row-major 16-bit operands (column slices allowed), db[N] += dy.sum(0); 16-bit MFMA, no
+    transposed copies.  gsize / gstride: output row n -> dw row (n // gsize) * gstride + n % gsize (dw = the first row's tensor)."""
+    _dev(dy)
+    if dy.dtype not in (torch.float16, torch.bfloat16) or x.dtype != dy.dtype:
+        raise TypeError("gemm_tn16: 16-bit operands of one dtype")
+    if dy.stride(1) != 1 or x.stride(1) != 1 or dy.shape[0] != x.shape[0]:
+        raise ValueError("gemm_tn16: row-major operands with the same number of rows")
+    _f32c(dw)
+    r, n = dy.shape
+    k = x.shape[1]
+    if db is not None:
+        _f32c(db)
+        if db.numel() != n:
+            raise ValueError("gemm_tn16: db must hold N elements")
+    _check(lib().la_gemm_tn16(_ptr(dy), C.c_int(dy.stride(0)), _ptr(x), C.c_int(x.stride(0)), _ptr(dw), C.c_int(k), C.c_int(r), C.c_int(n),
+                              C.c_int(k), C.c_int(gsize), C.c_int(gstride), _ptr(db), C.c_int(dt_of(dy)), _stream()), "la_gemm_tn16")
 
 
 def colsum_acc(dy: torch.Tensor, out: torch.Tensor) -> None:

@@ -88,6 +88,7 @@ class HfEncoderGraph:
         self.ctx = None
         self.last_scale = 1.0
         self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
+        self.tn16 = True                  # ... straight from the row-major 16-bit operands (la_gemm_tn16); False: transposed copies + la_gemm ksplit
         self._tbufs: Dict[tuple, Tensor] = {}
         self._xt_key = None                   # which activation the transposed-operand scratch of _wgrad currently holds
         self._runs = None
@@ -205,6 +206,11 @@ class HfEncoderGraph:
         dy = dy16 if dy16 is not None else dy32
         r, n = dy.shape
         k = x.shape[1]
+        if self.fast_wgrad and self.tn16 and dy16 is not None and x.dtype == dy16.dtype and n % 256 == 0 and k % 256 == 0 and r >= 128:
+            # both operands already 16-bit and row-major: the product reads them as they are (LDS transpose reads), db on the way
+            fused = db is not None and db.is_contiguous()
+            L.gemm_tn16(dy16, x, dw.view(n, k), db=db if fused else None)
+            return fused
         if self.fast_wgrad and k % 256 == 0 and r >= 128:
             rp = _ceil(r, 64)
             dt = self.ctx["dt"]
@@ -245,6 +251,13 @@ class HfEncoderGraph:
         if stride <= 0 or stride % (4 * e) or gw[2].data_ptr() - gw[1].data_ptr() != stride:
             return False
         rows_apart = stride // (4 * e)                       # in rows of E floats: E weight rows + the bias row(s) in between
+        if self.tn16 and x.dtype == dqkv16.dtype:
+            cs = self._tbuf("qkv_colsum", 3, e, torch.float32)
+            cs.zero_()
+            L.gemm_tn16(dqkv16, x, gw[0].view(e, e), db=cs.view(-1), gsize=e, gstride=rows_apart)
+            for j in range(3):
+                gb[j].add_(cs[j])
+            return True
         rp = _ceil(r, 64)
         dt = self.ctx["dt"]
         dyt = self._tbuf("dyt", 3 * e, rp, dt)

@@ -274,6 +274,41 @@ def test_split_k_weight_gradient_gemm_matches_torch(shape):
     assert float((dw.double() - ref).abs().max() / ref.abs().max()) < 1e-5      # fp32 accumulation of exactly representable products
 
 
+@pytest.mark.parametrize("shape", [(46852, 768, 768), (23426, 3072, 768), (5000, 256, 256), (901, 768, 3072), (130, 256, 512, "bf16"), (46852, 2304, 768, "group")])
+def test_weight_gradient_from_row_major_16bit_operands_matches_torch(shape):
+    """la_gemm_tn16: dW += dY^T X and db += colsum(dY) straight from the row-major 16-bit operands (LDS transpose reads feed both MFMA
+    operands; no la_transpose16 copies), split over the rows with fp32 atomics.  Operands are column slices of wider matrices (as q | k | v
+    gradients are), R is ragged (not a multiple of 64: the clamped tail rows must not count).  "group": the three [E, E] weight blocks of
+    HF's separate query / key / value Linears a fixed number of rows apart, from ONE product (la_gemm's LA_MAP_GROUP)."""
+    r, n, k = shape[:3]
+    dt = torch.bfloat16 if "bf16" in shape else torch.float16
+    g = torch.Generator().manual_seed(r + n)
+    dy_wide = torch.randn(r, n + 64, generator=g).to(dt).cuda()
+    x_wide = torch.randn(r, k + 8, generator=g).to(dt).cuda()
+    dy, x = dy_wide[:, 64:], x_wide[:, :k]
+    db0 = torch.randn(n, generator=g).cuda()
+    db = db0.clone()
+    ref = dy.double().t() @ x.double()
+    if "group" in shape:
+        e, apart = n // 3, n // 3 + 5                  # E weight rows, then 5 rows of something else (the bias and alignment) before the next block
+        buf0 = torch.randn(3 * apart, k, generator=g).cuda()
+        buf = buf0.clone()
+        L.gemm_tn16(dy, x, buf[:e], db=db, gsize=e, gstride=apart)
+        torch.cuda.synchronize()
+        for j in range(3):
+            got = buf[j * apart: j * apart + e].double() - buf0[j * apart: j * apart + e].double()
+            assert float((got - ref[j * e:(j + 1) * e]).abs().max() / ref.abs().max()) < 1e-5, j
+            assert torch.equal(buf[j * apart + e:(j + 1) * apart], buf0[j * apart + e:(j + 1) * apart])         # rows in between untouched
+    else:
+        dw0 = torch.randn(n, k, generator=g).cuda()
+        dw = dw0.clone()
+        L.gemm_tn16(dy, x, dw, db=db)
+        torch.cuda.synchronize()
+        assert float((dw.double() - dw0.double() - ref).abs().max() / ref.abs().max()) < 1e-5      # fp32 accumulation of exactly representable products
+    want = db0.double() + dy.double().sum(0)
+    assert float((db.double() - want).abs().max()) <= 2e-5 * float(dy.double().abs().sum(0).max()), "fused column sums"
+
+
 def test_trainer_leaves_the_models_inference_numerics_alone():
     """``LamTrainer(train_encoder=True)`` must not strip the token-mean correction groups from ``lam.precise`` - validation
     between training steps runs the SAME inference configuration as before; the training forward's own numerics live in the trainer's
