@@ -28,7 +28,7 @@ extern "C" {
  * [W_hi | W_hi | W_lo] (K' = 3 K) the product carries ~21 mantissa bits through the fast MFMA: the decoder-side (P, hw, D) stream at
  * fp32-level accuracy for 3 fp16 passes instead of the 16 passes an exact-fp32 MFMA costs. */
 enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2, LA_F16X2 = 3 };
-enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2 };
+enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2, LA_ACT_GELU_BWD = 3 /* la_gemm only, see LaGemmEpilogue.aux16 */ };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
 enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3, LA_MAP_WINDOW_PART = 4 };
 /* la_attn_fwd modes */
@@ -91,7 +91,16 @@ typedef struct LaGemmEpilogue {
                           dW[N, K] = dY^T X over all tokens, operands passed transposed) still fills the chip.  N % 256 == 0, K % 64 == 0;
                           no bias / residual / activation / out16; row map LA_MAP_NONE or LA_MAP_GROUP (several weight gradients a fixed
                           stride apart in one flat gradient buffer - HF's query / key / value weights - from ONE launch). */
+  void* aux16;         /* training (models/common.py:36-37 MLPBlock / transformers ViTIntermediate when the backbone trains, lam.py:321-347): a second
+                          16-bit matrix [M, N] (row stride ldaux).  act == LA_ACT_GELU: WRITTEN - the pre-activation A W^T + b beside
+                          out16 = GELU of it (what gelu' needs in the backward).  act == LA_ACT_GELU_BWD: READ - out16 = (A W^T) * gelu'(aux16),
+                          the data gradient through a GELU in one pass (A = dY, W = the transposed weight).  Only shapes for which
+                          la_gemm_fused_act_ok() says 1 (the persistent four-wave kernel); out16 only, no residual / maps / V^T. */
+  int ldaux;
 } LaGemmEpilogue;
+
+/* 1 when la_gemm takes LaGemmEpilogue.aux16 for this shape (N % 256 == 0, K % 64 == 0, K >= 128, at least one round of 256 x 256 tiles). */
+int la_gemm_fused_act_ok(int M, int N, int K);
 
 /* C[M,N] = A[M,K] . W[N,K]^T (nn.Linear layout), 16-bit operands, fp32 accumulate on MFMA.
  * K % 8 == 0.  Replaces every nn.Linear / 1x1 conv / im2col'd conv / k=s ConvTranspose of the path:

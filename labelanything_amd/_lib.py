@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libla_hip.so")      # the one product library; n
 #                                                     attribute for measurement builds before the first call)
 
 LA_F16, LA_BF16, LA_F32, LA_F16X2 = 0, 1, 2, 3
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
 MAP_NONE, MAP_GROUP, MAP_WINDOW_MERGE, MAP_CONVT2X2, MAP_WINDOW_PART = 0, 1, 2, 3, 4
 ATTN_PLAIN, ATTN_RELPOS, ATTN_RELPOS_WIN16 = 0, 1, 2
 
@@ -32,6 +32,7 @@ class LaGemmEpilogue(C.Structure):
         ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int), ("p3", C.c_int), ("p4", C.c_int),
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_T", C.c_int), ("vt_Tpad", C.c_int),
         ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int), ("a_kmod", C.c_int), ("ksplit", C.c_int),
+        ("aux16", C.c_void_p), ("ldaux", C.c_int),
     ]
 
 
@@ -60,7 +61,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_gemm_tn16", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
+    "la_gemm_tn", "la_gemm_tn16", "la_gemm_fused_act_ok", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
@@ -103,9 +104,10 @@ def _dev(t: torch.Tensor) -> None:
 # ----------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, out32=None, out16=None,
          act=ACT_NONE, map=MAP_NONE, p=(0, 0, 0, 0, 0), vt=None, vt_col0=0, vt_T=0, vt_Tpad=0, vt_hd=64,
-         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0, ksplit=0) -> None:
+         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0, ksplit=0, aux16=None) -> None:
     """C = epilogue(a @ w.T).  a: [M,K] 16-bit (row stride lda), w: [N,K] 16-bit.  a_kmod > 0: w is [N, j*a_kmod] (split-precision
-    planes [W_hi | W_lo]) and the columns of a repeat with period a_kmod."""
+    planes [W_hi | W_lo]) and the columns of a repeat with period a_kmod.  aux16 (training, shapes with ``gemm_fused_act_ok``): with
+    ACT_GELU the pre-activation is written there beside out16 = GELU; with ACT_GELU_BWD out16 = (a @ w.T) * gelu'(aux16)."""
     _dev(a)
     m = a.shape[0] if M is None else M
     k = w.shape[1]
@@ -127,9 +129,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, ou
     e.amap = amap
     e.a_kmod = a_kmod
     e.ksplit = ksplit
+    e.aux16 = aux16.data_ptr() if aux16 is not None else None
+    e.ldaux = aux16.stride(-2) if aux16 is not None else 0
     rc = lib().la_gemm(_ptr(a), C.c_int(a.stride(0) if lda is None else lda), _ptr(w), C.c_int(w.stride(0)),
                        C.c_int(m), C.c_int(n), C.c_int(k), C.byref(e), C.c_int(dt_of(a)), _stream())
     _check(rc, "la_gemm")
+
+
+def gemm_fused_act_ok(m: int, n: int, k: int) -> bool:
+    """True when ``gemm(..., aux16=...)`` runs for this shape (the persistent four-wave kernel's direct epilogue)."""
+    return bool(lib().la_gemm_fused_act_ok(C.c_int(m), C.c_int(n), C.c_int(k)))
 
 
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, *, x2=None, gelu=False, out32=None, out16=None,

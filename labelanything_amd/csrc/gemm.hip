@@ -2118,6 +2118,10 @@ extern "C" int la_dbg_gemm_stamps_clear() {
 }
 #endif
 
+extern "C" int la_gemm_fused_act_ok(int M, int N, int K) {
+  return M > 0 && (N % 256) == 0 && (K % 64) == 0 && K >= 128 && (long)((M + 255) / 256) * (N / 256) >= 256 && (la::g_gemm_variant & 0xff) == 2;
+}
+
 extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue* epi, int dt,
                        void* stream) {
   LA_CHECK_ARG(A && W && epi, "la_gemm: null pointer");
@@ -2133,6 +2137,28 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
                epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  LA_CHECK_ARG(epi->act != LA_ACT_GELU_BWD || epi->aux16, "la_gemm: LA_ACT_GELU_BWD needs aux16 (the saved pre-activation)");
+  if (epi->aux16) {
+    // the training forms of the MLP's GELU (see LaGemmEpilogue.aux16): the direct epilogue of the persistent four-wave kernel only
+    LA_CHECK_ARG(epi->act == LA_ACT_GELU || epi->act == LA_ACT_GELU_BWD, "la_gemm: aux16 goes with LA_ACT_GELU (written) or LA_ACT_GELU_BWD (read)");
+    LA_CHECK_ARG(dt != LA_F32 && la_gemm_fused_act_ok(M, N, K) && la::fast_ok(A, lda, W, ldw, M, N, K, *epi),
+                 "la_gemm: aux16 needs 16-bit operands and a shape la_gemm_fused_act_ok() accepts (M=%d N=%d K=%d)", M, N, K);
+    LA_CHECK_ARG(epi->out16 && !epi->out32 && !epi->res && !epi->vt && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && epi->a_kmod == 0 &&
+                     epi->ksplit == 0 && (epi->ld16 % 8) == 0 && (epi->ldaux % 8) == 0 && epi->ld16 >= N && epi->ldaux >= N &&
+                     ((reinterpret_cast<uintptr_t>(epi->out16) | reinterpret_cast<uintptr_t>(epi->aux16)) & 15) == 0,
+                 "la_gemm: aux16 forms write out16 only (no residual / fp32 output / maps / V^T / planes), rows 16-byte aligned");
+    LA_CHECK_ARG(epi->act == LA_ACT_GELU || !epi->bias, "la_gemm: LA_ACT_GELU_BWD takes no bias");
+    const int gm = la::tile_group_m(N >= 2560 ? 8 : 2);
+    if (epi->act == LA_ACT_GELU) {
+      if (dt == LA_F16) la::launch_t256w_fused<la::f16_t, 5>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+      else la::launch_t256w_fused<la::bf16_t, 5>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    } else {
+      if (dt == LA_F16) la::launch_t256w_fused<la::f16_t, 6>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+      else la::launch_t256w_fused<la::bf16_t, 6>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    }
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
   // up to 512 fp32 rows (decoder tokens of many prompt pairs): an MFMA grid of 128 x 128 tiles is a handful of workgroups and leaves the
   // chip idle (240 x 256 x 2048: 155 us on four tiles) - 32 x 32 wave tiles (gemm_f32_small_kernel) above 128 rows, the VALU kernel below
   const bool few_rows = M <= 32 || (dt == LA_F32 && M <= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64);

@@ -387,5 +387,7 @@ __device__ __forceinline__ void epilogue_wave(char* slab, unsigned* rtab, f32x16
 // gemm_w4.hip: the four-wave persistent 256 x 256 x 64 kernel (EPI 1 / 2 / 3 as epilogue_wave; K % 64 == 0, K >= 128, N % 256 == 0)
 template <typename T, int EPI>
 void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st);
+template <typename T, int EPI>
+void launch_t256w_fused(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st);
 
 }  // namespace la

@@ -126,6 +126,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   float bias[2][8];
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
+    if (EPI == 6) continue;
     const float4 b0 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b1 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     bias[jp][0] = b0.x; bias[jp][1] = b0.y; bias[jp][2] = b0.z; bias[jp][3] = b0.w;
@@ -162,7 +163,18 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         res[s_][h] = (e.res && row0 + i * 32 + rq * 4 + s_ < M) ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h)
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);      // (rows beyond M: the last, ragged row tile)
   };
-  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2]) {
+  // EPI 5 / 6 (training): aux16 = a second 16-bit matrix of the output's shape.  5: the pre-activation (bias added, before the GELU) is
+  // written there beside out16 = GELU - the forward that keeps what gelu' needs.  6: it is READ - out16 = acc * gelu'(aux16), the data
+  // gradient of the layer in front of a GELU (dX = dY W of fc2 times gelu'(pre): no fp32 d-activation round trip, no la_gelu_bwd16 pass);
+  // its row segments are requested a round ahead like the residual's
+  T* aux16 = reinterpret_cast<T*>(e.aux16);
+  auto ldaux = [&](int i, int jp, uint4 (&ax)[4]) {
+    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+      ax[s_] = row + s_ < M ? *reinterpret_cast<const uint4*>(aux16 + (size_t)(row + s_) * e.ldaux + col) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2], const uint4 (&ax)[4]) {
     const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
     if (EPI == 3) {
 #pragma unroll
@@ -191,8 +203,54 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]} + f32x2{bias[jp][t], bias[jp][t]};
-        if (EPI == 2) {
+        for (int t = 0; t < 8; ++t) {
+          v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]};
+          if (EPI != 6) v[t][sp] = v[t][sp] + f32x2{bias[jp][t], bias[jp][t]};        // (a data gradient has no bias)
+        }
+        if (EPI == 5) {                        // the two rows of this pair as they are before the activation
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint4 pk;
+            pk.x = pack2<T>(v[0][sp][h], v[1][sp][h]);
+            pk.y = pack2<T>(v[2][sp][h], v[3][sp][h]);
+            pk.z = pack2<T>(v[4][sp][h], v[5][sp][h]);
+            pk.w = pack2<T>(v[6][sp][h], v[7][sp][h]);
+            if (row + 2 * sp + h < M) *reinterpret_cast<uint4*>(aux16 + (size_t)(row + 2 * sp + h) * e.ldaux + col) = pk;
+          }
+        }
+        if (EPI == 6) {                        // v *= gelu'(x), x = the saved pre-activation: 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2 / 2) / sqrt(2 pi)
+          f32x2 x[8], u[8], tt[8], p[8], ex[8];
+          const T* a0 = reinterpret_cast<const T*>(&ax[2 * sp]);
+          const T* a1 = reinterpret_cast<const T*>(&ax[2 * sp + 1]);
+#define LA_W4_STEP(expr)                          \
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) { \
+    expr;                                         \
+  }                                               \
+  __builtin_amdgcn_sched_barrier(0);
+          LA_W4_STEP(x[t] = (f32x2{(float)a0[t], (float)a1[t]}))
+          LA_W4_STEP(u[t] = x[t] * 0.70710678118654752440f)
+          LA_W4_STEP(u[t].x = __builtin_amdgcn_fmed3f(u[t].x, -3.0f, 3.0f); u[t].y = __builtin_amdgcn_fmed3f(u[t].y, -3.0f, 3.0f))
+          LA_W4_STEP(tt[t] = u[t] * u[t])
+          LA_W4_STEP(p[t] = tt[t] * -3.753537037e-09f + 1.995845196e-07f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -4.771217391e-06f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 6.851813669e-05f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -6.692335592e-04f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 4.784903489e-03f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -2.622046508e-02f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.123065501e-01f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + -3.759292066e-01f)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.128377676e+00f)
+          LA_W4_STEP(p[t] = p[t] * u[t])                                   // erf(x / sqrt 2)
+          LA_W4_STEP(ex[t] = x[t] * x[t])
+          LA_W4_STEP(ex[t] = ex[t] * -0.72134752044448170368f)            // -x^2 / 2 in base 2
+          LA_W4_STEP(ex[t].x = __builtin_amdgcn_exp2f(ex[t].x); ex[t].y = __builtin_amdgcn_exp2f(ex[t].y))
+          LA_W4_STEP(p[t] = p[t] * 0.5f + 0.5f)
+          LA_W4_STEP(x[t] = x[t] * 0.39894228040143267794f)
+          LA_W4_STEP(p[t] = x[t] * ex[t] + p[t])
+          LA_W4_STEP(v[t][sp] = v[t][sp] * p[t])
+#undef LA_W4_STEP
+        }
+        if (EPI == 2 || EPI == 5) {
           f32x2 u[8], tt[8], p[8];
 #define LA_W4_STEP(expr)                          \
   _Pragma("unroll") for (int t = 0; t < 8; ++t) { \
@@ -235,55 +293,66 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   // rounds r = 2 i + jp.  ONE fragment set: the wave must not spill here - a reload is a VMEM load behind the round's stores, i.e. an
   // s_waitcnt vmcnt(0) that drains them (and the LDS-DMA pieces of the next tile) once per round
   float4 res0[4][2], res1[4][2];
+  uint4 aux0[4], aux1[4];
   if (EPI == 3) {
     ldres(0, 0, res0);
     ldres(0, 1, res1);
+  }
+  if (EPI == 6) {
+    ldaux(0, 0, aux0);
+    ldaux(0, 1, aux1);
   }
   wr(I0{}, I0{});
   rd(rd0);
   wr(I0{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 0, rd0, res0);
+  out(0, 0, rd0, res0, aux0);
   if (EPI == 3) ldres(1, 0, res0);
+  if (EPI == 6) ldaux(1, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 1, rd0, res1);
+  out(0, 1, rd0, res1, aux1);
   if (EPI == 3) ldres(1, 1, res1);
+  if (EPI == 6) ldaux(1, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 0, rd0, res0);
+  out(1, 0, rd0, res0, aux0);
   if (EPI == 3) ldres(2, 0, res0);
+  if (EPI == 6) ldaux(2, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 1, rd0, res1);
+  out(1, 1, rd0, res1, aux1);
   if (EPI == 3) ldres(2, 1, res1);
+  if (EPI == 6) ldaux(2, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 0, rd0, res0);
+  out(2, 0, rd0, res0, aux0);
   if (EPI == 3) ldres(3, 0, res0);
+  if (EPI == 6) ldaux(3, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 1, rd0, res1);
+  out(2, 1, rd0, res1, aux1);
   if (EPI == 3) ldres(3, 1, res1);
+  if (EPI == 6) ldaux(3, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 0, rd0, res0);
+  out(3, 0, rd0, res0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 1, rd0, res1);
+  out(3, 1, rd0, res1, aux1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -294,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
                                                              int K, LaGemmEpilogue e, int gm, int stg) {
   constexpr int BK_ = 64;
   constexpr unsigned REG = 32768;                     // one operand of one k-tile
-  constexpr int SEAM = (EPI == 3) ? 47 : 32;          // epilogue stores per wave that the first two waits of a tile may leave outstanding
+  constexpr int SEAM = (EPI == 3 || EPI == 5) ? 47 : 32;      // epilogue stores per wave that the first two waits of a tile may leave outstanding
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef LA_DEBUG
@@ -544,6 +613,16 @@ void launch_t256w(const void* A, int lda, const void* W, int ldw, int M, int N, 
   if (direct) launch_t256w_abl<T, EPI, 0, true>(A, lda, W, ldw, M, N, K, e, gm, st);
   else launch_t256w_abl<T, EPI, 0, false>(A, lda, W, ldw, M, N, K, e, gm, st);
 }
+
+// EPI 5 / 6 (GELU forward that also keeps the pre-activation; data gradient times gelu' - training only) exist on the direct epilogue alone
+template <typename T, int EPI>
+void launch_t256w_fused(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue& e, int gm, hipStream_t st) {
+  launch_t256w_abl<T, EPI, 0, true>(A, lda, W, ldw, M, N, K, e, gm & ~0x100, st);
+}
+template void launch_t256w_fused<f16_t, 5>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 6>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<bf16_t, 5>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<bf16_t, 6>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 
 #define LA_W4_INST(T, EPI) \
   template void launch_t256w<T, EPI>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);

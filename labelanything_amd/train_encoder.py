@@ -88,6 +88,7 @@ class HfEncoderGraph:
         self.ctx = None
         self.last_scale = 1.0
         self.fast_wgrad = True            # 16-bit split-K weight gradients where the shape allows (False: exact-fp32 la_gemm_tn everywhere)
+        self.fused_gelu = True            # fc1 forward / fc2 data gradient with the GELU (and gelu') in the GEMM epilogue where the shape allows
         self.tn16 = True                  # ... straight from the row-major 16-bit operands (la_gemm_tn16); False: transposed copies + la_gemm ksplit
         self._tbufs: Dict[tuple, Tensor] = {}
         self._xt_key = None                   # which activation the transposed-operand scratch of _wgrad currently holds
@@ -173,8 +174,7 @@ class HfEncoderGraph:
             eng.ln(x_mid, lp + ".layernorm_after", 1e-12, out16=x16b)
             sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
-            eng.gemm_w(x16b, lp + ".fc1.w", bias=w[lp + ".intermediate.dense.bias"], out16=sv["pre"])    # the pre-activation gelu' needs;
-            L.gelu_fwd16(sv["pre"], sv["post"])                                                             # the activation from it
+            self._fc1_fwd(eng, x16b, lp + ".fc1.w", w[lp + ".intermediate.dense.bias"], sv["pre"], sv["post"])
             res = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["post"], lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=x_mid, out32=res)
             layers.append(sv)
@@ -184,6 +184,29 @@ class HfEncoderGraph:
         self.ctx = dict(images=images, layers=layers, x_fin=res, bn=bn, g=g, hw=hw, t=t, rows=rows, tpad=tpad, e=e, ea=ea, heads=heads,
                         scale=scale, dt=dt)
         return out
+
+    def _fc1_fwd(self, eng, x16: Tensor, key: str, bias: Tensor, pre: Tensor, post: Tensor) -> None:
+        """post = GELU(x W1^T + b), pre = x W1^T + b (what gelu' needs in the backward): one launch where the shape runs on the
+        persistent four-wave kernel (LaGemmEpilogue.aux16: the epilogue writes both), else the GEMM + la_gelu_fwd16."""
+        if self.fused_gelu and eng.kmod.get(key, 0) == 0 and L.gemm_fused_act_ok(x16.shape[0], pre.shape[1], x16.shape[1]):
+            L.gemm(x16, eng.p[key], bias=bias, out16=post, act=L.ACT_GELU, aux16=pre)
+        else:
+            eng.gemm_w(x16, key, bias=bias, out16=pre)
+            L.gelu_fwd16(pre, post)
+
+    def _fc2_bwd(self, dy32: Tensor, dy16: Tensor, a: dict, wname: str, bname: str, dh: Tensor, dpre32, dpre16: Tensor) -> None:
+        """Backward of fc2 and of the GELU in front of it: dW2 += dY^T post, db2 += colsum dY, d pre = (dY W2) * gelu'(pre) - the last as
+        ONE product whose epilogue reads the saved pre-activation (LA_ACT_GELU_BWD) where the shape allows, else product + la_gelu_bwd16.
+        dpre32 (None = not needed): the fp32 copy the exact-fp32 fallbacks of fc1's weight / bias gradient read."""
+        r, n, k = dy16.shape[0], a["pre"].shape[1], dy16.shape[1]
+        if self.fused_gelu and dpre32 is None and L.gemm_fused_act_ok(r, n, k):
+            wt = self.w[wname]
+            if not self._wgrad(dy16, dy32, a["post"], self.sviews[wname], db=self.sviews[bname]):
+                L.colsum_acc(dy32, self.sviews[bname])
+            L.gemm(dy16, self._wt16(wname, lambda: wt, dy16.dtype), out16=dpre16, act=L.ACT_GELU_BWD, aux16=a["pre"])
+        else:
+            self._linear_bwd(dy32, dy16, a["post"], wname, bname, dx32=dh)
+            L.gelu_bwd16(a["pre"], dh, dpre32, dpre16)
 
     # ---- backward --------------------------------------------------------------------------------------------------------------
     def _wt16(self, key: str, wt_fn, dt) -> Tensor:
@@ -405,10 +428,9 @@ class HfEncoderGraph:
             lp = f"{pre}.encoder.layer.{i}"
             a = c["layers"][i]
             # ---- MLP: res = x_mid + fc2(gelu(fc1(LN2(x_mid)))) -----------------------------------------------------------------
-            self._linear_bwd(dres, d16, a["post"], lp + ".output.dense.weight", lp + ".output.dense.bias", dx32=dh)
             # (the fp32 copy of d pre-activation only feeds the exact-fp32 fallbacks of the weight / bias gradient)
             need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
-            L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
+            self._fc2_bwd(dres, d16, a, lp + ".output.dense.weight", lp + ".output.dense.bias", dh, dpre32 if need32 else None, dpre16)
             self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], lp + ".intermediate.dense.weight", lp + ".intermediate.dense.bias",
                              dx32=dxn)
             L.layernorm_bwd_res(a["x_mid"], dxn, w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, dres, dres, d16,
@@ -614,8 +636,7 @@ class SamEncoderGraph(HfEncoderGraph):
             eng.ln(x_mid, bp + ".norm2", 1e-6, out16=x16b)
             sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
-            eng.gemm_w(x16b, bp + ".lin1.w", bias=w[bp + ".mlp.lin1.bias"], out16=sv["pre"])
-            L.gelu_fwd16(sv["pre"], sv["post"])
+            self._fc1_fwd(eng, x16b, bp + ".lin1.w", w[bp + ".mlp.lin1.bias"], sv["pre"], sv["post"])
             res = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["post"], bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=x_mid, out32=res)
             layers.append(sv)
@@ -645,9 +666,8 @@ class SamEncoderGraph(HfEncoderGraph):
             a = c["layers"][i]
             nb, gg, t, tpad, arows = a["nb"], a["g"], a["t"], a["tpad"], a["arows"]
             # ---- MLP: res = x_mid + lin2(gelu(lin1(LN2(x_mid)))) -----------------------------------------------------------------
-            self._linear_bwd(dres, d16, a["post"], bp + ".mlp.lin2.weight", bp + ".mlp.lin2.bias", dx32=dh)
             need32 = not (self.fast_wgrad and e % 256 == 0 and rows >= 128)
-            L.gelu_bwd16(a["pre"], dh, dpre32 if need32 else None, dpre16)
+            self._fc2_bwd(dres, d16, a, bp + ".mlp.lin2.weight", bp + ".mlp.lin2.bias", dh, dpre32 if need32 else None, dpre16)
             self._linear_bwd(dpre32 if need32 else None, dpre16, a["xnb"], bp + ".mlp.lin1.weight", bp + ".mlp.lin1.bias", dx32=dxn)
             L.layernorm_bwd_res(a["x_mid"], dxn, w[bp + ".norm2.weight"], w[bp + ".norm2.bias"], 1e-6, dres, dres, d16, sv[bp + ".norm2.weight"],
                                 sv[bp + ".norm2.bias"])

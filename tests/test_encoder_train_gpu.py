@@ -309,6 +309,52 @@ def test_weight_gradient_from_row_major_16bit_operands_matches_torch(shape):
     assert float((db.double() - want).abs().max()) <= 2e-5 * float(dy.double().abs().sum(0).max()), "fused column sums"
 
 
+@pytest.mark.parametrize("shape", [(46852, 3072, 768), (16384, 3072, 768), (65636, 1024, 256, "bf16")])
+def test_gelu_in_the_gemm_epilogue_forward_with_saved_pre_activation_and_backward(shape):
+    """LaGemmEpilogue.aux16 (training forms of the MLP's GELU on the persistent four-wave kernel): ACT_GELU writes the pre-activation beside
+    the activation in ONE launch - both bit-identical to what the plain and the GELU epilogue write alone; ACT_GELU_BWD multiplies the data
+    gradient dY W by gelu'(saved pre-activation) in the epilogue - against torch in fp64 (models/common.py:36-37, erf GELU)."""
+    m, n, k = shape[:3]
+    dt = torch.bfloat16 if "bf16" in shape else torch.float16
+    assert L.gemm_fused_act_ok(m, n, k) and not L.gemm_fused_act_ok(300, n, k) and not L.gemm_fused_act_ok(m, n + 64, k)
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).to(dt).cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).to(dt).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    pre, post = torch.empty(m, n, dtype=dt, device="cuda"), torch.empty(m, n, dtype=dt, device="cuda")
+    L.gemm(x, w, bias=b, out16=post, act=L.ACT_GELU, aux16=pre)
+    pre1, post1 = torch.empty_like(pre), torch.empty_like(post)
+    L.gemm(x, w, bias=b, out16=pre1)
+    L.gemm(x, w, bias=b, out16=post1, act=L.ACT_GELU)
+    torch.cuda.synchronize()
+    assert torch.equal(pre, pre1) and torch.equal(post, post1)
+    rows = torch.randperm(m, generator=g)[:2048].cuda()
+    ref_pre = x[rows].double() @ w.double().t() + b.double()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert float((pre[rows].double() - ref_pre).abs().max()) <= eps * float(ref_pre.abs().max())
+    ref_post = torch.nn.functional.gelu(ref_pre)
+    assert float((post[rows].double() - ref_post).abs().max()) <= eps * float(ref_post.abs().max()) + 1e-4
+    # backward: d pre = (dY W2) * gelu'(pre), W2 [k2, n] as the transposed weight [n, k2] of the data-gradient product
+    k2 = k
+    dy = torch.randn(m, k2, generator=g).to(dt).cuda()
+    w2t = (torch.randn(n, k2, generator=g) * k2 ** -0.5).to(dt).cuda()
+    dpre = torch.full((m, n), float("nan"), dtype=dt, device="cuda")
+    L.gemm(dy, w2t, out16=dpre, act=L.ACT_GELU_BWD, aux16=pre)
+    torch.cuda.synchronize()
+    xs = pre[rows].double()
+    gp = 0.5 * (1.0 + torch.erf(xs * 0.5 ** 0.5)) + xs * torch.exp(-0.5 * xs * xs) * (2.0 * math.pi) ** -0.5
+    ref = (dy[rows].double() @ w2t.double().t()) * gp
+    assert bool(torch.isfinite(dpre).all())
+    assert float((dpre[rows].double() - ref).abs().max()) <= (eps + 1e-4) * float(ref.abs().max())
+    # ... and the two-pass form it replaces (product in fp32, la_gelu_bwd16) agrees to the 16-bit rounding of the result
+    dh = torch.empty(m, n, device="cuda")
+    L.gemm(dy, w2t, out32=dh)
+    two = torch.empty_like(dpre)
+    L.gelu_bwd16(pre, dh, None, two)
+    torch.cuda.synchronize()
+    assert float((two.double() - dpre.double()).abs().max()) <= 2.0 * eps * float(ref.abs().max())
+
+
 def test_trainer_leaves_the_models_inference_numerics_alone():
     """``LamTrainer(train_encoder=True)`` must not strip the token-mean correction groups from ``lam.precise`` - validation
     between training steps runs the SAME inference configuration as before; the training forward's own numerics live in the trainer's
