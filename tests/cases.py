@@ -127,3 +127,13 @@ TRAIN_SAM_CASE = dict(
     episode=dict(batch=1, n_ways=1, k_shots=2, image_size=224, seed=123, prompts=("mask", "point")),
     lr=1e-3, weight_decay=1e-2, steps=2, warmup=2,
 )
+
+
+# The same with SAM ViT-H style 80-wide heads (build_encoder.py:9-28: 1280 / 16; here 160 / 2) - tests/golden/train_step_sam_hd80.safetensors:
+# forward AND backward run the heads zero-padded to 128 columns; ``lam_h`` with nothing frozen.
+TRAIN_SAM_HD80_CASE = dict(
+    cfg=LamConfig(encoder="sam_hd80_tiny", image_size=224, image_embed_dim=96, embed_dim=64, spatial_convs=3, custom_preprocess=False),
+    weight_seed=24,
+    episode=dict(batch=1, n_ways=1, k_shots=2, image_size=224, seed=124, prompts=("mask", "point")),
+    lr=1e-3, weight_decay=1e-2, steps=2, warmup=2,
+)

@@ -154,8 +154,11 @@ def test_sam_block_stack_gradients_of_a_linear_functional_match_oracle_autograd(
         assert float(grads[k].abs().max()) > 0 and worst[k] <= 1e-2, (k, worst[k])
 
 
-def test_steps_with_trainable_sam_encoder_match_the_reference_fixture():
-    """tests/golden/train_step_sam.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up with NO frozen
+@pytest.mark.parametrize("fixture", ["train_step_sam", "train_step_sam_hd80"])
+def test_steps_with_trainable_sam_encoder_match_the_reference_fixture(fixture):
+    """(train_step_sam_hd80: the same model with SAM ViT-H style 80-wide heads - ``lam_h`` - whose attention runs zero-padded to 128 columns
+    per head in the forward and, since round 5, in the backward: tools/make_golden_train.py sam_hd80.)
+    tests/golden/train_step_sam.safetensors = the REFERENCE's WrapperModule + LabelAnythingLoss + torch AdamW + HF warm-up with NO frozen
     parameters on the reduced SAM model (tools/make_golden_train.py sam): losses, per-tensor gradient norms of the first step, the full
     gradient and the final value of 17 tensors (15 of them inside the image encoder: rel-pos tables, position embedding, qkv, SAM neck)."""
     import json
@@ -164,10 +167,11 @@ def test_steps_with_trainable_sam_encoder_match_the_reference_fixture():
     from labelanything_amd.episodes import make_episode
     from labelanything_amd.models import Lam
     from labelanything_amd.train import LamTrainer
-    from tests.cases import TRAIN_SAM_CASE as case
+    import tests.cases as cases
     from tests.helpers import GOLDEN, rel_err
-    gold = load_file(os.path.join(GOLDEN, "train_step_sam.safetensors"))
-    with open(os.path.join(GOLDEN, "train_step_sam.json")) as fh:
+    case = cases.TRAIN_SAM_CASE if fixture == "train_step_sam" else cases.TRAIN_SAM_HD80_CASE
+    gold = load_file(os.path.join(GOLDEN, fixture + ".safetensors"))
+    with open(os.path.join(GOLDEN, fixture + ".json")) as fh:
         keys = json.load(fh)["keys"]
     batch = make_episode(**case["episode"])
     lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()

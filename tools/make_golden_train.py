@@ -45,14 +45,16 @@ FULL_SAM = ["image_encoder.pos_embed", "image_encoder.patch_embed.proj.weight", 
 
 
 def main():
-    from tests.cases import TRAIN_CASE, TRAIN_ENC_CASE, TRAIN_SAM_CASE
-    which = sys.argv[1:] or ["decoder", "hf", "sam"]
+    from tests.cases import TRAIN_CASE, TRAIN_ENC_CASE, TRAIN_SAM_CASE, TRAIN_SAM_HD80_CASE
+    which = sys.argv[1:] or ["decoder", "hf", "sam", "sam_hd80"]
     if "decoder" in which:
         run(TRAIN_CASE, "train_step", FULL, seed_gt=9)
     if "hf" in which:
         run(TRAIN_ENC_CASE, "train_step_encoder", FULL_ENC, seed_gt=11)
     if "sam" in which:          # the SAM ViTDet stack trainable (window + global rel-pos attention, position embedding, SAM neck)
         run(TRAIN_SAM_CASE, "train_step_sam", FULL_SAM, seed_gt=13)
+    if "sam_hd80" in which:     # ... with 80-wide heads (SAM ViT-H style): the padded-head backward against the reference
+        run(TRAIN_SAM_HD80_CASE, "train_step_sam_hd80", FULL_SAM, seed_gt=14)
 
 
 def _to_4x(k: str) -> str:
