@@ -63,6 +63,7 @@ timeout 300 python tools/attn_ab.py > $OUT/${R}_attn_shapes.log 2>&1
 # training-side kernels by shape: flash-attention backward next to its forward, the fp32 weight-gradient GEMM, the rel-pos backward
 timeout 300 python tools/attn_bwd_bench.py > $OUT/${R}_attn_bwd_shapes.log 2>&1
 timeout 300 python tools/gemm_tn_bench.py > $OUT/${R}_gemm_tn_shapes.log 2>&1
+timeout 300 python tools/wgrad_ab.py > $OUT/${R}_wgrad_ab_final.log 2>&1      # la_gemm_tn16 against transposes + split-K la_gemm
 timeout 300 python tools/relpos_bwd_bench.py > $OUT/${R}_relpos_bwd_bench.log 2>&1
 timeout 600 python bench.py --workload cfg3_train --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg3_train.log > /dev/null
 timeout 600 python bench.py --workload cfg3_train --train-encoder --gemm-shapes --no-cpu-baseline --no-eager-baseline 2> $OUT/${R}_gemm_shapes_cfg3_train_encoder.log > /dev/null
