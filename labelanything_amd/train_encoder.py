@@ -13,11 +13,15 @@ that arrives from the decoder graph is multiplied by a power of two that puts it
 fp32 intermediate of the encoder backward carries that factor, and the parameter gradients are un-scaled when they are folded into
 the flat gradient buffer (non-finite results: the step is repeated with a smaller factor).
   data gradients   dX = dY . W     la_gemm on W^T re-packed per step (16-bit single plane)
-  weight gradients dW += dY^T . X  la_gemm with LaGemmEpilogue.ksplit on la_transpose16 copies (16-bit MFMA, the token range cut into
-                                   independent chunks that add into dW with fp32 atomics); shapes it does not take (output widths
+  weight gradients dW += dY^T . X  la_gemm_tn16: 16-bit MFMA straight from the row-major operands (LDS transpose reads; the token range cut
+                                   into chunks that add into dW with fp32 atomics, db = colsum(dY) on the way) - rounds 3 - 4: la_gemm
+                                   with LaGemmEpilogue.ksplit on la_transpose16 copies (``tn16 = False``); shapes neither takes (widths
                                    that are not multiples of 256: the reduced test encoders) go to la_gemm_tn (exact-fp32 MFMA)
+  MLP                              the GELU and gelu' run in GEMM epilogues where the shape is on the four-wave kernel
+                                   (LaGemmEpilogue.aux16: fc1 writes activation + pre-activation, fc2's dX is multiplied by
+                                   gelu'(pre)); else la_gelu_fwd16 / la_gelu_bwd16 passes
   attention        la_attn_fwd_lse / la_attn_bwd (flash form, recomputed probabilities, csrc/attn_bwd.hip)
-  LayerNorm, GELU  la_layernorm_bwd, la_gelu_bwd16
+  LayerNorm        la_layernorm_bwd / la_layernorm_bwd_res
   SAM stack         la_relpos_terms + la_attn_fwd_relpos_lse / la_attn_bwd_relpos + la_relpos_bwd (window and global attention with the
                     decomposed rel-pos bias; gradients of rel_pos_h / rel_pos_w), windows as row gathers - see SamEncoderGraph
 Heads: 64 wide (ViT-MAE-B / -L, DINO, IN21k - cfg3, cfg5 -, SAM ViT-B / -L) natively; other widths up to 128 run ZERO-PADDED to 64 / 128
