@@ -112,6 +112,52 @@ def test_encoder_gradients_of_a_linear_functional_match_oracle_autograd(size):
     assert order[0][1] <= 1e-2, order[:6]
 
 
+def test_encoder_backward_loss_scale_retry_and_non_finite_gradients():
+    """The encoder backward scales the incoming gradient by a power of two (largest entry near TARGET_MAX), checks that every scaled
+    gradient is finite with ONE min / max reduction over its scratch and repeats with 1 / 256 of the scale when a 16-bit intermediate
+    overflowed.  A target far above what fp16 holds forces that retry: the gradients must equal the normal run's to 16-bit accuracy and
+    ``last_scale`` must be smaller than the first scale tried.  A NaN or an infinity in the incoming gradient raises instead of training on."""
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train_encoder import HfEncoderGraph
+    import tests.cases  # noqa: F401  (registers hf_tiny)
+    import math
+    cfg = _hf_cfg(224)
+    g = torch.Generator().manual_seed(5)
+    images = torch.randn(2, 3, 224, 224, generator=g).cuda()
+    lam = Lam(cfg, seed=31).cuda()
+    names = [k for k, p in lam.named_parameters() if k.startswith("image_encoder.")]
+
+    def run(target):
+        grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}
+        graph = HfEncoderGraph(lam, grads)
+        if target is not None:
+            graph.TARGET_MAX = target
+        out = graph.forward(images)
+        r = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).cuda()
+        graph.backward(r)
+        torch.cuda.synchronize()
+        first = 2.0 ** math.floor(math.log2(graph.TARGET_MAX / float(r.abs().max())))
+        return grads, graph, out, first
+
+    base, graph0, out, first0 = run(None)
+    assert graph0.last_scale == first0                                   # the normal run needs no retry
+    big, graph1, _, first1 = run(float(HfEncoderGraph.TARGET_MAX) * 2.0 ** 14)
+    assert graph1.last_scale < first1, (graph1.last_scale, first1)      # the first scale overflowed a 16-bit intermediate
+    gmax = max(float(v.abs().max()) for v in base.values())
+    for k in names:
+        assert bool(torch.isfinite(big[k]).all()), k
+        err = float((big[k] - base[k]).abs().max()) / max(float(base[k].abs().max()), 1e-2 * gmax)
+        assert err <= 1e-2, (k, err)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        grads = {k: torch.zeros_like(dict(lam.named_parameters())[k]) for k in names}
+        graph = HfEncoderGraph(lam, grads)
+        graph.forward(images)
+        r = torch.randn(out.shape, generator=torch.Generator().manual_seed(7)).cuda()
+        r[3, 5] = bad
+        with pytest.raises(FloatingPointError):
+            graph.backward(r)
+
+
 def test_training_step_with_trainable_encoder_matches_oracle_autograd():
     """LamTrainer(train_encoder=True) on the hf_tiny episode: loss, logits and EVERY parameter's gradient (encoder included) against
     the oracle's autograd.  The decoder of a random-weight model amplifies the encoder's 16-bit operand error (the frozen-encoder
