@@ -305,6 +305,13 @@ int la_attn_small_bwd(const float* q, int ldq, const float* k, int ldk, const fl
 int la_bilinear_bwd(const float* dy, int n, int oh, int ow, long dy_plane, int dy_ld, float* dx, int ih, int iw, long dx_plane, int dx_ld,
                     void* stream);
 
+/* The same adjoint for REDUCTIONS (oh <= ih, ow <= iw: the 64 x 64 -> grid resize of a dense mask embedding, prompt_encoder.py:528-540), as a
+ * gather: every dx entry is a sum of <= 2 x 2 taps in a fixed order - no atomics, and dx is WRITTEN (no zero-filled destination).
+ * la_bilinear_bwd_set_ok says whether a shape qualifies (ih, iw <= 128, oh * ow <= 4096). */
+int la_bilinear_bwd_set_ok(int oh, int ow, int ih, int iw);
+int la_bilinear_bwd_set(const float* dy, int n, int oh, int ow, long dy_plane, int dy_ld, float* dx, int ih, int iw, long dx_plane, int dx_ld,
+                        void* stream);
+
 /* Backward of la_classify: dfeat[b, pix, f] (written), dprotos[b, c, f] (ACCUMULATED).  C <= 32, cf in {8, 16, 32, 64}. */
 int la_classify_bwd(const float* dseg, const float* feat, const float* protos, int B, int npix, int C, int cf, float* dfeat, float* dprotos,
                     void* stream);

@@ -1033,3 +1033,27 @@ def test_gemm_residual_that_repeats_every_res_mod_rows_on_the_four_wave_kernel(L
     torch.cuda.synchronize()
     ref = (a.double() @ w.double().t() + bias.double() + pos.double().repeat(m // period, 1)).float()
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(7, 64, 64, 30, 30), (3, 64, 64, 64, 64), (5, 37, 50, 36, 17), (2, 128, 128, 64, 63), (4, 16, 16, 1, 1)])
+def test_bilinear_backward_as_a_gather_matches_autograd(L, shape):
+    """la_bilinear_bwd_set (reductions: every dx entry a sum of <= 2 x 2 taps, written, no atomics) against torch autograd of
+    F.interpolate(mode="bilinear", align_corners=False) and against the scatter kernel la_bilinear_bwd on a zero-filled destination."""
+    n, ih, iw, oh, ow = shape
+    assert L.bilinear_bwd_set_ok(oh, ow, ih, iw) and not L.bilinear_bwd_set_ok(ih + 1, ow, ih, iw) and not L.bilinear_bwd_set_ok(oh, ow, 129, iw)
+    x = rnd(n, ih, iw, seed=211).double().requires_grad_(True)
+    dy = rnd(n, oh, ow, seed=212)
+    F.interpolate(x.unsqueeze(0), size=(oh, ow), mode="bilinear", align_corners=False)[0].backward(dy.double())
+    dx = torch.full((n, ih, iw), float("nan"), device="cuda")
+    L.bilinear_bwd_set(dy, n, oh, ow, oh * ow, ow, dx, ih, iw, ih * iw, iw)
+    dx2 = torch.zeros(n, ih, iw, device="cuda")
+    L.bilinear_bwd(dy, n, oh, ow, oh * ow, ow, dx2, ih, iw, ih * iw, iw)
+    torch.cuda.synchronize()
+    ref = x.grad.float()
+    # (tap weights are formed in fp32 from coordinates up to 128: a few 1e-6 of the fp64 reference; the two kernels share them)
+    assert rel_err(dx, ref) < 3e-5 and rel_err(dx2, ref) < 3e-5 and rel_err(dx, dx2) < 1e-6
+    # a destination frame with padding around the plane (explicit strides): only the ih x iw region is written
+    frame = torch.full((n, ih + 3, iw + 5), 7.0, device="cuda")
+    L.bilinear_bwd_set(dy, n, oh, ow, oh * ow, ow, frame, ih, iw, (ih + 3) * (iw + 5), iw + 5)
+    torch.cuda.synchronize()
+    assert torch.equal(frame[:, :ih, :iw], dx) and bool((frame[:, ih:, :] == 7.0).all()) and bool((frame[:, :, iw:] == 7.0).all())
