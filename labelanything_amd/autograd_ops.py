@@ -149,6 +149,74 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     return _Linear.apply(x, w, b)
 
 
+class _LinearFan(Function):
+    """y_i = (x [+ pe]) W_i^T + b_i for i < n: several projections of ONE input as one autograd node - the image-side stream of the
+    TwoWayTransformer feeds k_proj / v_proj of tokens -> image and q_proj of image -> tokens in the same layer (transformer.py:255-329,
+    common.py:103-105), k and q from keys + pe.  Forward: the same launches as n separate ``linear`` calls (bit-identical outputs); backward:
+    the n data gradients are added in ONE buffer through the GEMM's fp32 residual epilogue instead of n - 1 fan-in adds by autograd (three
+    passes over the 270000 x 256 stream each on cfg3), and keys + pe is formed once.  pe: [period, D] without gradient, or None."""
+
+    @staticmethod
+    def forward(ctx, x, pe, use_pe, *wb):
+        x = _c(x)
+        n = len(wb) // 2
+        xp = x
+        if pe is not None and any(use_pe):
+            pe = _c(pe)
+            xp = torch.empty_like(x)
+            L.add_cast(x, pe, pe.shape[0] if pe.shape[0] != x.shape[0] else 0, out32=xp, dt=L.LA_F32)
+        ws, outs, bkeys = [], [], []
+        for i in range(n):
+            w, b = _c(wb[2 * i]), wb[2 * i + 1]
+            y = x.new_empty(x.shape[0], w.shape[0])
+            L.gemm(xp if use_pe[i] else x, w, bias=b, out32=y)
+            ws.append(w)
+            outs.append(y)
+            bkeys.append((b.data_ptr(), tuple(b.shape)) if b is not None and b.is_contiguous() else None)
+        ctx.save_for_backward(x, xp, *ws)
+        ctx.use_pe, ctx.has_bias, ctx.bias_keys, ctx.n = tuple(use_pe), [wb[2 * i + 1] is not None for i in range(n)], bkeys, n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, xp, *ws = ctx.saved_tensors
+        n = ctx.n
+        dx = None
+        grads = [None] * (2 * n)
+        for i in range(n):
+            if dys[i] is None:
+                continue
+            dy, w = _c(dys[i]), ws[i]
+            if ctx.needs_input_grad[0]:
+                wt = WT.get(w)
+                if dx is None:
+                    dx = torch.empty_like(x)
+                    L.gemm(dy, wt, out32=dx)
+                else:
+                    L.gemm(dy, wt, res=dx, out32=dx)            # dx += dY_i . W_i in the epilogue
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * i], ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]
+            gw = SINK.find(w) if need_w else None
+            gb = SINK.find_ptr(*ctx.bias_keys[i]) if need_b and ctx.bias_keys[i] is not None and SINK.map else None
+            if need_b and gb is None:
+                grads[2 * i + 1] = dy.new_zeros(dy.shape[1])
+            bsum = gb if gb is not None else grads[2 * i + 1]
+            if need_w:
+                if gw is None:
+                    grads[2 * i] = torch.zeros_like(w)
+                L.gemm_tn(dy, xp if ctx.use_pe[i] else x, gw if gw is not None else grads[2 * i], bsum if need_b else None)
+            elif need_b:
+                L.colsum_acc(dy, bsum)
+        return (dx, None, None, *grads)
+
+
+def linear_fan(x: Tensor, pe: Optional[Tensor], projections) -> tuple:
+    """projections: [(weight, bias or None, add_pe), ...] -> one output per entry (see _LinearFan)."""
+    flat = []
+    for w, b, _ in projections:
+        flat += [w, b]
+    return _LinearFan.apply(x, pe, tuple(bool(f) for _, _, f in projections), *flat)
+
+
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, gelu):

@@ -122,10 +122,16 @@ class DecoderGraph:
         a = A.conv3x3(a, self.w[pre + ".2.weight"], None, bn, g, g)
         return self.ln(pre + ".3", a, 1e-6)
 
-    def attn(self, pre: str, q_in: Tensor, k_in: Tensor, v_in: Tensor, groups: int, nq: int, nk: int) -> Tensor:
-        """Attention of models/common.py:57-148 (projections, softmax(qk^T/sqrt(c_head)) v, out_proj)."""
-        q, k, v = self.lin(pre + ".q_proj", q_in), self.lin(pre + ".k_proj", k_in), self.lin(pre + ".v_proj", v_in)
+    def attn(self, pre: str, q_in: Tensor, k_in: Tensor, v_in: Tensor, groups: int, nq: int, nk: int, q=None, k=None, v=None) -> Tensor:
+        """Attention of models/common.py:57-148 (projections, softmax(qk^T/sqrt(c_head)) v, out_proj).  q / k / v: projections the caller
+        already holds (two_way: the image-side ones of a layer come out of one ``A.linear_fan`` node)."""
+        q = self.lin(pre + ".q_proj", q_in) if q is None else q
+        k = self.lin(pre + ".k_proj", k_in) if k is None else k
+        v = self.lin(pre + ".v_proj", v_in) if v is None else v
         return self.lin(pre + ".out_proj", A.attention(q, k, v, groups, nq, nk, self.cfg.dec_heads))
+
+    def _wb(self, name: str, add_pe: bool):
+        return (self.w[name + ".weight"], self.w.get(name + ".bias"), add_pe)
 
     def attention_mlp_block(self, pre: str, x: Tensor, groups: int, n: int) -> Tensor:
         """common.py:151-184: y = LN(attn(x) + x); out = LN(mlp(y) + y), one shared LayerNorm, GELU."""
@@ -144,18 +150,21 @@ class DecoderGraph:
                 qq = A.add_rows(qs, tpe)
                 qs = A.add_rows(qs, self.attn(lp + ".self_attn", qq, qq, qs, groups, nt, nt))
             qs = self.ln(lp + ".norm1", qs, 1e-5)
-            kk = A.add_rows(keys, pe)
-            qs = self.ln(lp + ".norm2", A.add_rows(qs, self.attn(lp + ".cross_attn_token_to_image", A.add_rows(qs, tpe), kk, keys,
-                                                                 groups, nt, hw)), 1e-5)
+            # the layer's three projections of the image-side stream - k (keys + pe), v (keys) of tokens -> image, q (keys + pe) of
+            # image -> tokens - as ONE node: their data gradients meet in one buffer instead of two fan-in passes over the stream
+            t2i, i2t = lp + ".cross_attn_token_to_image", lp + ".cross_attn_image_to_token"
+            k_img, v_img, q_img = A.linear_fan(keys, pe, [self._wb(t2i + ".k_proj", True), self._wb(t2i + ".v_proj", False),
+                                                          self._wb(i2t + ".q_proj", True)])
+            qs = self.ln(lp + ".norm2", A.add_rows(qs, self.attn(t2i, A.add_rows(qs, tpe), None, None, groups, nt, hw, k=k_img, v=v_img)), 1e-5)
             m = self.lin(lp + ".mlp.lin2", A.relu(self.lin(lp + ".mlp.lin1", qs)))
             qs = self.ln(lp + ".norm3", A.add_rows(qs, m), 1e-5)
-            keys = self.ln(lp + ".norm4", A.add_rows(keys, self.attn(lp + ".cross_attn_image_to_token", kk, A.add_rows(qs, tpe), qs,
-                                                                     groups, hw, nt)), 1e-5)
+            keys = self.ln(lp + ".norm4", A.add_rows(keys, self.attn(i2t, None, A.add_rows(qs, tpe), qs, groups, hw, nt, q=q_img)), 1e-5)
         if not want_tokens:
             return None, keys
+        fin = pre + ".final_attn_token_to_image"
+        k_img, v_img = A.linear_fan(keys, pe, [self._wb(fin + ".k_proj", True), self._wb(fin + ".v_proj", False)])
         qs = self.ln(pre + ".norm_final_attn",
-                     A.add_rows(qs, self.attn(pre + ".final_attn_token_to_image", A.add_rows(qs, tpe), A.add_rows(keys, pe), keys,
-                                              groups, nt, hw)), 1e-5)
+                     A.add_rows(qs, self.attn(fin, A.add_rows(qs, tpe), None, None, groups, nt, hw, k=k_img, v=v_img)), 1e-5)
         return qs, keys
 
     # ---- prompt encoder (prompt_encoder.py:564-827) ----------------------------------------------------------------------------
