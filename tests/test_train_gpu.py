@@ -382,3 +382,39 @@ def test_weight_transposes_in_one_launch_and_the_trainer_side_cache():
         assert t.data_ptr() == f.data_ptr() and torch.equal(t, v.t().contiguous())
     other = torch.randn(7, 9, generator=g).cuda()            # not a view of the flat buffer: transposed on its own, not cached
     assert torch.equal(wt.get(other), other.t().contiguous()) and len(wt.entries) == 3
+
+
+@pytest.mark.parametrize("period", [30, 0])
+def test_linear_fan_matches_separate_linear_nodes(period):
+    """autograd_ops.linear_fan (several projections of one input as ONE node: the image-side k / v / q of a two-way layer) against the
+    separate ``add_rows`` + ``linear`` nodes it replaces: outputs bit-identical (same launches), data gradient equal to autograd's
+    fan-in sum up to the order of three fp32 additions, weight / bias gradients bit-identical (same kernel on the same operands)."""
+    from labelanything_amd import autograd_ops as A
+    g = torch.Generator().manual_seed(17)
+    rows, d, di = 30 * 7, 64, 32
+    x0 = torch.randn(rows, d, generator=g).cuda()
+    pe = torch.randn(period, d, generator=g).cuda() if period else None
+    ws = [(torch.randn(di, d, generator=g) / 8).cuda() for _ in range(3)]
+    bs = [torch.randn(di, generator=g).cuda(), None, torch.randn(di, generator=g).cuda()]
+    use = [True, False, True]
+    rs = [torch.randn(rows, di, generator=g).cuda() for _ in range(3)]
+
+    def leaves():
+        return (x0.clone().requires_grad_(True), [w.clone().requires_grad_(True) for w in ws],
+                [b.clone().requires_grad_(True) if b is not None else None for b in bs])
+
+    x, w, b = leaves()
+    outs = A.linear_fan(x, pe, [(w[i], b[i], use[i] and pe is not None) for i in range(3)])
+    sum((o * r).sum() for o, r in zip(outs, rs)).backward()
+    x2, w2, b2 = leaves()
+    xp = A.add_rows(x2, pe) if pe is not None else x2
+    outs2 = [A.linear(xp if use[i] else x2, w2[i], b2[i]) for i in range(3)]
+    sum((o * r).sum() for o, r in zip(outs2, rs)).backward()
+    torch.cuda.synchronize()
+    for o, o2 in zip(outs, outs2):
+        assert torch.equal(o, o2)
+    assert rel_err(x.grad, x2.grad) < 1e-6
+    for i in range(3):
+        assert torch.equal(w[i].grad, w2[i].grad)
+        if b[i] is not None:
+            assert torch.equal(b[i].grad, b2[i].grad)
