@@ -101,7 +101,7 @@ class KernelTimer:
         names = ["twoway_t2i", "twoway_i2t", "gemm", "layernorm", "im2col_patch", "im2col_3x3", "relpos_terms", "attn_fwd", "mask_embed", "attn_small",
                  "colmean", "class_mean", "classify", "add_cast", "bilinear", "post_final", "point_embed", "nchw_to_nhwc",
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
-                 "attn_small_bwd", "bilinear_bwd", "bilinear_bwd_set", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
+                 "attn_small_bwd", "bilinear_bwd", "bilinear_bwd_set", "bilinear_rows", "bilinear_rows_bwd_set", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
                  "attn_fwd_lse", "attn_bwd", "head_transpose", "cast", "gelu_bwd16", "axpy", "transpose16", "colmean16", "layernorm_g", "add_rowvec", "add_rowvec_split", "qk_fp8", "attn_fwd_fp8", "attn_fwd_cs", "colsum_fold", "gelu_fwd16",
                  "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows", "gemm_tn16"]
         for n in names:

@@ -312,6 +312,12 @@ int la_bilinear_bwd_set_ok(int oh, int ow, int ih, int iw);
 int la_bilinear_bwd_set(const float* dy, int n, int oh, int ow, long dy_plane, int dy_ld, float* dx, int ih, int iw, long dx_plane, int dx_ld,
                         void* stream);
 
+/* The same resize on NHWC rows, forward and (reductions, la_bilinear_bwd_set_ok) backward: in [N, h * w, C] -> out [N, H * W, C], C % 4 == 0 -
+ * the dense mask embedding of the TRAINING graph (prompt_encoder.py:528-540) without plane transposes around the resize; taps and blend
+ * are those of la_bilinear per channel.  la_bilinear_rows_bwd_set WRITES dx [n, ih * iw, C] from dy [n, oh * ow, C]. */
+int la_bilinear_rows(const float* in, int N, int h, int w, int C, float* out, int H, int W, void* stream);
+int la_bilinear_rows_bwd_set(const float* dy, int n, int oh, int ow, int C, float* dx, int ih, int iw, void* stream);
+
 /* Backward of la_classify: dfeat[b, pix, f] (written), dprotos[b, c, f] (ACCUMULATED).  C <= 32, cf in {8, 16, 32, 64}. */
 int la_classify_bwd(const float* dseg, const float* feat, const float* protos, int B, int npix, int C, int cf, float* dfeat, float* dprotos,
                     void* stream);

@@ -61,7 +61,7 @@ EXPORTS = [
     "la_dense_pe", "la_point_embed", "la_mask_embed", "la_attn_small", "la_colmean", "la_class_mean",
     "la_classify", "la_add_cast", "la_conv3x3_f32", "la_nchw_to_nhwc", "la_nhwc_to_nchw", "la_bilinear", "la_post_final",
     "la_confmat_update", "la_resample_u8", "la_u8_to_chw_norm", "la_prompt_masks", "la_focal_loss", "la_adamw_step",
-    "la_gemm_tn", "la_gemm_tn16", "la_gemm_fused_act_ok", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd", "la_bilinear_bwd_set", "la_bilinear_bwd_set_ok",
+    "la_gemm_tn", "la_gemm_tn16", "la_gemm_fused_act_ok", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd", "la_bilinear_bwd_set", "la_bilinear_bwd_set_ok", "la_bilinear_rows", "la_bilinear_rows_bwd_set",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
 ]
@@ -432,6 +432,17 @@ def attn_small_bwd(q, k, v, o, dout, lse, b: int, nq: int, nk: int, heads: int, 
     _check(lib().la_attn_small_bwd(_ptr(q), C.c_int(q.stride(0)), _ptr(k), C.c_int(k.stride(0)), _ptr(v), C.c_int(v.stride(0)), _ptr(o),
                                    _ptr(dout), C.c_int(dout.stride(0)), _ptr(lse), C.c_int(b), C.c_int(nq), C.c_int(nk), C.c_int(heads),
                                    C.c_int(hd), _ptr(dq), _ptr(dk), _ptr(dv), _stream()), "la_attn_small_bwd")
+
+
+def bilinear_rows(x, n: int, h: int, w: int, c: int, oh: int, ow: int, out) -> None:
+    """la_bilinear_rows: NHWC rows [n, h * w, c] -> [n, oh * ow, c] (bilinear, align_corners=False)."""
+    _check(lib().la_bilinear_rows(_ptr(x), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), _ptr(out), C.c_int(oh), C.c_int(ow), _stream()), "la_bilinear_rows")
+
+
+def bilinear_rows_bwd_set(dy, n: int, oh: int, ow: int, c: int, dx, ih: int, iw: int) -> None:
+    """la_bilinear_rows_bwd_set: adjoint of bilinear_rows for reductions (bilinear_bwd_set_ok), dx written."""
+    _check(lib().la_bilinear_rows_bwd_set(_ptr(dy), C.c_int(n), C.c_int(oh), C.c_int(ow), C.c_int(c), _ptr(dx), C.c_int(ih), C.c_int(iw), _stream()),
+           "la_bilinear_rows_bwd_set")
 
 
 def bilinear_bwd_set_ok(oh: int, ow: int, ih: int, iw: int) -> bool:

@@ -496,6 +496,39 @@ class _PlanesToRows(Function):
         return dx, None, None, None
 
 
+class _BilinearRows(Function):
+    """Bilinear resize of NHWC rows [n * h * w, c] -> [n * oh * ow, c] (la_bilinear_rows) - the dense mask embedding between the mask
+    downscaler's 4x-reduced map and the embedding grid (prompt_encoder.py:528-540) without the plane transposes around the planar kernel.
+    Backward: reductions are gathered on rows too (la_bilinear_rows_bwd_set); other shapes go through the planar adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, n, h, w, c, oh, ow):
+        x = _c(x)
+        out = x.new_empty(n * oh * ow, c)
+        L.bilinear_rows(x, n, h, w, c, oh, ow, out)
+        ctx.dims = (n, h, w, c, oh, ow)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c, oh, ow = ctx.dims
+        dy = _c(dy)
+        dx = dy.new_empty(n * h * w, c)
+        if L.bilinear_bwd_set_ok(oh, ow, h, w):
+            L.bilinear_rows_bwd_set(dy, n, oh, ow, c, dx, h, w)
+        else:
+            planes = dy.new_empty(n * c, oh * ow)
+            L.nhwc_to_nchw(dy, n, c, oh * ow, planes)
+            dpl = dy.new_zeros(n * c, h, w)
+            L.bilinear_bwd(planes, n * c, oh, ow, oh * ow, ow, dpl, h, w, h * w, w)
+            L.nchw_to_nhwc(dpl.view(n * c, h * w), n, c, h * w, out32=dx, dt=L.LA_F32)
+        return dx, None, None, None, None, None, None
+
+
+def bilinear_rows(x: Tensor, n: int, h: int, w: int, c: int, oh: int, ow: int) -> Tensor:
+    return _BilinearRows.apply(x, n, h, w, c, oh, ow)
+
+
 def rows_to_planes(x: Tensor, n: int, c: int, hw: int) -> Tensor:
     return _RowsToPlanes.apply(x, n, c, hw)
 

@@ -37,6 +37,34 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__
   }
 }
 
+// NHWC rows [N, h * w, C] -> [N, H * W, C]: the same taps and the same blend per channel, four channels per thread - the resize of a dense mask
+// embedding in the training graph without the plane transposes around it (prompt_encoder.py:528-540; 2 x 1.3 GB per direction on cfg3)
+__global__ __launch_bounds__(256) void bilinear_rows_kernel(const float* __restrict__ in, int N, int h, int w, int C, int H, int W,
+                                                            float* __restrict__ out) {
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int c4 = C >> 2;
+  const long total = (long)N * H * W * c4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4);
+    const long pix = i / c4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long n = pix / ((long)W * H);
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    tap(y, sy, h, y0, y1, wy0, wy1);
+    tap(x, sx, w, x0, x1, wx0, wx1);
+    const float4* p = reinterpret_cast<const float4*>(in) + n * h * w * c4 + c;
+    const float4 a00 = p[(long)(y0 * w + x0) * c4], a01 = p[(long)(y0 * w + x1) * c4];
+    const float4 a10 = p[(long)(y1 * w + x0) * c4], a11 = p[(long)(y1 * w + x1) * c4];
+    float4 o;
+    o.x = wy0 * (wx0 * a00.x + wx1 * a01.x) + wy1 * (wx0 * a10.x + wx1 * a11.x);
+    o.y = wy0 * (wx0 * a00.y + wx1 * a01.y) + wy1 * (wx0 * a10.y + wx1 * a11.y);
+    o.z = wy0 * (wx0 * a00.z + wx1 * a01.z) + wy1 * (wx0 * a10.z + wx1 * a11.z);
+    o.w = wy0 * (wx0 * a00.w + wx1 * a01.w) + wy1 * (wx0 * a10.w + wx1 * a11.w);
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+
 // Second half of postprocess_masks for a batch: per item b the S x S logits are cropped to (ph, pw), resampled to
 // the original (oh, ow), written into the (Hmax, Wmax) frame padded with -inf (class 0 padded with 0), classes
 // without ground truth forced to -inf, and the class argmax is taken (first maximal index, as torch.argmax).
@@ -87,6 +115,15 @@ extern "C" int la_bilinear(const float* in, int N, int h, int w, int H, int W, f
   const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   hipLaunchKernelGGL(la::bilinear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, N, h, w, H, W, out);
   LA_CHECK_LAUNCH("la_bilinear");
+  return 0;
+}
+
+extern "C" int la_bilinear_rows(const float* in, int N, int h, int w, int C, float* out, int H, int W, void* stream) {
+  LA_CHECK_ARG(in && out && N > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0, "la_bilinear_rows: bad arguments (C %% 4 == 0)");
+  const long total = (long)N * H * W * (C / 4);
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(la::bilinear_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, N, h, w, C, H, W, out);
+  LA_CHECK_LAUNCH("la_bilinear_rows");
   return 0;
 }
 

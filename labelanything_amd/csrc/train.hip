@@ -846,6 +846,42 @@ __global__ __launch_bounds__(256) void bilinear_bwd_gather_kernel(const float* _
   }
 }
 
+// ... and on NHWC rows (adjoint of la_bilinear_rows): workgroup = one input row (n, iy) of dx [N, ih * iw, C]; its <= 2 output rows and the x
+// taps of every column come from the same tables, a thread adds the <= 2 x 2 float4 of dy for four channels of one pixel.
+__global__ __launch_bounds__(256) void bilinear_rows_bwd_gather_kernel(const float* __restrict__ dy, int oh, int ow, int C, float* __restrict__ dx,
+                                                                       int ih, int iw) {
+  __shared__ int ycnt[BG_MAXDIM], xcnt[BG_MAXDIM], yidx[BG_MAXDIM * BG_KMAX], xidx[BG_MAXDIM * BG_KMAX];
+  __shared__ float ywt[BG_MAXDIM * BG_KMAX], xwt[BG_MAXDIM * BG_KMAX];
+  const long n = blockIdx.x / ih;
+  const int iy = blockIdx.x % ih;
+  const float sy = (float)ih / (float)oh, sx = (float)iw / (float)ow;
+  for (int i = threadIdx.x; i < iw + 1; i += 256) {
+    if (i < iw) bg_taps(i, iw, ow, sx, xcnt, xidx, xwt);
+    else bg_taps(iy, ih, oh, sy, ycnt, yidx, ywt);
+  }
+  __syncthreads();
+  const int c4 = C >> 2, ny = ycnt[iy];
+  const float4* g = reinterpret_cast<const float4*>(dy) + n * oh * ow * c4;
+  float4* out = reinterpret_cast<float4*>(dx) + (n * ih + iy) * iw * c4;
+  for (int e = threadIdx.x; e < iw * c4; e += 256) {
+    const int ix = e / c4, c = e % c4;
+    const int nx = xcnt[ix];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < ny; ++ky) {
+      const float4* row = g + (long)yidx[iy * BG_KMAX + ky] * ow * c4 + c;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kx = 0; kx < nx; ++kx) {
+        const float wx = xwt[ix * BG_KMAX + kx];
+        const float4 v = row[(long)xidx[ix * BG_KMAX + kx] * c4];
+        r.x += wx * v.x; r.y += wx * v.y; r.z += wx * v.z; r.w += wx * v.w;
+      }
+      const float wy = ywt[iy * BG_KMAX + ky];
+      acc.x += wy * r.x; acc.y += wy * r.y; acc.z += wy * r.z; acc.w += wy * r.w;
+    }
+    out[e] = acc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // seg[b, c, pix] = sum_f protos[b, c, f] feat[b, pix, f]  ->  dfeat[b, pix, f] = sum_c dseg[b, c, pix] protos[b, c, f],
 // dprotos[b, c, f] += sum_pix dseg[b, c, pix] feat[b, pix, f]  (wave reduction + one atomic per wave).  C <= 32, CF <= 64.
@@ -1269,6 +1305,16 @@ extern "C" int la_bilinear_bwd_set(const float* dy, int n, int oh, int ow, long 
   hipLaunchKernelGGL(la::bilinear_bwd_gather_kernel, dim3(n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, oh, ow, dy_plane, dy_ld, dx,
                      ih, iw, dx_plane, dx_ld);
   LA_CHECK_LAUNCH("la_bilinear_bwd_set");
+  return 0;
+}
+
+extern "C" int la_bilinear_rows_bwd_set(const float* dy, int n, int oh, int ow, int C, float* dx, int ih, int iw, void* stream) {
+  LA_CHECK_ARG(dy && dx && n > 0 && C > 0 && (C % 4) == 0, "la_bilinear_rows_bwd_set: bad arguments (C %% 4 == 0)");
+  LA_CHECK_ARG(la_bilinear_bwd_set_ok(oh, ow, ih, iw), "la_bilinear_rows_bwd_set: a reduction with ih, iw <= %d (got %d x %d -> %d x %d)", la::BG_MAXDIM,
+               ih, iw, oh, ow);
+  hipLaunchKernelGGL(la::bilinear_rows_bwd_gather_kernel, dim3((unsigned)((long)n * ih)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, oh,
+                     ow, C, dx, ih, iw);
+  LA_CHECK_LAUNCH("la_bilinear_rows_bwd_set");
   return 0;
 }
 

@@ -187,9 +187,12 @@ class DecoderGraph:
         w6 = self.w[pre + ".6.weight"]
         dense = A.linear(a, w6.reshape(w6.shape[0], -1), self.w[pre + ".6.bias"])                    # [P*h4*h4, D]
         if h4 != g:
-            planes = A.rows_to_planes(dense, p, d, h4 * h4).reshape(p * d, h4, h4)
-            planes = A.bilinear(planes, g, g)
-            dense = A.planes_to_rows(planes.reshape(p * d, g * g), p, d, g * g)
+            if d % 4 == 0:
+                dense = A.bilinear_rows(dense, p, h4, h4, d, g, g)           # on the NHWC rows: no plane transposes around the resize
+            else:
+                planes = A.rows_to_planes(dense, p, d, h4 * h4).reshape(p * d, h4, h4)
+                planes = A.bilinear(planes, g, g)
+                dense = A.planes_to_rows(planes.reshape(p * d, g * g), p, d, g * g)
         missing = (flags.reshape(p) == 0).view(p, 1, 1)
         nam = self.w["prompt_encoder.not_a_mask_embed.weight"].view(1, 1, d)
         return torch.where(missing, nam, dense.reshape(p, g * g, d)).reshape(p * g * g, d)

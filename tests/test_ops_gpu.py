@@ -1057,3 +1057,29 @@ def test_bilinear_backward_as_a_gather_matches_autograd(L, shape):
     L.bilinear_bwd_set(dy, n, oh, ow, oh * ow, ow, frame, ih, iw, (ih + 3) * (iw + 5), iw + 5)
     torch.cuda.synchronize()
     assert torch.equal(frame[:, :ih, :iw], dx) and bool((frame[:, ih:, :] == 7.0).all()) and bool((frame[:, :, iw:] == 7.0).all())
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 64, 30, 30, 256), (2, 16, 24, 16, 24, 8), (2, 40, 33, 17, 20, 12), (2, 8, 8, 20, 20, 16)])
+def test_bilinear_on_nhwc_rows_forward_and_backward(L, shape):
+    """la_bilinear_rows against F.interpolate on the planes and - bit for bit - against la_bilinear on transposed planes (same taps, same
+    blend); its autograd node (gathered adjoint for reductions, planar adjoint otherwise) against torch autograd."""
+    from labelanything_amd import autograd_ops as A
+    n, h, w, oh, ow, c = shape
+    x = rnd(n * h * w, c, seed=221)
+    out = torch.empty(n * oh * ow, c, device="cuda")
+    L.bilinear_rows(x, n, h, w, c, oh, ow, out)
+    planes = x.view(n, h * w, c).permute(0, 2, 1).reshape(n * c, h, w).contiguous()
+    pout = torch.empty(n * c, oh, ow, device="cuda")
+    L.bilinear(planes, n * c, h, w, oh, ow, pout)
+    torch.cuda.synchronize()
+    assert torch.equal(out, pout.view(n, c, oh * ow).permute(0, 2, 1).reshape(n * oh * ow, c))
+    xd = planes.view(n, c, h, w).double().requires_grad_(True)
+    ref = F.interpolate(xd, size=(oh, ow), mode="bilinear", align_corners=False)
+    assert rel_err(pout.view(n, c, oh, ow), ref.detach().float()) < 3e-5
+    r = rnd(n * oh * ow, c, seed=222)
+    ref.backward(r.view(n, oh * ow, c).permute(0, 2, 1).reshape(n, c, oh, ow).double())
+    xr = x.clone().requires_grad_(True)
+    (A.bilinear_rows(xr, n, h, w, c, oh, ow) * r).sum().backward()
+    torch.cuda.synchronize()
+    gref = xd.grad.float().view(n, c, h * w).permute(0, 2, 1).reshape(n * h * w, c)
+    assert rel_err(xr.grad, gref) < 3e-5
