@@ -4,11 +4,13 @@ import torch, bench
 from torch.profiler import profile, ProfilerActivity
 from labelanything_amd.train import LamTrainer
 enc = "--train-encoder" in sys.argv
-lam, cfg = bench.build_model(torch.float16, torch.float32, "cfg3_train", None)
+wl = next((a.split("=")[1] for a in sys.argv if a.startswith("--workload=")), "cfg3_train")
+lam, cfg = bench.build_model(torch.float16, torch.float32, wl, None)
 lam = lam.cuda()
-batch = bench.make_inputs(2, 1234, torch.device("cuda"), "cfg3_train")
+batch = bench.make_inputs(2, 1234, torch.device("cuda"), wl)
 tr = LamTrainer(lam, lr=5e-5, num_warmup_steps=1000, train_encoder=enc)
-gt = torch.randint(0, batch["flag_examples"].shape[2], (2, 480, 480)).cuda()
+size = bench.WORKLOADS[wl]["episode"]["image_size"]
+gt = torch.randint(0, batch["flag_examples"].shape[2], (2, size, size)).cuda()
 for _ in range(2):
     tr.step(batch, gt)
 torch.cuda.synchronize()
