@@ -436,11 +436,19 @@ def attn_small_bwd(q, k, v, o, dout, lse, b: int, nq: int, nk: int, heads: int, 
 
 def bilinear_rows(x, n: int, h: int, w: int, c: int, oh: int, ow: int, out) -> None:
     """la_bilinear_rows: NHWC rows [n, h * w, c] -> [n, oh * ow, c] (bilinear, align_corners=False)."""
+    _f32c(x, out)
+    if c % 4 or x.numel() != n * h * w * c or out.numel() != n * oh * ow * c:
+        raise ValueError(f"la_bilinear_rows: [{n}, {h}x{w}, {c}] -> [{n}, {oh}x{ow}, {c}] needs c % 4 == 0 and tensors of exactly those "
+                         f"sizes (got {x.numel()} and {out.numel()} elements)")
     _check(lib().la_bilinear_rows(_ptr(x), C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(c), _ptr(out), C.c_int(oh), C.c_int(ow), _stream()), "la_bilinear_rows")
 
 
 def bilinear_rows_bwd_set(dy, n: int, oh: int, ow: int, c: int, dx, ih: int, iw: int) -> None:
     """la_bilinear_rows_bwd_set: adjoint of bilinear_rows for reductions (bilinear_bwd_set_ok), dx written."""
+    _f32c(dy, dx)
+    if c % 4 or dy.numel() != n * oh * ow * c or dx.numel() != n * ih * iw * c or not bilinear_bwd_set_ok(oh, ow, ih, iw):
+        raise ValueError(f"la_bilinear_rows_bwd_set: dy [{n}, {oh}x{ow}, {c}] -> dx [{n}, {ih}x{iw}, {c}] needs c % 4 == 0, a reduction "
+                         f"the gathered adjoint takes (bilinear_bwd_set_ok) and tensors of exactly those sizes (got {dy.numel()} and {dx.numel()})")
     _check(lib().la_bilinear_rows_bwd_set(_ptr(dy), C.c_int(n), C.c_int(oh), C.c_int(ow), C.c_int(c), _ptr(dx), C.c_int(ih), C.c_int(iw), _stream()),
            "la_bilinear_rows_bwd_set")
 
@@ -452,6 +460,11 @@ def bilinear_bwd_set_ok(oh: int, ow: int, ih: int, iw: int) -> bool:
 
 def bilinear_bwd_set(dy, n: int, oh: int, ow: int, dy_plane: int, dy_ld: int, dx, ih: int, iw: int, dx_plane: int, dx_ld: int) -> None:
     """la_bilinear_bwd_set: the adjoint of a bilinear REDUCTION as a gather (no atomics, dx written)."""
+    _f32c(dy, dx)
+    if n <= 0 or dy_ld < ow or dx_ld < iw or (n - 1) * dy_plane + (oh - 1) * dy_ld + ow > dy.numel() or \
+            (n - 1) * dx_plane + (ih - 1) * dx_ld + iw > dx.numel() or not bilinear_bwd_set_ok(oh, ow, ih, iw):
+        raise ValueError(f"la_bilinear_bwd_set: {n} planes {oh}x{ow} (plane {dy_plane}, ld {dy_ld}) -> {ih}x{iw} (plane {dx_plane}, ld {dx_ld}) "
+                         f"reaches beyond the tensors ({dy.numel()} / {dx.numel()} elements) or is not a reduction the gathered adjoint takes")
     _check(lib().la_bilinear_bwd_set(_ptr(dy), C.c_int(n), C.c_int(oh), C.c_int(ow), C.c_long(dy_plane), C.c_int(dy_ld), _ptr(dx), C.c_int(ih),
                                      C.c_int(iw), C.c_long(dx_plane), C.c_int(dx_ld), _stream()), "la_bilinear_bwd_set")
 

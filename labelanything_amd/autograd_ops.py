@@ -162,6 +162,10 @@ class _LinearFan(Function):
         n = len(wb) // 2
         xp = x
         if pe is not None and any(use_pe):
+            if pe.requires_grad:
+                raise ValueError("linear_fan: pe must not require a gradient (the node returns none for it; use add_rows + linear for a trainable pe)")
+            if pe.dim() != 2 or pe.shape[1] != x.shape[1] or pe.shape[0] == 0 or x.shape[0] % pe.shape[0]:
+                raise ValueError(f"linear_fan: pe {tuple(pe.shape)} must be [period, {x.shape[1]}] with period dividing the {x.shape[0]} rows of x")
             pe = _c(pe)
             xp = torch.empty_like(x)
             L.add_cast(x, pe, pe.shape[0] if pe.shape[0] != x.shape[0] else 0, out32=xp, dt=L.LA_F32)

@@ -82,6 +82,9 @@ class LamConfig:
     spatial_convs: Optional[int] = None
     class_encoder: Optional[dict] = None      # {"name": "RandomMatrixEncoder", "bank_size": 100, "embed_dim": D}
     custom_preprocess: bool = True
+    # Dropout probability of the decoder-side MLP / attention blocks (models/common.py:25-32,68-75, build_lam.py:128).  An inference
+    # no-op (eval mode); remembered so that LamTrainer can refuse to train a configuration whose reference applies it.
+    dropout: float = 0.0
     # fixed in the reference for this path
     dec_heads: int = 8
     dec_mlp: int = 2048
@@ -122,7 +125,8 @@ def config_from_kwargs(**kw) -> LamConfig:
     for k, dflt in _OFF_PATH_DEFAULTS.items():
         if k in kw:
             v = kw.pop(k)
-            if k == "dropout":          # dropout is an inference no-op (eval mode); accepted like the reference does
+            if k == "dropout":          # an inference no-op (eval mode), accepted like the reference does; LamTrainer raises on != 0
+                kw["dropout"] = float(v or 0.0)
                 continue
             if v != dflt:
                 raise NotImplementedError(f"{k}={v!r} is an off-path ablation of the reference; only {dflt!r} is built")

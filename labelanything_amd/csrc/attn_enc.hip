@@ -20,6 +20,9 @@
 #ifndef LA_ATTN_ABL
 #define LA_ATTN_ABL 0       // measurement ablations of attn_fwd_kernel (results wrong): 1 no exp, 2 no S MFMAs, 4 no PV MFMAs, 8 no staging / barrier
 #endif
+#ifndef LA_ATTN_X
+#define LA_ATTN_X 0         // timing experiments (results wrong beyond tile 0): 2 no maximum pass after the first tile, 4 exp2 of the bare score, 8 no row sums
+#endif
 #include "../../include/la_hip.h"
 
 namespace la {
@@ -524,6 +527,9 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     // Scores live in "raw" units (logit / scale); true score = s + rh.  The running max is only advanced when some row
     // of the wave outgrows it by more than RESCALE_THR (in log2 units): P then stays <= 2^THR, which fp16/bf16 hold at
     // full relative precision, and the O / l rescale pass disappears from almost every tile.
+#if LA_ATTN_X & 2
+    if (j == 0) {
+#endif
     float mx = s[0][0];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -540,6 +546,9 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
       m_run = m_new;
     }
+#if LA_ATTN_X & 2
+    }
+#endif
     const float mc = (rh - m_run) * c2;
     float psum = 0.f;
 #pragma unroll
@@ -551,10 +560,16 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #if LA_ATTN_ABL & 1
         const float p = fmaf(s[t][r], c2, mc);
 #else
+#if LA_ATTN_X & 4
+        const float p = __builtin_amdgcn_exp2f(s[t][r]);
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, mc));   // raw v_exp_f32 (no denormal fix-up)
 #endif
+#endif
         s[t][r] = p;
+#if !(LA_ATTN_X & 8)
         psum += p;
+#endif
       }
     l_run += psum;
 

@@ -2118,8 +2118,11 @@ extern "C" int la_dbg_gemm_stamps_clear() {
 }
 #endif
 
+// (the persistent kernel pays off from one tile per CU of the CURRENT device - not a constant, not cached across devices)
 extern "C" int la_gemm_fused_act_ok(int M, int N, int K) {
-  return M > 0 && (N % 256) == 0 && (K % 64) == 0 && K >= 128 && (long)((M + 255) / 256) * (N / 256) >= 256 && (la::g_gemm_variant & 0xff) == 2;
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  return M > 0 && (N % 256) == 0 && (K % 64) == 0 && K >= 128 && (long)((M + 255) / 256) * (N / 256) >= ncu && (la::g_gemm_variant & 0xff) == 2;
 }
 
 extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const LaGemmEpilogue* epi, int dt,

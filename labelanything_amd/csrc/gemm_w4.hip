@@ -571,10 +571,11 @@ static void launch_t256w_abl(const void* A, int lda, const void* W, int ldw, int
   constexpr int LDS = 4 * 32768 + 4 * 8192;      // two k-tile buffers + 8 KiB slab per wave: all 160 KiB
   static unsigned long long attr_mask = 0;
   ensure_dyn_lds(reinterpret_cast<const void*>(gemm_t256w_kernel<T, EPI, ABL, DIRECT>), LDS, attr_mask);
-  static int ncu = 0;
+  static int ncu_of[64] = {0};                        // per device: a process may drive several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& ncu = ncu_of[dev & 63];
   if (ncu == 0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     if (ncu <= 0) ncu = 256;
   }

@@ -316,7 +316,18 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ x, 
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       reinterpret_cast<float4*>(x)[i] = a;
     }
-    if (SPLIT) store4_split<f16_t>(split + (size_t)r * 2 * D, D, c * 4, a.x, a.y, a.z, a.w);
+    if (SPLIT) {
+      // fp16 planes hold |x| <= 65504 in hi and as much again in lo: the planes SATURATE (|x| up to 131008 stays exact to 2^-11, beyond
+      // that the pair clamps) instead of turning into (inf, -inf) -> NaN in the three-product GEMM.  The fp32 stream itself is unchanged.
+      constexpr float H = 65504.0f, H2 = 131008.0f;
+      const float sx = __builtin_amdgcn_fmed3f(a.x, -H2, H2), sy = __builtin_amdgcn_fmed3f(a.y, -H2, H2);
+      const float sz = __builtin_amdgcn_fmed3f(a.z, -H2, H2), sw = __builtin_amdgcn_fmed3f(a.w, -H2, H2);
+      const float hx = (float)(f16_t)__builtin_amdgcn_fmed3f(sx, -H, H), hy = (float)(f16_t)__builtin_amdgcn_fmed3f(sy, -H, H);
+      const float hz = (float)(f16_t)__builtin_amdgcn_fmed3f(sz, -H, H), hw = (float)(f16_t)__builtin_amdgcn_fmed3f(sw, -H, H);
+      f16_t* row = split + (size_t)r * 2 * D;
+      store4v<f16_t>(row + c * 4, hx, hy, hz, hw);
+      store4v<f16_t>(row + D + c * 4, sx - hx, sy - hy, sz - hz, sw - hw);
+    }
   }
 }
 }  // namespace la

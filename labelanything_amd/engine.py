@@ -711,6 +711,8 @@ class LamEngine:
         xs = None
         split_neck = self.cfg.use_vit_sam_neck and (pre + ".neck.0.ws") in p
         if split_neck:                 # the stream's last pass also leaves it as fp16 plane pairs: the neck's 1 x 1 conv operand
+            # (range: the pair [hi | lo] holds |x| <= 131008 - la_add_rowvec_split saturates beyond, it never emits inf / NaN; SAM
+            # checkpoints keep the un-normalised stream three orders of magnitude below that)
             xs = self.buf("enc.res_split", (rows, 2 * e), torch.float16)
             L.add_rowvec_split(res, rvec, hw, xs)
         elif rvec is not None:         # the stream leaves the block stack: fold the pending corrections in

@@ -345,6 +345,11 @@ class LamTrainer:
         bucket, launched from inside the backward pass - they are final when the encoder backward starts.
         train_encoder=True: every parameter trains, as with parameters/trainval/coco20i/mae_noembs.yaml (no
         ``freeze_backbone``: models/lam.py:347 returns ``self.parameters()``); needs an HF ViT encoder (train_encoder.py)."""
+        if float(getattr(lam.cfg, "dropout", 0.0) or 0.0) != 0.0:
+            # the reference trains with nn.Dropout(p) inside MLPBlock / AttentionMLPBlock when it is set (models/common.py:25-32,68-75,
+            # build_lam.py:128); the training graph here has no dropout node, so training such a model would silently be a different model
+            raise NotImplementedError(f"dropout={lam.cfg.dropout} is not built into the training graph (every canonical parameters/*.yaml "
+                                      f"leaves it at 0); build the model with dropout=0.0 to train it here")
         if lam._device().type != "cuda":
             raise RuntimeError("LamTrainer needs the model on an MI355X (there is no CPU path)")
         self.lam = lam

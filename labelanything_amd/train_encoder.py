@@ -179,6 +179,9 @@ class HfEncoderGraph:
             sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             self._fc1_fwd(eng, x16b, lp + ".fc1.w", w[lp + ".intermediate.dense.bias"], sv["pre"], sv["post"])
+            # fused / unfused is decided ONCE per graph, here, for the backward half too (la_gemm_fused_act_ok reads the library's
+            # mutable kernel selection: an A/B tool that toggles it between forward and backward must not mix the two forms)
+            sv["fuse_fc2_bwd"] = bool(self.fused_gelu and L.gemm_fused_act_ok(rows, spec.mlp, e))
             res = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["post"], lp + ".fc2.w", bias=w[lp + ".output.dense.bias"], res=x_mid, out32=res)
             layers.append(sv)
@@ -203,7 +206,8 @@ class HfEncoderGraph:
         ONE product whose epilogue reads the saved pre-activation (LA_ACT_GELU_BWD) where the shape allows, else product + la_gelu_bwd16.
         dpre32 (None = not needed): the fp32 copy the exact-fp32 fallbacks of fc1's weight / bias gradient read."""
         r, n, k = dy16.shape[0], a["pre"].shape[1], dy16.shape[1]
-        if self.fused_gelu and dpre32 is None and L.gemm_fused_act_ok(r, n, k):
+        fuse = a["fuse_fc2_bwd"] if "fuse_fc2_bwd" in a else (self.fused_gelu and L.gemm_fused_act_ok(r, n, k))
+        if fuse and dpre32 is None:
             wt = self.w[wname]
             if not self._wgrad(dy16, dy32, a["post"], self.sviews[wname], db=self.sviews[bname]):
                 L.colsum_acc(dy32, self.sviews[bname])
@@ -644,6 +648,7 @@ class SamEncoderGraph(HfEncoderGraph):
             sv["post"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             sv["pre"] = torch.empty(rows, spec.mlp, device=dev, dtype=dt)
             self._fc1_fwd(eng, x16b, bp + ".lin1.w", w[bp + ".mlp.lin1.bias"], sv["pre"], sv["post"])
+            sv["fuse_fc2_bwd"] = bool(self.fused_gelu and L.gemm_fused_act_ok(rows, spec.mlp, e))      # (decided with the forward: see HfEncoderGraph)
             res = torch.empty(rows, e, device=dev)
             eng.gemm_w(sv["post"], bp + ".lin2.w", bias=w[bp + ".mlp.lin2.bias"], res=x_mid, out32=res)
             layers.append(sv)

@@ -68,6 +68,18 @@ def test_off_path_switches_are_rejected():
         config_from_kwargs(encoder="vit_b", not_an_argument=1)
 
 
+def test_dropout_is_accepted_for_inference_and_refused_by_the_trainer():
+    """models/common.py:25-32,68-75: the reference applies nn.Dropout(p) in training mode only.  Inference accepts the switch (eval-mode
+    no-op, like the reference); the trainer has no dropout node and must say so instead of silently training a different model."""
+    from labelanything_amd.models import Lam
+    from labelanything_amd.train import LamTrainer
+    cfg = config_from_kwargs(encoder=None, use_vit=False, image_size=64, embed_dim=64, image_embed_dim=64, spatial_convs=3, dropout=0.1)
+    assert cfg.dropout == pytest.approx(0.1)
+    assert config_from_kwargs(encoder=None, use_vit=False, image_size=64, embed_dim=64, image_embed_dim=64).dropout == 0.0
+    with pytest.raises(NotImplementedError, match="dropout"):
+        LamTrainer(Lam(cfg))
+
+
 def test_model_refuses_to_run_without_gpu_or_library(monkeypatch):
     from labelanything_amd.models import Lam
     lam = Lam(LamConfig(encoder=None, use_vit=False, image_size=64, embed_dim=64, image_embed_dim=64, spatial_convs=3))

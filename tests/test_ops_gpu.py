@@ -1018,6 +1018,17 @@ def test_add_rowvec_split_leaves_the_stream_as_plane_pairs(L, with_v):
     ref = (want.double() @ w.double().t()).float()
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 2e-6
+    # beyond the fp16 range the plane pair saturates (hi at 65504, lo takes the rest up to 131008) instead of becoming (inf, -inf):
+    # the stream itself keeps its fp32 values, the planes stay finite
+    big = torch.zeros(4, d, device="cuda")
+    big[0, 0], big[1, 1], big[2, 2], big[3, 3] = 7.0e4, -1.2e5, 3.0e5, -65504.0
+    keep = big.clone()
+    bs = torch.full((4, 2 * d), float("nan"), device="cuda", dtype=torch.float16)
+    L.add_rowvec_split(big, None, 1, bs)
+    torch.cuda.synchronize()
+    assert torch.equal(big, keep) and bool(torch.isfinite(bs.float()).all())
+    pair = bs[:, :d].float() + bs[:, d:].float()
+    assert abs(float(pair[0, 0]) - 7.0e4) <= 32 and abs(float(pair[1, 1]) + 1.2e5) <= 64 and float(pair[2, 2]) == 131008.0 and float(pair[3, 3]) == -65504.0
 
 
 def test_gemm_residual_that_repeats_every_res_mod_rows_on_the_four_wave_kernel(L):
