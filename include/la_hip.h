@@ -97,6 +97,24 @@ typedef struct LaGemmEpilogue {
                           the data gradient through a GELU in one pass (A = dY, W = the transposed weight).  Only shapes for which
                           la_gemm_fused_act_ok() says 1 (the persistent four-wave kernel); out16 only, no residual / maps / V^T. */
   int ldaux;
+  /* LayerNorm folded into the GEMMs on both sides of it (round 6; image_encoder.py:181-197 `x = x + attn(norm1(x))`, `x + mlp(norm2(x))`,
+   * transformers ViTLayer layernorm_before / layernorm_after): the LayerNorm pass over the residual stream (24 launches, 8 % of a cfg2
+   * step) disappears.  16-bit fp16 operands, N % 256 == 0, K % 64 == 0, K >= 128, no row maps / V^T / ksplit / aux16: the direct epilogue
+   * of the persistent four-wave kernel.
+   * PRODUCER (the GEMM that writes the stream; needs res or bias, out32 AND out16): nstat_out != NULL - beside out32 = acc + bias + res
+   *   (+ rvec[row / rvec_rpg][col], a per-group fp32 vector [groups, N]: the token-mean correction of the block, added to the stream HERE
+   *   instead of being carried as a pending vector) and out16 = its 16-bit rounding, every epilogue round leaves the partial row sums of its 64
+   *   columns: nstat_out[(row * (N / 64) + col / 64) * 2 + {0, 1}] = sum x, sum x^2 over those columns (fp32, fixed order: deterministic).
+   *   la_norm_finalize turns the N / 64 partials of a row into (mean, rstd).
+   * CONSUMER (the GEMM behind the LayerNorm; out16 only, act NONE or GELU): nstat_in != NULL - A is the UN-normalised 16-bit stream, W the
+   *   16-bit rounding of W diag(gamma), and the epilogue applies the normalisation to the product:
+   *     out = act( rstd[row] * (acc - mean[row] * ncol[col]) + bias[col] ),   ncol[col] = sum_k W16[col][k],  bias = b + W beta
+   *   which is LayerNorm(x16) W^T + b with the row statistics of the fp32 stream.  nstat_in: fp32 [ceil(M / 256) * 256][2] = (mean, rstd). */
+  float* nstat_out;
+  const float* rvec;
+  int rvec_rpg;
+  const float* nstat_in;
+  const float* ncol;
 } LaGemmEpilogue;
 
 /* 1 when la_gemm takes LaGemmEpilogue.aux16 for this shape (N % 256 == 0, K % 64 == 0, K >= 128, at least one round of 256 x 256 tiles). */
@@ -477,6 +495,22 @@ int la_add_rowvec(float* x, const float* v, long rows, int rows_per_group, int D
  * [hi | lo]: the fp32 token stream leaving the block stack becomes the A operand of the SAM neck's 1 x 1 convolution (image_encoder.py:92-108)
  * as three fp16 MFMA products instead of the exact-fp32 MFMA, without another pass over it. */
 int la_add_rowvec_split(float* x, const float* v, long rows, int rows_per_group, int D, void* split16, void* stream);
+
+/* ---- LayerNorm folded into its neighbour GEMMs (LaGemmEpilogue.nstat_out / nstat_in; image_encoder.py:181-197) --------------------
+ * la_norm_finalize: the row statistics a consumer GEMM's epilogue applies, and the token means the V correction needs.
+ *   part != NULL (fp32 [M][nslots][2], written by producer GEMMs): mr[row] = (mean, rstd) with mean = sum_s part[row][s][0] / E,
+ *     var = sum_s part[row][s][1] / E - mean^2 (biased, like nn.LayerNorm), rstd = 1 / sqrt(var + eps); slots added in index order.
+ *   part == NULL: mr is an input (la_norm_stats wrote it).
+ *   cs_part != NULL (fp32 [M / rows_per_group * ceil(rows_per_group / 128), E]; needs x16, 16-bit [M, E], row stride ld16): per 128-row
+ *     chunk of a group the column sums of rstd[row] * (x16[row] - mean[row]) - the normalised rows BEFORE gamma / beta, which live in the
+ *     folded weights - for la_colsum_fold (the token means of the qkv operand: LamEngine "vmean").  M % rows_per_group == 0.
+ *   mr has ceil(M / 256) * 256 rows; rows beyond M are written as (0, 0). */
+int la_norm_finalize(const float* part, int M, int nslots, int E, float eps, float* mr, const void* x16, int ld16, int rows_per_group,
+                     float* cs_part, int dt, void* stream);
+/* la_norm_stats: the same statistics from the fp32 stream itself, one pass: x16 = 16-bit rounding of x, mr[row] = (mean, rstd)
+ * (two-pass variance on the row in registers).  The entry of a block stack whose first rows do not come from a producer GEMM
+ * (HF ViT: CLS row + patch embedding through a row map). */
+int la_norm_stats(const float* x, int ldx, int M, int E, float eps, void* x16, float* mr, int dt, void* stream);
 
 #ifdef __cplusplus
 }

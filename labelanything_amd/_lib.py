@@ -33,6 +33,7 @@ class LaGemmEpilogue(C.Structure):
         ("vt", C.c_void_p), ("vt_col0", C.c_int), ("vt_T", C.c_int), ("vt_Tpad", C.c_int),
         ("vt_hd", C.c_int), ("vt_heads", C.c_int), ("vt_ws", C.c_int), ("amap", C.c_int), ("a_kmod", C.c_int), ("ksplit", C.c_int),
         ("aux16", C.c_void_p), ("ldaux", C.c_int),
+        ("nstat_out", C.c_void_p), ("rvec", C.c_void_p), ("rvec_rpg", C.c_int), ("nstat_in", C.c_void_p), ("ncol", C.c_void_p),
     ]
 
 
@@ -64,6 +65,7 @@ EXPORTS = [
     "la_gemm_tn", "la_gemm_tn16", "la_gemm_fused_act_ok", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd", "la_bilinear_bwd_set", "la_bilinear_bwd_set_ok", "la_bilinear_rows", "la_bilinear_rows_bwd_set",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
+    "la_norm_finalize", "la_norm_stats",
 ]
 
 
@@ -104,10 +106,13 @@ def _dev(t: torch.Tensor) -> None:
 # ----------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, out32=None, out16=None,
          act=ACT_NONE, map=MAP_NONE, p=(0, 0, 0, 0, 0), vt=None, vt_col0=0, vt_T=0, vt_Tpad=0, vt_hd=64,
-         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0, ksplit=0, aux16=None) -> None:
+         vt_heads=0, vt_ws=0, M=None, lda=None, amap=MAP_NONE, a_kmod=0, ksplit=0, aux16=None, nstat_out=None, rvec=None, rvec_rpg=0,
+         nstat_in=None, ncol=None) -> None:
     """C = epilogue(a @ w.T).  a: [M,K] 16-bit (row stride lda), w: [N,K] 16-bit.  a_kmod > 0: w is [N, j*a_kmod] (split-precision
     planes [W_hi | W_lo]) and the columns of a repeat with period a_kmod.  aux16 (training, shapes with ``gemm_fused_act_ok``): with
-    ACT_GELU the pre-activation is written there beside out16 = GELU; with ACT_GELU_BWD out16 = (a @ w.T) * gelu'(aux16)."""
+    ACT_GELU the pre-activation is written there beside out16 = GELU; with ACT_GELU_BWD out16 = (a @ w.T) * gelu'(aux16).
+    nstat_out / rvec / nstat_in / ncol: the producer and consumer sides of a LayerNorm folded into its neighbour GEMMs (see
+    LaGemmEpilogue in include/la_hip.h; ``norm_finalize`` turns the producer's partial sums into the consumer's (mean, rstd) rows)."""
     _dev(a)
     m = a.shape[0] if M is None else M
     k = w.shape[1]
@@ -131,9 +136,60 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias=None, res=None, res_mod=0, ou
     e.ksplit = ksplit
     e.aux16 = aux16.data_ptr() if aux16 is not None else None
     e.ldaux = aux16.stride(-2) if aux16 is not None else 0
+    if nstat_out is not None or nstat_in is not None or rvec is not None:
+        mpad = -(-m // 256) * 256
+        if nstat_out is not None and (nstat_out.dtype != torch.float32 or nstat_out.numel() < m * (n // 64) * 2):
+            raise RuntimeError(f"gemm: nstat_out must be fp32 with at least M * (N / 64) * 2 = {m * (n // 64) * 2} entries")
+        if nstat_in is not None and (nstat_in.dtype != torch.float32 or nstat_in.numel() < mpad * 2 or ncol is None
+                                     or ncol.dtype != torch.float32 or ncol.numel() < n):
+            raise RuntimeError(f"gemm: nstat_in must be fp32 [ceil(M / 256) * 256, 2] (>= {mpad * 2} entries) and needs ncol fp32 [N]")
+        if rvec is not None and (rvec.dtype != torch.float32 or rvec_rpg <= 0 or rvec.numel() < -(-m // rvec_rpg) * n):
+            raise RuntimeError("gemm: rvec must be fp32 [ceil(M / rvec_rpg), N] with rvec_rpg > 0")
+    e.nstat_out = nstat_out.data_ptr() if nstat_out is not None else None
+    e.rvec = rvec.data_ptr() if rvec is not None else None
+    e.rvec_rpg = rvec_rpg
+    e.nstat_in = nstat_in.data_ptr() if nstat_in is not None else None
+    e.ncol = ncol.data_ptr() if ncol is not None else None
     rc = lib().la_gemm(_ptr(a), C.c_int(a.stride(0) if lda is None else lda), _ptr(w), C.c_int(w.stride(0)),
                        C.c_int(m), C.c_int(n), C.c_int(k), C.byref(e), C.c_int(dt_of(a)), _stream())
     _check(rc, "la_gemm")
+
+
+def norm_finalize(part: Optional[torch.Tensor], m: int, e: int, eps: float, mr: torch.Tensor, x16: Optional[torch.Tensor] = None, rpg: int = 0,
+                  cs_part: Optional[torch.Tensor] = None) -> None:
+    """mr[row] = (mean, rstd) from a producer GEMM's partial row sums ``part`` ([m, e / 64, 2]; None: mr is an input); cs_part (with x16,
+    rpg): column sums of rstd (x16 - mean) per 128-row chunk of every group of rpg rows (``norm_cs_chunks(rpg)`` chunks per group)."""
+    _dev(mr)
+    mpad = -(-m // 256) * 256
+    if mr.dtype != torch.float32 or mr.numel() < mpad * 2 or not mr.is_contiguous():
+        raise RuntimeError(f"norm_finalize: mr must be contiguous fp32 with >= {mpad * 2} entries")
+    if part is not None and (part.dtype != torch.float32 or part.numel() < m * (e // 64) * 2):
+        raise RuntimeError("norm_finalize: part must be fp32 [m, e / 64, 2]")
+    if cs_part is not None:
+        if x16 is None or rpg <= 0 or m % rpg or x16.shape[0] < m or x16.shape[1] != e or x16.stride(1) != 1:
+            raise RuntimeError("norm_finalize: column sums need x16 [m, e] and m % rpg == 0")
+        if cs_part.dtype != torch.float32 or cs_part.numel() < (m // rpg) * norm_cs_chunks(rpg) * e:
+            raise RuntimeError("norm_finalize: cs_part too small")
+    _check(lib().la_norm_finalize(_ptr(part), C.c_int(m), C.c_int(e // 64), C.c_int(e), C.c_float(eps), _ptr(mr), _ptr(x16),
+                                  C.c_int(x16.stride(0) if x16 is not None else 0), C.c_int(rpg), _ptr(cs_part),
+                                  C.c_int(dt_of(x16) if x16 is not None else LA_F16), _stream()), "la_norm_finalize")
+
+
+def norm_cs_chunks(rpg: int) -> int:
+    """Column-sum partials per group that ``norm_finalize(cs_part=...)`` writes (128 rows each)."""
+    return -(-rpg // 128)
+
+
+def norm_stats(x: torch.Tensor, eps: float, x16: torch.Tensor, mr: torch.Tensor) -> None:
+    """x16 = 16-bit rounding of the fp32 rows x, mr[row] = (mean, rstd): the entry of a folded-LayerNorm block stack."""
+    _dev(x)
+    m, e = x.shape
+    mpad = -(-m // 256) * 256
+    if x.dtype != torch.float32 or x.stride(1) != 1 or x16.shape != x.shape or not x16.is_contiguous() or mr.dtype != torch.float32 \
+            or mr.numel() < mpad * 2:
+        raise RuntimeError("norm_stats: x fp32 [m, e], x16 contiguous 16-bit [m, e], mr fp32 with >= ceil(m / 256) * 256 * 2 entries")
+    _check(lib().la_norm_stats(_ptr(x), C.c_int(x.stride(0)), C.c_int(m), C.c_int(e), C.c_float(eps), _ptr(x16), _ptr(mr),
+                               C.c_int(dt_of(x16)), _stream()), "la_norm_stats")
 
 
 def gemm_fused_act_ok(m: int, n: int, k: int) -> bool:

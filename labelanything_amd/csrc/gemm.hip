@@ -2162,6 +2162,37 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
     LA_CHECK_LAUNCH("la_gemm");
     return 0;
   }
+  if (epi->nstat_out || epi->nstat_in || epi->rvec) {
+    // LayerNorm folded into its neighbour GEMMs (see LaGemmEpilogue.nstat_out): the direct epilogue of the persistent four-wave kernel only
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    LA_CHECK_ARG(dt == LA_F16 && (N % 256) == 0 && K >= 128 && (epi->a_kmod == 0 || (epi->a_kmod % 64) == 0) &&
+                     la::fast_ok(A, lda, W, ldw, M, N, K, *epi) && (la::g_gemm_variant & 0xff) == 2,
+                 "la_gemm: nstat_out / nstat_in need fp16 operands, N %% 256 == 0, K %% 64 == 0, K >= 128, 16-byte aligned rows (M=%d N=%d K=%d)", M,
+                 N, K);
+    LA_CHECK_ARG(!epi->vt && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && epi->ksplit == 0 && !epi->aux16 &&
+                     !(epi->nstat_out && epi->nstat_in),
+                 "la_gemm: nstat_out / nstat_in take no row maps / V^T / ksplit / aux16, and not both at once");
+    const int gm = la::tile_group_m(N >= 2560 ? 8 : 2);
+    if (epi->nstat_in) {
+      LA_CHECK_ARG(epi->ncol && epi->out16 && !epi->out32 && !epi->res && !epi->rvec && (epi->act == LA_ACT_NONE || epi->act == LA_ACT_GELU) &&
+                       (epi->ld16 % 8) == 0 && epi->ld16 >= N && al16(epi->out16) && al16(epi->nstat_in) && al16(epi->ncol) && epi->a_kmod == 0,
+                   "la_gemm: nstat_in writes out16 only (act NONE / GELU), needs ncol, one weight plane");
+      if (epi->act == LA_ACT_GELU) la::launch_t256w_fused<la::f16_t, 9>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+      else la::launch_t256w_fused<la::f16_t, 8>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    } else {
+      LA_CHECK_ARG(epi->nstat_out && epi->out32 && epi->out16 && epi->act == LA_ACT_NONE && (epi->ld16 % 8) == 0 && epi->ld16 >= N &&
+                       (epi->ld32 % 4) == 0 && epi->ld32 >= N && al16(epi->out16) && al16(epi->out32) && (!epi->res || (epi->ldr % 4) == 0) &&
+                       (reinterpret_cast<uintptr_t>(epi->nstat_out) & 7) == 0,
+                   "la_gemm: nstat_out goes with out32 + out16 (no activation), 16-byte aligned rows");
+      LA_CHECK_ARG(epi->res_mod == 0 || ((epi->res_mod % 256) == 0 && (M % 256) == 0 && epi->res),
+                   "la_gemm: nstat_out with a periodic residual needs res_mod %% 256 == 0 and M %% 256 == 0 (res_mod=%d M=%d)", epi->res_mod, M);
+      LA_CHECK_ARG(!epi->rvec || (epi->rvec_rpg > 0 && al16(epi->rvec)), "la_gemm: rvec needs rvec_rpg > 0 and a 16-byte aligned vector");
+      if (epi->rvec && (epi->rvec_rpg % 256) != 0) la::launch_t256w_fused<la::f16_t, 10>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+      else la::launch_t256w_fused<la::f16_t, 7>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    }
+    LA_CHECK_LAUNCH("la_gemm");
+    return 0;
+  }
   // up to 512 fp32 rows (decoder tokens of many prompt pairs): an MFMA grid of 128 x 128 tiles is a handful of workgroups and leaves the
   // chip idle (240 x 256 x 2048: 155 us on four tiles) - 32 x 32 wave tiles (gemm_f32_small_kernel) above 128 rows, the VALU kernel below
   const bool few_rows = M <= 32 || (dt == LA_F32 && M <= 512 && (long)((M + 127) / 128) * ((N + 127) / 128) < 64);

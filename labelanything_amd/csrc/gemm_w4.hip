@@ -113,7 +113,7 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() { asm volatile(
 //   read:  lane -> q = lane >> 3, column group cg = lane & 7: columns 8 cg + t, t = 0..7      (8 loads per round, conflict-free)
 // The LDS queue of a wave is in order: round r + 1 is written right behind the read instructions of round r.
 template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], int row0, int col0, const LaGemmEpilogue& e, int lane, int M) {
+__device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], int row0, int col0, const LaGemmEpilogue& e, int lane, int M, int N) {
   const int fr = lane & 31, fh = lane >> 5;
   const int rq = lane >> 3, cg = lane & 7;
   const unsigned sl = lds_addr_of(slab);
@@ -123,7 +123,15 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   unsigned raddr[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) raddr[t] = sl + (unsigned)((rq * 64 + cg * 8 + (t ^ ((cg ^ rq) & 7))) << 4);
+  // EPI 7 / 10: EPI 3 as the PRODUCER side of a folded LayerNorm (LaGemmEpilogue.nstat_out): + out16, + the partial row sums of the wave's
+  // 128 columns, + the per-group vector rvec (7: every row of the tile in one group - the vector joins the bias; 10: a group per row).
+  // EPI 8 / 9: EPI 1 / 2 as the CONSUMER side (nstat_in): the normalisation applied to the product.
+  constexpr bool PROD = EPI == 7 || EPI == 10;
+  constexpr bool RES = EPI == 3 || PROD;
+  constexpr bool NORM = EPI == 8 || EPI == 9;
+  constexpr bool GELU = EPI == 2 || EPI == 5 || EPI == 9;
   float bias[2][8];
+  float ncol[2][8];
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
     if (EPI == 6) continue;
@@ -131,7 +139,32 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     const float4 b1 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     bias[jp][0] = b0.x; bias[jp][1] = b0.y; bias[jp][2] = b0.z; bias[jp][3] = b0.w;
     bias[jp][4] = b1.x; bias[jp][5] = b1.y; bias[jp][6] = b1.z; bias[jp][7] = b1.w;
+    if (EPI == 7 && e.rvec) {
+      const float* rv = e.rvec + (size_t)(row0 / e.rvec_rpg) * N + col0 + jp * 64 + cg * 8;
+      const float4 r0 = *reinterpret_cast<const float4*>(rv), r1 = *reinterpret_cast<const float4*>(rv + 4);
+      bias[jp][0] += r0.x; bias[jp][1] += r0.y; bias[jp][2] += r0.z; bias[jp][3] += r0.w;
+      bias[jp][4] += r1.x; bias[jp][5] += r1.y; bias[jp][6] += r1.z; bias[jp][7] += r1.w;
+    }
+    if (NORM) {
+      const float4 c0 = *reinterpret_cast<const float4*>(e.ncol + col0 + jp * 64 + cg * 8);
+      const float4 c1 = *reinterpret_cast<const float4*>(e.ncol + col0 + jp * 64 + cg * 8 + 4);
+      ncol[jp][0] = c0.x; ncol[jp][1] = c0.y; ncol[jp][2] = c0.z; ncol[jp][3] = c0.w;
+      ncol[jp][4] = c1.x; ncol[jp][5] = c1.y; ncol[jp][6] = c1.z; ncol[jp][7] = c1.w;
+    }
   }
+  // (mean, rstd) of the wave's rows 32 i + 4 rq + s (nstat_in is padded to whole row tiles: no row predicate): a ring of two row
+  // blocks, block i + 2 requested when block i is done
+  float4 mrv[2][2];
+  auto ldmr = [&](int i) {
+    const float4* mp = reinterpret_cast<const float4*>(e.nstat_in + (size_t)(row0 + i * 32 + rq * 4) * 2);
+    mrv[i & 1][0] = mp[0];
+    mrv[i & 1][1] = mp[1];
+  };
+  if (NORM) {
+    ldmr(0);
+    ldmr(1);
+  }
+  const int nslots = N >> 6;      // PROD: one partial per row and 64-column round (nothing carried from round to round: registers)
   T* out16 = reinterpret_cast<T*>(e.out16);
   auto wr = [&](auto ic, auto jpc) {
     constexpr int i = decltype(ic)::value, jp = decltype(jpc)::value;
@@ -163,6 +196,15 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         res[s_][h] = (e.res && row0 + i * 32 + rq * 4 + s_ < M) ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h)
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);      // (rows beyond M: the last, ragged row tile)
   };
+  auto ldrv = [&](int i, int jp, float4 (&rv)[4][2]) {      // EPI 10: the group vector of every row (requested with the residual rows)
+    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        rv[s_][h] = (e.rvec && row + s_ < M) ? *reinterpret_cast<const float4*>(e.rvec + (size_t)((row + s_) / e.rvec_rpg) * N + col + 4 * h)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
   // EPI 5 / 6 (training): aux16 = a second 16-bit matrix of the output's shape.  5: the pre-activation (bias added, before the GELU) is
   // written there beside out16 = GELU - the forward that keeps what gelu' needs.  6: it is READ - out16 = acc * gelu'(aux16), the data
   // gradient of the layer in front of a GELU (dX = dY W of fc2 times gelu'(pre): no fp32 d-activation round trip, no la_gelu_bwd16 pass);
@@ -174,9 +216,9 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     for (int s_ = 0; s_ < 4; ++s_)
       ax[s_] = row + s_ < M ? *reinterpret_cast<const uint4*>(aux16 + (size_t)(row + s_) * e.ldaux + col) : make_uint4(0u, 0u, 0u, 0u);
   };
-  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2], const uint4 (&ax)[4]) {
+  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2], const uint4 (&ax)[4], const float4 (&rv)[4][2]) {
     const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
-    if (EPI == 3) {
+    if (RES) {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         float4 o0, o1;
@@ -184,6 +226,18 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         o0.z = r[2][s_] + bias[jp][2] + res[s_][0].z; o0.w = r[3][s_] + bias[jp][3] + res[s_][0].w;
         o1.x = r[4][s_] + bias[jp][4] + res[s_][1].x; o1.y = r[5][s_] + bias[jp][5] + res[s_][1].y;
         o1.z = r[6][s_] + bias[jp][6] + res[s_][1].z; o1.w = r[7][s_] + bias[jp][7] + res[s_][1].w;
+        if (EPI == 10) {
+          o0.x += rv[s_][0].x; o0.y += rv[s_][0].y; o0.z += rv[s_][0].z; o0.w += rv[s_][0].w;
+          o1.x += rv[s_][1].x; o1.y += rv[s_][1].y; o1.z += rv[s_][1].z; o1.w += rv[s_][1].w;
+        }
+        if (PROD) {      // sum x, sum x^2 over the round's 64 columns of this row: the 8 lanes of a row quad folded by DPP, lane cg == 0 stores
+          float a = ((o0.x + o0.y) + (o0.z + o0.w)) + ((o1.x + o1.y) + (o1.z + o1.w));
+          float b = ((o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w)) + ((o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w));
+          a += dpp_mov<0xB1>(a); b += dpp_mov<0xB1>(b);         // quad_perm [1,0,3,2]
+          a += dpp_mov<0x4E>(a); b += dpp_mov<0x4E>(b);         // quad_perm [2,3,0,1]
+          a += dpp_mov<0x141>(a); b += dpp_mov<0x141>(b);       // row_half_mirror: the other quad of the 8-lane group
+          if (cg == 0 && row + s_ < M) *reinterpret_cast<float2*>(e.nstat_out + ((size_t)(row + s_) * nslots + (col >> 6)) * 2) = make_float2(a, b);
+        }
         if (row + s_ >= M) continue;
         float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
         *reinterpret_cast<float4*>(op) = o0;
@@ -200,10 +254,23 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
       // emits each 13-deep dependent chain on its own with an s_nop behind every packed instruction - a third of the epilogue's
       // instructions - and a wave that is alone on its SIMD has nothing else to put there.
       f32x2 v[8][2];
+      if constexpr (NORM) {      // rstd (acc - mean ncol) + bias on the row pairs (2 sp, 2 sp + 1); both pairs first: the slab registers die here
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const float4 m4 = mrv[i & 1][sp];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]} - f32x2{m4.x, m4.z} * f32x2{ncol[jp][t], ncol[jp][t]};
+            v[t][sp] = v[t][sp] * f32x2{m4.y, m4.w} + f32x2{bias[jp][t], bias[jp][t]};
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
+          if constexpr (NORM) continue;
           v[t][sp] = f32x2{r[t][2 * sp], r[t][2 * sp + 1]};
           if (EPI != 6) v[t][sp] = v[t][sp] + f32x2{bias[jp][t], bias[jp][t]};        // (a data gradient has no bias)
         }
@@ -250,7 +317,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
           LA_W4_STEP(v[t][sp] = v[t][sp] * p[t])
 #undef LA_W4_STEP
         }
-        if (EPI == 2 || EPI == 5) {
+        if (GELU) {
           f32x2 u[8], tt[8], p[8];
 #define LA_W4_STEP(expr)                          \
   _Pragma("unroll") for (int t = 0; t < 8; ++t) { \
@@ -293,10 +360,15 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   // rounds r = 2 i + jp.  ONE fragment set: the wave must not spill here - a reload is a VMEM load behind the round's stores, i.e. an
   // s_waitcnt vmcnt(0) that drains them (and the LDS-DMA pieces of the next tile) once per round
   float4 res0[4][2], res1[4][2];
+  float4 rv0[4][2], rv1[4][2];      // (EPI 10 only; dead otherwise)
   uint4 aux0[4], aux1[4];
-  if (EPI == 3) {
+  if (RES) {
     ldres(0, 0, res0);
     ldres(0, 1, res1);
+  }
+  if constexpr (EPI == 10) {
+    ldrv(0, 0, rv0);
+    ldrv(0, 1, rv1);
   }
   if (EPI == 6) {
     ldaux(0, 0, aux0);
@@ -306,53 +378,61 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   rd(rd0);
   wr(I0{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 0, rd0, res0, aux0);
-  if (EPI == 3) ldres(1, 0, res0);
+  out(0, 0, rd0, res0, aux0, rv0);
+  if (RES) ldres(1, 0, res0);
+  if constexpr (EPI == 10) ldrv(1, 0, rv0);
   if (EPI == 6) ldaux(1, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 1, rd0, res1, aux1);
-  if (EPI == 3) ldres(1, 1, res1);
+  out(0, 1, rd0, res1, aux1, rv1);
+  if (NORM) ldmr(2);
+  if (RES) ldres(1, 1, res1);
+  if constexpr (EPI == 10) ldrv(1, 1, rv1);
   if (EPI == 6) ldaux(1, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 0, rd0, res0, aux0);
-  if (EPI == 3) ldres(2, 0, res0);
+  out(1, 0, rd0, res0, aux0, rv0);
+  if (RES) ldres(2, 0, res0);
+  if constexpr (EPI == 10) ldrv(2, 0, rv0);
   if (EPI == 6) ldaux(2, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 1, rd0, res1, aux1);
-  if (EPI == 3) ldres(2, 1, res1);
+  out(1, 1, rd0, res1, aux1, rv1);
+  if (NORM) ldmr(3);
+  if (RES) ldres(2, 1, res1);
+  if constexpr (EPI == 10) ldrv(2, 1, rv1);
   if (EPI == 6) ldaux(2, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 0, rd0, res0, aux0);
-  if (EPI == 3) ldres(3, 0, res0);
+  out(2, 0, rd0, res0, aux0, rv0);
+  if (RES) ldres(3, 0, res0);
+  if constexpr (EPI == 10) ldrv(3, 0, rv0);
   if (EPI == 6) ldaux(3, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 1, rd0, res1, aux1);
-  if (EPI == 3) ldres(3, 1, res1);
+  out(2, 1, rd0, res1, aux1, rv1);
+  if (RES) ldres(3, 1, res1);
+  if constexpr (EPI == 10) ldrv(3, 1, rv1);
   if (EPI == 6) ldaux(3, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 0, rd0, res0, aux0);
+  out(3, 0, rd0, res0, aux0, rv0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 1, rd0, res1, aux1);
+  out(3, 1, rd0, res1, aux1, rv1);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -363,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
                                                              int K, LaGemmEpilogue e, int gm, int stg) {
   constexpr int BK_ = 64;
   constexpr unsigned REG = 32768;                     // one operand of one k-tile
-  constexpr int SEAM = (EPI == 3 || EPI == 5) ? 47 : 32;      // epilogue stores per wave that the first two waits of a tile may leave outstanding
+  constexpr int SEAM = (EPI == 3 || EPI == 5 || EPI == 7 || EPI == 10) ? 47 : 32;      // epilogue stores per wave that the first two waits of a tile may leave outstanding
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef LA_DEBUG
@@ -419,6 +499,11 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     tile_coords(xcd_remap(tile, ntiles), ntm, ntn, gm, tm_, tn_);
     pm0 = tm_ * 256;
     pn0 = tn_ * 256;
+    // (EPI >= 7: the lane-dependent row / chunk terms below are loop invariants that hipcc hoists and then - these epilogues leave no
+    // register for them - spills, with a reload + s_waitcnt vmcnt(0) per use; an opaque copy of the lane keeps them local to the call)
+    int lane_ = lane;
+    if constexpr (EPI >= 7) asm volatile("" : "+v"(lane_));
+    const int lane = lane_;
     const int lr = lane >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -525,12 +610,26 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[0][i][j]));
+    // EPI >= 7 (folded LayerNorm: more live values in the epilogue than the register file has beside the main loop's): the 16 DMA source
+    // offsets of the next tile wait out the epilogue in LDS - the wave's own A1 region of the buffer the finished k-tile used (4 KiB, 64 B
+    // per lane) is dead from barrier B2 of that k-tile until the next tile's first A1 pieces, which are issued behind the epilogue.
+    // Without it hipcc spills them to scratch and reloads them INSIDE the k-tile loop (a vmcnt(0) in front of every piece).
+    constexpr bool STASH = DIRECT && EPI >= 7;
+    const unsigned stash = dstA + 8192 + (bofs ^ REG) + (unsigned)lane * 64;
+    if constexpr (STASH) {
+      const u32x4 q0 = {soA0[0], soA0[1], soA0[2], soA0[3]}, q1 = {soA1[0], soA1[1], soA1[2], soA1[3]};
+      const u32x4 q2 = {soW[0], soW[1], soW[2], soW[3]}, q3 = {soW[4], soW[5], soW[6], soW[7]};
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\tds_write_b128 %0, %4 offset:48"
+                   :
+                   : "v"(stash), "v"(q0), "v"(q1), "v"(q2), "v"(q3)
+                   : "memory");
+    }
     if constexpr (DIRECT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[1][i][j]));
-      epilogue_w4<T, EPI>(slab, acc, m0 + wr * 128, n0 + wc * 128, e, lane, M);
+      epilogue_w4<T, EPI>(slab, acc, m0 + wr * 128, n0 + wc * 128, e, lane, M, N);
     } else {
       epilogue_wave<T, EPI>(slab, rtab, acc[0], m0 + wr * 128, n0 + wc * 128, n0, M, e, lane, nostore);
 #pragma unroll
@@ -542,6 +641,21 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
     seam = (m0 + 256 <= M) && !vtile;
     stamp(3);                                          // epilogue issued
     if (!more) break;
+    if constexpr (STASH) {
+      u32x4 q0, q1, q2, q3;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                   : "v"(stash)
+                   : "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        soA0[i] = q0[i];
+        soA1[i] = q1[i];
+        soW[i] = q2[i];
+        soW[4 + i] = q3[i];
+      }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -624,6 +738,11 @@ template void launch_t256w_fused<f16_t, 5>(const void*, int, const void*, int, i
 template void launch_t256w_fused<f16_t, 6>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 template void launch_t256w_fused<bf16_t, 5>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 template void launch_t256w_fused<bf16_t, 6>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+// EPI 7 / 10 / 8 / 9: the producer and consumer sides of a folded LayerNorm (LaGemmEpilogue.nstat_out / nstat_in), fp16 operands
+template void launch_t256w_fused<f16_t, 7>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 10>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 8>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 9>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 
 #define LA_W4_INST(T, EPI) \
   template void launch_t256w<T, EPI>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);

@@ -374,3 +374,127 @@ extern "C" int la_add_rowvec_split(float* x, const float* v, long rows, int rows
   LA_CHECK_LAUNCH("la_add_rowvec_split");
   return 0;
 }
+
+// ---- LayerNorm folded into its neighbour GEMMs (LaGemmEpilogue.nstat_out / nstat_in) ---------------------------------------------------
+namespace la {
+constexpr int NF_ROWS = 128;      // rows per workgroup of la_norm_finalize = rows per column-sum partial (as CM_CHUNK)
+
+// workgroup (group g, chunk c): rows [c * 128, +128) of group g.  Phase A: thread t < 128 folds the partial sums of its row (slots in index
+// order) into (mean, rstd).  Phase B (cs_part): column sums of rstd (x16 - mean) over the chunk, laid out like colmean16_kernel's partials.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restrict__ part, int M, int nslots, int E, float eps, float* __restrict__ mr,
+                                                            const T* __restrict__ x16, int ld16, int rpg, float* __restrict__ cs_part) {
+  __shared__ float2 smr[NF_ROWS];
+  __shared__ float red[256 * 8];
+  const int g = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+  const int r0 = c * NF_ROWS, r1 = min(r0 + NF_ROWS, rpg);
+  const size_t base = (size_t)g * rpg;
+  if (tid < NF_ROWS && r0 + tid < r1) {
+    const size_t row = base + r0 + tid;
+    float2 v;
+    if (part != nullptr) {
+      const float2* pp = reinterpret_cast<const float2*>(part) + row * nslots;
+      float s1 = 0.f, s2 = 0.f;
+      for (int j = 0; j < nslots; ++j) {
+        const float2 t = pp[j];
+        s1 += t.x;
+        s2 += t.y;
+      }
+      const float mean = s1 / (float)E;
+      const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
+      v = make_float2(mean, 1.0f / sqrtf(var + eps));
+      reinterpret_cast<float2*>(mr)[row] = v;
+    } else {
+      v = reinterpret_cast<const float2*>(mr)[row];
+    }
+    smr[tid] = v;
+  }
+  // the padding rows of mr (a consumer GEMM's last row tile reads them unpredicated)
+  if (part != nullptr && g == (int)gridDim.x - 1 && c == (int)gridDim.y - 1)
+    for (int r = M + tid; r < ((M + 255) / 256) * 256; r += 256) reinterpret_cast<float2*>(mr)[r] = make_float2(0.f, 0.f);
+  if (cs_part == nullptr) return;
+  __syncthreads();
+  const int cols8 = E / 8, rl = 256 / cols8;
+  const int cv = tid % cols8, rlane = tid / cols8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rlane < rl) {
+    for (int r = r0 + rlane; r < r1; r += rl) {
+      const float2 m = smr[r - r0];
+      const uint4 v = *reinterpret_cast<const uint4*>(x16 + (base + r) * ld16 + cv * 8);
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += ((float)e[k] - m.x) * m.y;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[tid * 8 + k] = acc[k];
+  __syncthreads();
+  if (rlane == 0) {
+    float* dst = cs_part + ((size_t)g * gridDim.y + c) * E + cv * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float s_ = 0.f;
+      for (int j = 0; j < rl; ++j) s_ += red[(j * cols8 + cv) * 8 + k];
+      dst[k] = s_;
+    }
+  }
+}
+
+// one wave per row: x16 = rn16(x), mr = (mean, rstd) with the two-pass variance of la_layernorm (the row lives in registers)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, int ldx, int M, int E, float eps, T* __restrict__ x16,
+                                                         float* __restrict__ mr) {
+  const int lane = threadIdx.x & 63, nv = E >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
+    const float4* xp = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+    float4 v[LN_MAXV];
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      v[i] = c < nv ? xp[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_ += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum_dpp(s_) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        store4v<T>(x16 + (size_t)row * E + c * 4, v[i].x, v[i].y, v[i].z, v[i].w);
+      }
+    }
+    q = wave_sum_dpp(q);
+    if (lane == 0) reinterpret_cast<float2*>(mr)[row] = make_float2(mean, 1.0f / sqrtf(q / (float)E + eps));
+  }
+}
+}  // namespace la
+
+extern "C" int la_norm_finalize(const float* part, int M, int nslots, int E, float eps, float* mr, const void* x16, int ld16, int rows_per_group,
+                                float* cs_part, int dt, void* stream) {
+  LA_CHECK_ARG(mr && M > 0 && E > 0 && (E % 8) == 0 && E <= 2048 && (part == nullptr || nslots > 0), "la_norm_finalize: bad arguments (E %% 8, E <= 2048)");
+  LA_CHECK_ARG(part != nullptr || cs_part != nullptr, "la_norm_finalize: nothing to do (no partial sums and no column sums)");
+  LA_CHECK_ARG(cs_part == nullptr || (x16 && rows_per_group > 0 && (M % rows_per_group) == 0 && (ld16 % 8) == 0 && (dt == LA_F16 || dt == LA_BF16)),
+               "la_norm_finalize: column sums need x16 (16-bit, ld %% 8) and M %% rows_per_group == 0");
+  const int rpg = cs_part ? rows_per_group : M;
+  const dim3 grid(M / rpg, (rpg + la::NF_ROWS - 1) / la::NF_ROWS);
+  LA_CHECK_ARG(grid.y <= 65535, "la_norm_finalize: more than 65535 chunks of 128 rows per group");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dt == LA_BF16) hipLaunchKernelGGL(la::norm_finalize_kernel<la::bf16_t>, grid, dim3(256), 0, st, part, M, nslots, E, eps, mr, (const la::bf16_t*)x16, ld16, rpg, cs_part);
+  else hipLaunchKernelGGL(la::norm_finalize_kernel<la::f16_t>, grid, dim3(256), 0, st, part, M, nslots, E, eps, mr, (const la::f16_t*)x16, ld16, rpg, cs_part);
+  LA_CHECK_LAUNCH("la_norm_finalize");
+  return 0;
+}
+
+extern "C" int la_norm_stats(const float* x, int ldx, int M, int E, float eps, void* x16, float* mr, int dt, void* stream) {
+  LA_CHECK_ARG(x && x16 && mr && M > 0 && E > 0 && (E % 4) == 0 && E <= 4 * 64 * la::LN_MAXV && (ldx % 4) == 0 && (dt == LA_F16 || dt == LA_BF16),
+               "la_norm_stats: bad arguments (E %% 4, E <= 2048, 16-bit output)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = (M + 3) / 4 > 16384 ? 16384 : (M + 3) / 4;
+  if (dt == LA_BF16) hipLaunchKernelGGL(la::norm_stats_kernel<la::bf16_t>, dim3(blocks), dim3(256), 0, st, x, ldx, M, E, eps, (la::bf16_t*)x16, mr);
+  else hipLaunchKernelGGL(la::norm_stats_kernel<la::f16_t>, dim3(blocks), dim3(256), 0, st, x, ldx, M, E, eps, (la::f16_t*)x16, mr);
+  LA_CHECK_LAUNCH("la_norm_stats");
+  return 0;
+}

@@ -158,6 +158,15 @@ class LamEngine:
         # attention without V^T copies / window buffers (la_attn_fwd_rows) wherever its forms cover the block: plain attention, the 64 x 64
         # rel-pos grid, 16-slot windows; False keeps the V^T epilogue + window scatter path (A/B, and what the other geometries still use)
         self.attn_rows = True
+        # LayerNorm folded into its neighbour GEMMs (round 6; LaGemmEpilogue.nstat_out / nstat_in): the residual GEMMs (patch embedding, proj,
+        # lin2) also write the 16-bit copy of the stream and the partial sums of every row, q | k | v and lin1 run on gamma-folded weights
+        # and normalise the product in their epilogue - no LayerNorm pass over the stream (24 launches, 10.4 ms of a 131 ms cfg2 step).
+        # Wide fp16 encoders with one-plane q | k | v and lin1 weights (the measured default of the BASELINE encoders); emulated on the
+        # fixtures before it was built (tools/error_budget.py --fold, profiles/r06_normfold_emulation.log).  False keeps the LayerNorm kernels.
+        spec = cfg.encoder_spec
+        self.norm_fold = (scope == "all" and spec is not None and dtype == torch.float16 and spec.dim >= 512 and spec.dim % 256 == 0
+                          and spec.mlp % 256 == 0 and (3 * spec.heads * 64 * ((spec.head_dim + 63) // 64)) % 256 == 0
+                          and not (self.precise & {"qkv", "v", "lin1"}))
         self._last16 = None
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]
@@ -220,7 +229,27 @@ class LamEngine:
             self.p[key] = t.to(self.dt)
             self.kmod.pop(key, None)
 
-    def _pack_mean(self, pre: str, wv: Tensor, wo: Tensor) -> None:
+    def _pack_fold(self, key: str, wt: Tensor, bias: Tensor, gamma: Tensor, beta: Tensor) -> None:
+        """The consumer side of a folded LayerNorm (LaGemmEpilogue.nstat_in): weight rn16(W diag(gamma)) as ``key + "n"``, its row sums
+        (what multiplies the row mean) as ``.cn`` and b + W beta as ``.bn`` beside the plain packing of the same layer."""
+        wf = (wt * gamma[None, :]).to(self.dt).contiguous()
+        self.p[key + "n"] = wf
+        self.p[key[:-2] + ".cn"] = wf.double().sum(1).float().contiguous()
+        self.p[key[:-2] + ".bn"] = (bias.double() + wt.double() @ beta.double()).float().contiguous()
+
+    def _pack_mean(self, pre: str, wv: Tensor, wo: Tensor, gamma: Optional[Tensor] = None) -> None:
+        if gamma is not None and self.norm_fold and self.mean_planes:
+            # the folded form multiplies the token means of the normalised rows BEFORE gamma: the lost plane is that of Wv diag(gamma)
+            cols = []
+            if "vmean" in self.precise:
+                wvg = wv * gamma[None, :]
+                cols.append((wo.double() @ (wvg - wvg.to(self.dt).float()).double()).float())
+            if "projmean" in self.precise:
+                cols.append((wo - wo.to(self.dt).float()).float())
+            self.p[pre + ".mean.w32n"] = torch.cat(cols, dim=1).contiguous()
+        self._pack_mean_plain(pre, wv, wo)
+
+    def _pack_mean_plain(self, pre: str, wv: Tensor, wo: Tensor) -> None:
         """fp32 operand of the token-mean corrections of one block: rvec += [mean(x) | mean(o)] . [Wo Wv_lo | Wo_lo]^T, where *_lo is what
         the 16-bit plane of a weight lost (c_v = mean(x) Wv_lo^T belongs on every V row of the image, softmax rows sum to one, so it
         leaves attention unchanged and goes through proj as c_v Wo^T: one [E, E] product formed here, once)."""
@@ -414,7 +443,11 @@ class LamEngine:
                              self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(bp + ".proj.w", self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp), "proj")
                 self._pack_mean(bp, self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp)[2 * spec.heads * hdp:],
-                                self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp))
+                                self._pad_heads_in(w[bp + ".attn.proj.weight"], spec.heads, hd, hdp), gamma=w[bp + ".norm1.weight"])
+                if self.norm_fold:
+                    self._pack_fold(bp + ".qkv.w", self._pad_heads_out(w[bp + ".attn.qkv.weight"], 3 * spec.heads, hd, hdp),
+                                    self._pad_heads_out(w[bp + ".attn.qkv.bias"], 3 * spec.heads, hd, hdp), w[bp + ".norm1.weight"], w[bp + ".norm1.bias"])
+                    self._pack_fold(bp + ".lin1.w", w[bp + ".mlp.lin1.weight"], w[bp + ".mlp.lin1.bias"], w[bp + ".norm2.weight"], w[bp + ".norm2.bias"])
                 self._hw(bp + ".lin1.w", w[bp + ".mlp.lin1.weight"], "lin1")
                 self._hw(bp + ".lin2.w", w[bp + ".mlp.lin2.weight"], "lin2")
                 size = g if i in spec.global_idx else spec.window
@@ -439,7 +472,12 @@ class LamEngine:
                              self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp), spec.heads * hdp)
                 self._hw(lp + ".o.w", self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp), "proj")
                 self._pack_mean(lp, self._pad_heads_out(w[lp + ".attention.attention.value.weight"], spec.heads, hd, hdp),
-                                self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp))
+                                self._pad_heads_in(w[lp + ".attention.output.dense.weight"], spec.heads, hd, hdp), gamma=w[lp + ".layernorm_before.weight"])
+                if self.norm_fold:
+                    self._pack_fold(lp + ".qkv.w", self._pad_heads_out(qkv_w, 3 * spec.heads, hd, hdp), self._pad_heads_out(qkv_b, 3 * spec.heads, hd, hdp),
+                                    w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"])
+                    self._pack_fold(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], w[lp + ".intermediate.dense.bias"],
+                                    w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"])
                 self._hw(lp + ".fc1.w", w[lp + ".intermediate.dense.weight"], "lin1")
                 self._hw(lp + ".fc2.w", w[lp + ".output.dense.weight"], "lin2")
         if self.scope == "encoder":
@@ -591,6 +629,8 @@ class LamEngine:
         ea = heads * hdp                # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
         w, p = self.w32, self.p
         images = images.contiguous()
+        if self.norm_fold and self.attn_rows and ws <= 16 and (g == 64 or not spec.global_idx):
+            return self._sam_encoder_fold(images, want_last_block)
         a, akw = self.patches("enc.patchA", images, rows, spec.patch)
         res = self.f32("enc.res", (rows, e))
         L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
@@ -727,6 +767,98 @@ class LamEngine:
             return (out, None, spec.out_chans), res
         return out, None, spec.out_chans
 
+    # ---- LayerNorm folded into its neighbour GEMMs (norm_fold) -------------------------------------------------------------------------
+    def _fold_bufs(self, tag: str, rows: int, e: int):
+        """(partial row sums of the producer GEMMs, (mean, rstd) rows of the consumer GEMMs - padded to whole 256-row tiles)."""
+        return self.f32(tag + ".npart", (rows, e // 64, 2)), self.f32(tag + ".nmr", (_ceil(rows, 256), 2), zero=True)
+
+    def _fold_mean(self, pre: str, xpart, opart, bn: int, rpg: int, o_chunks: int, e: int, ea: int, ao) -> Optional[Tensor]:
+        """The block's token-mean correction as a FRESH per-image vector (the proj GEMM's epilogue adds it to the stream: nothing stays
+        pending): dR[img] = [mean(z) | mean(o)] . [Wo (Wv gamma)_lo | Wo_lo]^T, z = the normalised rows before gamma (la_norm_finalize)."""
+        if not self.mean_planes:
+            return None
+        wm = self.p[pre + ".mean.w32n"]
+        bar = self.f32("mean.bar", (bn, wm.shape[1]))
+        kx = self.mean_kx[pre]
+        if xpart is not None:
+            L.colsum_fold(xpart, bn, L.norm_cs_chunks(rpg), e, 1.0 / rpg, bar[:, :kx])
+        if opart is not None and o_chunks > 0:
+            L.colsum_fold(opart, bn, o_chunks, ea, 1.0 / rpg, bar[:, kx:])
+        elif opart is not None:
+            obar = self.f32("mean.obar", (bn, ea))
+            L.colmean16(ao, bn, rpg, obar, opart, 0, 0, 0)
+            bar[:, kx:].copy_(obar)
+        dr = self.f32("mean.dr", (bn, e))
+        L.gemm(bar, wm, out32=dr)
+        return dr
+
+    def _sam_encoder_fold(self, images: Tensor, want_last_block: bool = False):
+        """sam_encoder without LayerNorm passes (image_encoder.py:110-131,179-197): every residual GEMM is the PRODUCER of the next
+        LayerNorm's input (fp32 stream + 16-bit copy + partial row sums), q | k | v and lin1 are its CONSUMERS (gamma-folded weights,
+        normalisation in the epilogue); the token-mean correction of a block joins the stream in the proj epilogue."""
+        spec: EncoderSpec = self.cfg.encoder_spec
+        pre = "image_encoder"
+        bn, _, s, _ = images.shape
+        e, heads, g, ws = spec.dim, spec.heads, s // spec.patch, spec.window
+        hw = g * g
+        rows = bn * hw
+        scale = spec.head_dim ** -0.5
+        hdp = self.head_pad
+        ea = heads * hdp
+        w, p = self.w32, self.p
+        a, akw = self.patches("enc.patchA", images, rows, spec.patch)
+        res = self.f32("enc.res", (rows, e))
+        x16 = self.buf("enc.x16", (rows, e))
+        part, mr = self._fold_bufs("enc", rows, e)
+        have_mr = False
+        if hw % 256 == 0:
+            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, out16=x16,
+                   nstat_out=part, **akw)
+        else:       # (a position table that is not whole row tiles: the stream's statistics from a pass of their own, once)
+            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
+            L.norm_stats(res, 1e-6, x16, mr)
+            have_mr = True
+        nwy = (g + ws - 1) // ws
+        vm, pm = "vmean" in self.precise, "projmean" in self.precise
+        for i in range(spec.depth):
+            bp = f"{pre}.blocks.{i}"
+            is_global = i in spec.global_idx
+            o_chunks = _ceil(hw, 128) // 128 if is_global else nwy * nwy * (_ceil(ws * ws, 128) // 128)
+            xpart = self.f32("mean.xpart", (bn * L.ln_cs_chunks(hw) * e,)) if vm else None
+            opart = self.f32("mean.opart", (bn * max(o_chunks, _ceil(hw, 128) // 128) * ea,)) if pm else None
+            if vm or not have_mr:
+                L.norm_finalize(None if have_mr else part, rows, e, 1e-6, mr, x16=x16 if vm else None, rpg=hw, cs_part=xpart)
+            have_mr = False
+            qkv = self.buf("enc.qkv.r", (rows, 3 * ea))
+            L.gemm(x16, p[bp + ".qkv.wn"], bias=p[bp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[bp + ".qkv.cn"])
+            ao = self.buf("enc.ao.r", (rows, ea))
+            fused_o = opart is not None and is_global
+            if is_global:
+                L.attn_fwd_rows(qkv, ao, bn, heads, hw, _ceil(hw, 64), g, ea, scale, L.ATTN_RELPOS, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
+                                cspart=opart if fused_o else None)
+            else:
+                L.attn_fwd_rows(qkv, ao, bn * nwy * nwy, heads, ws * ws, _ceil(16 * ws, 64), ws, ea, scale, L.ATTN_RELPOS_WIN16,
+                                tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"], img_hw=(g, g), padrow=p[bp + ".qkv.pad16"])
+            dr = self._fold_mean(bp, xpart, opart, bn, hw, o_chunks if fused_o else 0, e, ea, ao)
+            L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res, out16=x16, nstat_out=part, rvec=dr,
+                   rvec_rpg=hw if dr is not None else 0, a_kmod=self.kmod.get(bp + ".proj.w", 0))
+            L.norm_finalize(part, rows, e, 1e-6, mr)
+            hbuf = self.buf("enc.mlp", (rows, spec.mlp))
+            L.gemm(x16, p[bp + ".lin1.wn"], bias=p[bp + ".lin1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[bp + ".lin1.cn"])
+            L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=x16, nstat_out=part,
+                   a_kmod=self.kmod.get(bp + ".lin2.w", 0))
+        last16 = x16               # (the last lin2 launch left the 16-bit rounding of the finished stream)
+        if not self.cfg.use_vit_sam_neck:
+            return (res, last16, e) if not want_last_block else ((res, last16, e), res)
+        xs = None
+        if (pre + ".neck.0.ws") in p:
+            xs = self.buf("enc.res_split", (rows, 2 * e), torch.float16)
+            L.add_rowvec_split(res, None, hw, xs)
+        out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck", x32=res, xs=xs)
+        if want_last_block:
+            return (out, None, spec.out_chans), res
+        return out, None, spec.out_chans
+
     def _sam_mlp(self, bp: str, i: int, res: Tensor, x16: Tensor, rows: int, spec, w, rvec, rkw) -> None:
         """norm2 + lin1 (GELU) + lin2 (residual) of one SAM block; the last block may leave a 16-bit copy of the stream in ``self._last16``."""
         e = spec.dim
@@ -785,6 +917,8 @@ class LamEngine:
         qkv = self.buf("hf.qkv", (rows, 3 * ea))
         fp8 = self.attn_fp8 and hdp == 64          # (the fp8 QK^T kernel keeps its V^T operand)
         rows_path = self.attn_rows and not fp8     # no V^T copy: la_attn_fwd_rows
+        if self.norm_fold and rows_path:
+            return self._hf_fold_blocks(res, bn, t, hw, e, heads, hdp, ea, spec, qkv)
         vt = None if rows_path else self.buf("hf.vt", (bn * heads, hdp, tpad), zero=True)
         ao = self.buf("hf.ao", (rows, ea))
         hbuf = self.buf("hf.mlp", (rows, spec.mlp))
@@ -826,6 +960,48 @@ class LamEngine:
         fin = self.f32("hf.final", (rows, e))
         fin16 = self.buf("hf.final16", (rows, e))
         self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16, **rkw)
+        out32 = self.f32("hf.out32", (bn * hw, e))
+        out16 = self.buf("hf.out16", (bn * hw, e))
+        out32.view(bn, hw, e).copy_(fin.view(bn, t, e)[:, 1:])          # drop CLS (plain strided copy)
+        out16.view(bn, hw, e).copy_(fin16.view(bn, t, e)[:, 1:])
+        return out32, out16, e
+
+    def _hf_fold_blocks(self, res: Tensor, bn: int, t: int, hw: int, e: int, heads: int, hdp: int, ea: int, spec, qkv: Tensor):
+        """The HF block stack without LayerNorm passes (transformers ViTLayer: layernorm_before / layernorm_after folded into the q | k | v
+        and fc1 GEMMs; eps 1e-12): see _sam_encoder_fold.  The stream enters through a row map (CLS gap), so the first statistics come
+        from one pass over it (la_norm_stats); the final ``layernorm`` is the LayerNorm kernel."""
+        pre = "image_encoder"
+        rows = bn * t
+        w, p = self.w32, self.p
+        x16 = self.buf("hf.x16", (rows, e))
+        part, mr = self._fold_bufs("hf", rows, e)
+        L.norm_stats(res, 1e-12, x16, mr)
+        have_mr = True
+        ao = self.buf("hf.ao", (rows, ea))
+        hbuf = self.buf("hf.mlp", (rows, spec.mlp))
+        scale = spec.head_dim ** -0.5
+        tpad = _ceil(t, 64)
+        vm, pm = "vmean" in self.precise, "projmean" in self.precise
+        o_chunks = _ceil(t, 128) // 128
+        xpart = self.f32("mean.xpart", (bn * L.ln_cs_chunks(t) * e,)) if vm else None
+        opart = self.f32("mean.opart", (bn * o_chunks * ea,)) if pm else None
+        for i in range(spec.depth):
+            lp = f"{pre}.encoder.layer.{i}"
+            if vm or not have_mr:
+                L.norm_finalize(None if have_mr else part, rows, e, 1e-12, mr, x16=x16 if vm else None, rpg=t, cs_part=xpart)
+            have_mr = False
+            L.gemm(x16, p[lp + ".qkv.wn"], bias=p[lp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[lp + ".qkv.cn"])
+            L.attn_fwd_rows(qkv, ao, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN, cspart=opart)
+            dr = self._fold_mean(lp, xpart, opart, bn, t, o_chunks, e, ea, ao)
+            L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res, out16=x16, nstat_out=part, rvec=dr,
+                   rvec_rpg=t if dr is not None else 0, a_kmod=self.kmod.get(lp + ".o.w", 0))
+            L.norm_finalize(part, rows, e, 1e-12, mr)
+            L.gemm(x16, p[lp + ".fc1.wn"], bias=p[lp + ".fc1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[lp + ".fc1.cn"])
+            L.gemm(hbuf, p[lp + ".fc2.w"], bias=w[lp + ".output.dense.bias"], res=res, out32=res, out16=x16, nstat_out=part,
+                   a_kmod=self.kmod.get(lp + ".fc2.w", 0))
+        fin = self.f32("hf.final", (rows, e))
+        fin16 = self.buf("hf.final16", (rows, e))
+        self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16)
         out32 = self.f32("hf.out32", (bn * hw, e))
         out16 = self.buf("hf.out16", (bn * hw, e))
         out32.view(bn, hw, e).copy_(fin.view(bn, t, e)[:, 1:])          # drop CLS (plain strided copy)

@@ -37,7 +37,8 @@ POINTS = ["patch.A", "patch.W", "qkv.A", "qk.W", "v.W", "attn.QK", "attn.V", "at
 
 
 class Policy:
-    def __init__(self, dtype, modes):
+    def __init__(self, dtype, modes, fold=False):
+        self.fold = fold
         self.dt = dtype
         self.modes = modes          # point -> "r" | "x" | "s"   (optionally "point@block" overrides)
 
@@ -81,16 +82,55 @@ def lin(pol, point, w, name, x, block=None):
     return F.linear(pol(point + ".A", x, block), wt, w.get(name + ".bias"))
 
 
-def sam_attention(pol, w, pre, x, heads, blk):
-    n, gh, gw, e = x.shape
+def fold_linear(pol, apoint, wpoint, wt, bias, gamma, beta, eps, x, blk):
+    """LayerNorm folded into the consumer GEMM (--fold): the MFMA operand is the 16-bit rounding of the UN-normalised stream x, the
+    weight is rn16(W diag(gamma)); the epilogue applies rstd (acc - mu c) + b' with c = row sums of the rounded plane, b' = b + W beta,
+    mu / rstd the fp32 row statistics.  Weight mode "m": + mean_tokens(rstd (x16 - mu)) . W'_lo^T per image."""
+    mu = x.mean(-1, keepdim=True)
+    rstd = (x.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+    xa = pol(apoint, x, blk)
+    wf = wt * gamma
+    m = pol.modes.get(wpoint, "x")
+    hi = wf if m == "x" else pol.r16(wf)
+    if m == "s":
+        hi = hi + pol.r16(wf - hi)
+    y = rstd * (F.linear(xa, hi) - mu * hi.sum(1)) + (bias + wt @ beta)
+    if m == "m":
+        lo = pol.r16(wf - hi)
+        z = rstd * (xa - mu)
+        y = y + F.linear(z.mean(dim=tuple(range(1, z.dim() - 1)), keepdim=True), lo)
+    return y
+
+
+def sam_qkv_folded(pol, w, bp, x, blk, win):
+    """q | k | v of one SAM block from the un-normalised stream (image order), window-partitioned with bias rows for padded tokens."""
+    pre = bp + ".attn"
+    e = x.shape[-1]
+    wq, bq = w[pre + ".qkv.weight"], w[pre + ".qkv.bias"]
+    g, b = w[bp + ".norm1.weight"], w[bp + ".norm1.bias"]
+    qk = fold_linear(pol, "qkv.A", "qk.W", wq[:2 * e], bq[:2 * e], g, b, 1e-6, x, blk)
+    v = fold_linear(pol, "qkv.A", "v.W", wq[2 * e:], bq[2 * e:], g, b, 1e-6, x, blk)
+    qkv = torch.cat([qk, v], dim=-1)
+    if win > 0:
+        qkv, padded = O.window_split(qkv - bq, win)
+        return qkv + bq, padded
+    return qkv, None
+
+
+def sam_attention(pol, w, pre, x, heads, blk, qkv=None):
+    n, gh, gw = x.shape[:3]
+    e = x.shape[-1] if qkv is None else x.shape[-1] // 3
     hd = e // heads
     t = gh * gw
     wq = w[pre + ".qkv.weight"]
-    xa = pol("qkv.A", x.reshape(n, t, e), blk)
-    if pol.modes.get("v.W") == "m":
+    if qkv is not None:
+        qkv = x.reshape(n, t, 3 * e)
+    elif pol.modes.get("v.W") == "m":
+        xa = pol("qkv.A", x.reshape(n, t, e), blk)
         qkv = torch.cat([F.linear(xa, pol("qk.W", wq[:2 * e], blk), w[pre + ".qkv.bias"][:2 * e]),
                          mean_corrected(pol, xa, wq[2 * e:], w[pre + ".qkv.bias"][2 * e:])], dim=-1)
     else:
+        xa = pol("qkv.A", x.reshape(n, t, e), blk)
         wq = torch.cat([pol("qk.W", wq[:2 * e], blk), pol("v.W", wq[2 * e:], blk)])
         qkv = F.linear(xa, wq, w[pre + ".qkv.bias"])
     qkv = qkv.view(n, t, 3, heads, hd).permute(2, 0, 3, 1, 4)
@@ -131,6 +171,20 @@ def sam_encoder(pol, w, geo, images, pre="image_encoder"):
     for i in range(geo.enc_depth):
         bp = f"{pre}.blocks.{i}"
         win = 0 if i in geo.global_idx else geo.window
+        if pol.fold:
+            h, wd, nimg = x.shape[1], x.shape[2], x.shape[0]
+            qkv, padded = sam_qkv_folded(pol, w, bp, x, i, win)
+            if win > 0:
+                MEAN_GROUP.update(n=qkv.shape[0] // nimg, tokens=h * wd)
+            y = sam_attention(pol, w, bp + ".attn", qkv, geo.enc_heads, i, qkv=True)
+            MEAN_GROUP.update(n=0)
+            if win > 0:
+                y = O.window_merge(y, win, padded, (h, wd))
+            x = x + y
+            z = O.gelu(fold_linear(pol, "lin1.A", "lin1.W", w[bp + ".mlp.lin1.weight"], w[bp + ".mlp.lin1.bias"], w[bp + ".norm2.weight"],
+                                   w[bp + ".norm2.bias"], 1e-6, x, i))
+            x = x + lin(pol, "lin2", w, bp + ".mlp.lin2", z, i)
+            continue
         y = O.layer_norm(w, bp + ".norm1", x, 1e-6)
         if win > 0:
             h, wd = y.shape[1], y.shape[2]
@@ -174,7 +228,12 @@ def hf_encoder(pol, w, geo, images, pre="image_encoder"):
         lp = f"{pre}.encoder.layer.{i}"
         y = O.layer_norm(w, lp + ".layernorm_before", x, 1e-12)
         ya = pol("qkv.A", y, i)
-        q, k, v = ((mean_corrected(pol, ya, w[f"{lp}.attention.attention.{n}.weight"], w[f"{lp}.attention.attention.{n}.bias"])
+        if pol.fold:
+            q, k, v = (fold_linear(pol, "qkv.A", "v.W" if n == "value" else "qk.W", w[f"{lp}.attention.attention.{n}.weight"],
+                                   w[f"{lp}.attention.attention.{n}.bias"], w[lp + ".layernorm_before.weight"], w[lp + ".layernorm_before.bias"],
+                                   1e-12, x, i).view(bn, t, heads, hd).transpose(1, 2) for n in ("query", "key", "value"))
+        else:
+          q, k, v = ((mean_corrected(pol, ya, w[f"{lp}.attention.attention.{n}.weight"], w[f"{lp}.attention.attention.{n}.bias"])
                     if (n == "value" and pol.modes.get("v.W") == "m") else
                     F.linear(ya, pol("v.W" if n == "value" else "qk.W", w[f"{lp}.attention.attention.{n}.weight"], i),
                              w[f"{lp}.attention.attention.{n}.bias"])).view(bn, t, heads, hd).transpose(1, 2)
@@ -186,8 +245,12 @@ def hf_encoder(pol, w, geo, images, pre="image_encoder"):
         o = (pol("attn.P", pe, i) @ v) / pe.sum(dim=-1, keepdim=True)
         o = o.transpose(1, 2).reshape(bn, t, e)
         x = x + lin(pol, "proj", w, lp + ".attention.output.dense", o, i)
-        y = O.layer_norm(w, lp + ".layernorm_after", x, 1e-12)
-        y = O.gelu(lin(pol, "lin1", w, lp + ".intermediate.dense", y, i))
+        if pol.fold:
+            y = O.gelu(fold_linear(pol, "lin1.A", "lin1.W", w[lp + ".intermediate.dense.weight"], w[lp + ".intermediate.dense.bias"],
+                                   w[lp + ".layernorm_after.weight"], w[lp + ".layernorm_after.bias"], 1e-12, x, i))
+        else:
+            y = O.layer_norm(w, lp + ".layernorm_after", x, 1e-12)
+            y = O.gelu(lin(pol, "lin1", w, lp + ".intermediate.dense", y, i))
         x = x + lin(pol, "lin2", w, lp + ".output.dense", y, i)
     x = O.layer_norm(w, pre + ".layernorm", x, 1e-12)
     return x[:, 1:, :].reshape(bn, g, g, e).permute(0, 3, 1, 2).contiguous()
@@ -230,6 +293,7 @@ def main():
     ap.add_argument("--split", default="", help="comma list of points kept as hi/lo pairs (others rounded)")
     ap.add_argument("--exact", default="", help="comma list of points kept exact (others rounded)")
     ap.add_argument("--mean", default="", help="comma list of WEIGHT points (v.W, proj.W, lin1.W, lin2.W) rounded + token-mean correction")
+    ap.add_argument("--fold", action="store_true", help="norm1 / norm2 folded into the qkv / lin1 GEMMs (operand = the un-normalised stream)")
     ap.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     if a.threads:
@@ -247,7 +311,7 @@ def main():
 
     def report(tag, modes):
         t0 = time.time()
-        emb, low, cls = run(Policy(dt, modes), w, geo, batch, rows)
+        emb, low, cls = run(Policy(dt, modes, a.fold), w, geo, batch, rows)
         print(f"{tag:34s} emb {rel(emb, ref[0]):.3e} (rms {rms(emb, ref[0]):.3e})  cls {rel(cls, ref[2]):.3e}  "
               f"low {rel(low, ref[1]):.3e} (rms {rms(low, ref[1]):.3e})   [{time.time() - t0:.1f}s]", flush=True)
 
