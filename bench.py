@@ -103,7 +103,8 @@ class KernelTimer:
                  "conv3x3_f32", "nhwc_to_nchw", "dense_pe", "gemm_tn", "layernorm_bwd", "act_fwd", "act_bwd", "attn_small_lse",
                  "attn_small_bwd", "bilinear_bwd", "bilinear_bwd_set", "bilinear_rows", "bilinear_rows_bwd_set", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
                  "attn_fwd_lse", "attn_bwd", "head_transpose", "cast", "gelu_bwd16", "axpy", "transpose16", "colmean16", "layernorm_g", "add_rowvec", "add_rowvec_split", "qk_fp8", "attn_fwd_fp8", "attn_fwd_cs", "colsum_fold", "gelu_fwd16",
-                 "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows", "gemm_tn16"]
+                 "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows", "gemm_tn16",
+                 "norm_finalize", "norm_stats"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn
@@ -309,6 +310,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the torch-eager-on-GPU comparator that fills vs_baseline (cfg2, 1 GPU)")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-norm-fold", action="store_true", help="A/B: keep the LayerNorm kernels of the encoder blocks instead of folding them into "
+                    "the neighbour GEMMs (LamEngine.norm_fold, round 6)")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
     a = ap.parse_args()
     if a.episodes is None:
@@ -350,6 +353,7 @@ def main():
     lam = lam.to(dev)
     train = bool(WORKLOADS[a.workload].get("train"))
     lam.attn_fp8 = bool(a.attn_fp8)
+    lam.norm_fold = not a.no_norm_fold
     lam.use_graphs = not a.no_graphs and not train
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
     if train:
@@ -443,7 +447,8 @@ def main():
                            "(fp16: 7e-4) and run 15 % slower with the full weight-plane set they need (profiles/r03_bench_cfg2_bf16.json); "
                            "--dtype bf16 runs that configuration") if a.dtype == "f16" else
                           "bf16 operands: outside the 1e-3 logit tolerance (4.4e-3 measured on cfg2); the parity configuration is --dtype f16",
-            "attn_fp8": bool(a.attn_fp8), "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
+            "attn_fp8": bool(a.attn_fp8), "norm_fold": bool(getattr((lam_fwd if train else lam)._engine, "norm_fold", False)) if getattr((lam_fwd if train else lam), "_engine", None) is not None else None,
+            "encoder_split_precision": list((lam_fwd if train else lam).precise), "decoder_gemm_dtype": {"f32": "f32", "f16x2": "f16x2 (fp16 plane pairs, 3 products)", "same": a.dtype}[a.decoder], "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload]["desc"] + ", random-init weights, full-resolution logits",
                        "episodes_per_step_per_gpu": a.episodes, "global_episodes_per_step": a.episodes * world,
                        "images_per_sec": round(eps * (1 + WORKLOADS[a.workload]["episode"]["n_ways"] * WORKLOADS[a.workload]["episode"]["k_shots"]), 2),

@@ -2186,7 +2186,8 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                    "la_gemm: nstat_out goes with out32 + out16 (no activation), 16-byte aligned rows");
       LA_CHECK_ARG(epi->res_mod == 0 || ((epi->res_mod % 256) == 0 && (M % 256) == 0 && epi->res),
                    "la_gemm: nstat_out with a periodic residual needs res_mod %% 256 == 0 and M %% 256 == 0 (res_mod=%d M=%d)", epi->res_mod, M);
-      LA_CHECK_ARG(!epi->rvec || (epi->rvec_rpg > 0 && al16(epi->rvec)), "la_gemm: rvec needs rvec_rpg > 0 and a 16-byte aligned vector");
+      LA_CHECK_ARG(!epi->rvec || (epi->rvec_rpg > 0 && al16(epi->rvec) && ((epi->rvec_rpg % 256) == 0 || epi->rvec_rpg >= 128)),
+                   "la_gemm: rvec needs a 16-byte aligned vector and groups of whole 256-row tiles or of at least 128 rows (rvec_rpg=%d)", epi->rvec_rpg);
       if (epi->rvec && (epi->rvec_rpg % 256) != 0) la::launch_t256w_fused<la::f16_t, 10>(A, lda, W, ldw, M, N, K, *epi, gm, st);
       else la::launch_t256w_fused<la::f16_t, 7>(A, lda, W, ldw, M, N, K, *epi, gm, st);
     }

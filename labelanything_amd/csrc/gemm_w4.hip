@@ -123,14 +123,16 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   unsigned raddr[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) raddr[t] = sl + (unsigned)((rq * 64 + cg * 8 + (t ^ ((cg ^ rq) & 7))) << 4);
-  // EPI 7 / 10: EPI 3 as the PRODUCER side of a folded LayerNorm (LaGemmEpilogue.nstat_out): + out16, + the partial row sums of the wave's
-  // 128 columns, + the per-group vector rvec (7: every row of the tile in one group - the vector joins the bias; 10: a group per row).
+  // EPI 7 / 10: EPI 3 as the PRODUCER side of a folded LayerNorm (LaGemmEpilogue.nstat_out): + out16, + the partial row sums of every
+  // round, + the per-group vector rvec (7: every row of the tile in one group - the vector joins the bias; 10: groups of >= 128 rows that
+  // do not end on tile edges - the wave's 128 rows lie in at most two groups: two bias sets, selected per row).
   // EPI 8 / 9: EPI 1 / 2 as the CONSUMER side (nstat_in): the normalisation applied to the product.
   constexpr bool PROD = EPI == 7 || EPI == 10;
   constexpr bool RES = EPI == 3 || PROD;
   constexpr bool NORM = EPI == 8 || EPI == 9;
   constexpr bool GELU = EPI == 2 || EPI == 5 || EPI == 9;
   float bias[2][8];
+  float biasB[2][8];      // (EPI 10 only)
   float ncol[2][8];
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
@@ -139,7 +141,16 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     const float4 b1 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     bias[jp][0] = b0.x; bias[jp][1] = b0.y; bias[jp][2] = b0.z; bias[jp][3] = b0.w;
     bias[jp][4] = b1.x; bias[jp][5] = b1.y; bias[jp][6] = b1.z; bias[jp][7] = b1.w;
-    if (EPI == 7 && e.rvec) {
+    if (EPI == 10) {      // a second copy for the rows of the NEXT group (selected per row: a group's rows never see another group's vector)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) biasB[jp][t] = bias[jp][t];
+      const int gB = min(row0 / e.rvec_rpg + 1, (M - 1) / e.rvec_rpg);
+      const float* rv = e.rvec + (size_t)gB * N + col0 + jp * 64 + cg * 8;
+      const float4 r0 = *reinterpret_cast<const float4*>(rv), r1 = *reinterpret_cast<const float4*>(rv + 4);
+      biasB[jp][0] += r0.x; biasB[jp][1] += r0.y; biasB[jp][2] += r0.z; biasB[jp][3] += r0.w;
+      biasB[jp][4] += r1.x; biasB[jp][5] += r1.y; biasB[jp][6] += r1.z; biasB[jp][7] += r1.w;
+    }
+    if (PROD && e.rvec) {
       const float* rv = e.rvec + (size_t)(row0 / e.rvec_rpg) * N + col0 + jp * 64 + cg * 8;
       const float4 r0 = *reinterpret_cast<const float4*>(rv), r1 = *reinterpret_cast<const float4*>(rv + 4);
       bias[jp][0] += r0.x; bias[jp][1] += r0.y; bias[jp][2] += r0.z; bias[jp][3] += r0.w;
@@ -156,6 +167,10 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   // blocks, block i + 2 requested when block i is done
   float4 mrv[2][2];
   auto ldmr = [&](int i) {
+#ifdef LA_W4_NO_MRLOAD      // (measurement builds only, results wrong: what the statistics loads cost the epilogue - tools/normfold_ab.py)
+    mrv[i & 1][0] = mrv[i & 1][1] = make_float4(0.f, 1.f, 0.f, 1.f);
+    return;
+#endif
     const float4* mp = reinterpret_cast<const float4*>(e.nstat_in + (size_t)(row0 + i * 32 + rq * 4) * 2);
     mrv[i & 1][0] = mp[0];
     mrv[i & 1][1] = mp[1];
@@ -164,6 +179,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     ldmr(0);
     ldmr(1);
   }
+  const int rowB = EPI == 10 ? (row0 / e.rvec_rpg + 1) * e.rvec_rpg : 0;      // first row of the next group
   const int nslots = N >> 6;      // PROD: one partial per row and 64-column round (nothing carried from round to round: registers)
   T* out16 = reinterpret_cast<T*>(e.out16);
   auto wr = [&](auto ic, auto jpc) {
@@ -196,15 +212,6 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         res[s_][h] = (e.res && row0 + i * 32 + rq * 4 + s_ < M) ? *reinterpret_cast<const float4*>(e.res + (size_t)(row + s_) * e.ldr + col + 4 * h)
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);      // (rows beyond M: the last, ragged row tile)
   };
-  auto ldrv = [&](int i, int jp, float4 (&rv)[4][2]) {      // EPI 10: the group vector of every row (requested with the residual rows)
-    const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-        rv[s_][h] = (e.rvec && row + s_ < M) ? *reinterpret_cast<const float4*>(e.rvec + (size_t)((row + s_) / e.rvec_rpg) * N + col + 4 * h)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-  };
   // EPI 5 / 6 (training): aux16 = a second 16-bit matrix of the output's shape.  5: the pre-activation (bias added, before the GELU) is
   // written there beside out16 = GELU - the forward that keeps what gelu' needs.  6: it is READ - out16 = acc * gelu'(aux16), the data
   // gradient of the layer in front of a GELU (dX = dY W of fc2 times gelu'(pre): no fp32 d-activation round trip, no la_gelu_bwd16 pass);
@@ -216,19 +223,23 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     for (int s_ = 0; s_ < 4; ++s_)
       ax[s_] = row + s_ < M ? *reinterpret_cast<const uint4*>(aux16 + (size_t)(row + s_) * e.ldaux + col) : make_uint4(0u, 0u, 0u, 0u);
   };
-  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2], const uint4 (&ax)[4], const float4 (&rv)[4][2]) {
+  auto out = [&](int i, int jp, const f32x4 (&r)[8], const float4 (&res)[4][2], const uint4 (&ax)[4]) {
     const int row = row0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
     if (RES) {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         float4 o0, o1;
-        o0.x = r[0][s_] + bias[jp][0] + res[s_][0].x; o0.y = r[1][s_] + bias[jp][1] + res[s_][0].y;
-        o0.z = r[2][s_] + bias[jp][2] + res[s_][0].z; o0.w = r[3][s_] + bias[jp][3] + res[s_][0].w;
-        o1.x = r[4][s_] + bias[jp][4] + res[s_][1].x; o1.y = r[5][s_] + bias[jp][5] + res[s_][1].y;
-        o1.z = r[6][s_] + bias[jp][6] + res[s_][1].z; o1.w = r[7][s_] + bias[jp][7] + res[s_][1].w;
         if (EPI == 10) {
-          o0.x += rv[s_][0].x; o0.y += rv[s_][0].y; o0.z += rv[s_][0].z; o0.w += rv[s_][0].w;
-          o1.x += rv[s_][1].x; o1.y += rv[s_][1].y; o1.z += rv[s_][1].z; o1.w += rv[s_][1].w;
+          const bool nb = row + s_ >= rowB;
+          o0.x = r[0][s_] + (nb ? biasB[jp][0] : bias[jp][0]) + res[s_][0].x; o0.y = r[1][s_] + (nb ? biasB[jp][1] : bias[jp][1]) + res[s_][0].y;
+          o0.z = r[2][s_] + (nb ? biasB[jp][2] : bias[jp][2]) + res[s_][0].z; o0.w = r[3][s_] + (nb ? biasB[jp][3] : bias[jp][3]) + res[s_][0].w;
+          o1.x = r[4][s_] + (nb ? biasB[jp][4] : bias[jp][4]) + res[s_][1].x; o1.y = r[5][s_] + (nb ? biasB[jp][5] : bias[jp][5]) + res[s_][1].y;
+          o1.z = r[6][s_] + (nb ? biasB[jp][6] : bias[jp][6]) + res[s_][1].z; o1.w = r[7][s_] + (nb ? biasB[jp][7] : bias[jp][7]) + res[s_][1].w;
+        } else {
+          o0.x = r[0][s_] + bias[jp][0] + res[s_][0].x; o0.y = r[1][s_] + bias[jp][1] + res[s_][0].y;
+          o0.z = r[2][s_] + bias[jp][2] + res[s_][0].z; o0.w = r[3][s_] + bias[jp][3] + res[s_][0].w;
+          o1.x = r[4][s_] + bias[jp][4] + res[s_][1].x; o1.y = r[5][s_] + bias[jp][5] + res[s_][1].y;
+          o1.z = r[6][s_] + bias[jp][6] + res[s_][1].z; o1.w = r[7][s_] + bias[jp][7] + res[s_][1].w;
         }
         if (PROD) {      // sum x, sum x^2 over the round's 64 columns of this row: the 8 lanes of a row quad folded by DPP, lane cg == 0 stores
           float a = ((o0.x + o0.y) + (o0.z + o0.w)) + ((o1.x + o1.y) + (o1.z + o1.w));
@@ -360,16 +371,12 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   // rounds r = 2 i + jp.  ONE fragment set: the wave must not spill here - a reload is a VMEM load behind the round's stores, i.e. an
   // s_waitcnt vmcnt(0) that drains them (and the LDS-DMA pieces of the next tile) once per round
   float4 res0[4][2], res1[4][2];
-  float4 rv0[4][2], rv1[4][2];      // (EPI 10 only; dead otherwise)
   uint4 aux0[4], aux1[4];
   if (RES) {
     ldres(0, 0, res0);
     ldres(0, 1, res1);
   }
-  if constexpr (EPI == 10) {
-    ldrv(0, 0, rv0);
-    ldrv(0, 1, rv1);
-  }
+
   if (EPI == 6) {
     ldaux(0, 0, aux0);
     ldaux(0, 1, aux1);
@@ -378,61 +385,55 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   rd(rd0);
   wr(I0{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 0, rd0, res0, aux0, rv0);
+  out(0, 0, rd0, res0, aux0);
   if (RES) ldres(1, 0, res0);
-  if constexpr (EPI == 10) ldrv(1, 0, rv0);
   if (EPI == 6) ldaux(1, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(0, 1, rd0, res1, aux1, rv1);
+  out(0, 1, rd0, res1, aux1);
   if (NORM) ldmr(2);
   if (RES) ldres(1, 1, res1);
-  if constexpr (EPI == 10) ldrv(1, 1, rv1);
   if (EPI == 6) ldaux(1, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I1{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 0, rd0, res0, aux0, rv0);
+  out(1, 0, rd0, res0, aux0);
   if (RES) ldres(2, 0, res0);
-  if constexpr (EPI == 10) ldrv(2, 0, rv0);
   if (EPI == 6) ldaux(2, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(1, 1, rd0, res1, aux1, rv1);
+  out(1, 1, rd0, res1, aux1);
   if (NORM) ldmr(3);
   if (RES) ldres(2, 1, res1);
-  if constexpr (EPI == 10) ldrv(2, 1, rv1);
   if (EPI == 6) ldaux(2, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I2{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 0, rd0, res0, aux0, rv0);
+  out(2, 0, rd0, res0, aux0);
   if (RES) ldres(3, 0, res0);
-  if constexpr (EPI == 10) ldrv(3, 0, rv0);
   if (EPI == 6) ldaux(3, 0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I0{});
   __builtin_amdgcn_sched_barrier(0);
-  out(2, 1, rd0, res1, aux1, rv1);
+  out(2, 1, rd0, res1, aux1);
   if (RES) ldres(3, 1, res1);
-  if constexpr (EPI == 10) ldrv(3, 1, rv1);
   if (EPI == 6) ldaux(3, 1, aux1);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   wr(I3{}, I1{});
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 0, rd0, res0, aux0, rv0);
+  out(3, 0, rd0, res0, aux0);
   __builtin_amdgcn_sched_barrier(0);
   rd(rd0);
   __builtin_amdgcn_sched_barrier(0);
-  out(3, 1, rd0, res1, aux1, rv1);
+  out(3, 1, rd0, res1, aux1);
   __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -167,6 +167,7 @@ class LamEngine:
         self.norm_fold = (scope == "all" and spec is not None and dtype == torch.float16 and spec.dim >= 512 and spec.dim % 256 == 0
                           and spec.mlp % 256 == 0 and (3 * spec.heads * 64 * ((spec.head_dim + 63) // 64)) % 256 == 0
                           and not (self.precise & {"qkv", "v", "lin1"}))
+        self.norm_fold_packed = self.norm_fold      # (the folded weights exist; Lam.norm_fold = False switches back to the LayerNorm kernels)
         self._last16 = None
         self.ddt = dtype if decoder_dtype is None else decoder_dtype
         self.ddti = L._DT[self.ddt]

@@ -107,6 +107,7 @@ class Lam(nn.Module):
         self._plist = None
         self._graphs: Dict[Any, Any] = {}
         self.use_graphs = False          # replay the device-side launch sequence from a HIP graph (per input plan)
+        self.norm_fold = True            # A/B switch: False keeps the LayerNorm kernels where the engine would fold them into the GEMMs (LamEngine.norm_fold)
         self.attn_fp8 = False            # opt-in: fp8 (e4m3) QK^T in the HF encoder's attention (BASELINE configs[4]); outside the 1e-3 tolerance
         self.selected_rows: Optional[torch.Tensor] = None   # fix the RandomMatrixEncoder rows (parity / reproducibility)
 
@@ -132,6 +133,10 @@ class Lam(nn.Module):
         if self._engine.attn_fp8 != bool(self.attn_fp8):
             self._engine.attn_fp8 = bool(self.attn_fp8)
             self._graphs = {}                # a captured launch sequence holds the kernel choice it was recorded with
+        fold = self._engine.norm_fold_packed and bool(self.norm_fold)
+        if self._engine.norm_fold != fold:
+            self._engine.norm_fold = fold
+            self._graphs = {}
         return self._engine
 
     def invalidate(self) -> None:

@@ -30,12 +30,14 @@ TOL = {
     torch.float16: dict(emb=1e-3, cls=1e-3, low=1e-3, logits=1e-3),
     torch.bfloat16: dict(emb=6.5e-3, cls=1.5e-3, low=9e-3, logits=8e-3),
 }
-# share of the pixels measured to flip inside the near-tie band, per case (profiles/r03_parity.log, default numerics); the test allows
-# 2 x that count (box-to-box the last bits of the token-mean sums are identical, so the spread is what a kernel change may move),
-# and at least ARGMAX_FLOOR pixels for the decoder-only cases that measure zero
+# share of the pixels measured to flip inside the near-tie band, per case (profiles/r06_parity.log, default numerics - round 6: LayerNorm
+# folded into the GEMMs for the two wide encoders, which draws another realisation of the weight roundings: cfg2 1.29e-3 -> 3.81e-3,
+# cfg1 2.66e-3 -> 6.5e-4).  The TOLERANCE is the assertion above: no pixel whose reference top-2 margin exceeds the band may flip.  The
+# count below is only a regression pin (2 x measured; results are deterministic, box to box the last bits are identical), and at least
+# ARGMAX_FLOOR pixels for the decoder-only cases that measure zero
 ARGMAX_MEASURED = {
     torch.float16: {"sam_tiny_2w2s_all_prompts": 8.7e-4, "hf_tiny_1w1s_masks": 2.1e-4, "novit_d256_2w3s": 0.0, "novit_d512_neck_1w2s": 0.0,
-                    "cfg2_sam_b_1024_1w1s": 1.29e-3, "cfg1_mae_b_480_1w1s": 2.66e-3},
+                    "cfg2_sam_b_1024_1w1s": 3.81e-3, "cfg1_mae_b_480_1w1s": 6.6e-4},
     torch.bfloat16: {"sam_tiny_2w2s_all_prompts": 4.6e-3, "hf_tiny_1w1s_masks": 2.5e-3, "novit_d256_2w3s": 0.0, "novit_d512_neck_1w2s": 0.0,
                      "cfg2_sam_b_1024_1w1s": 1.23e-2, "cfg1_mae_b_480_1w1s": 6.2e-3},
 }

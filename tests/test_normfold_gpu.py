@@ -34,7 +34,7 @@ def _producer(L, m, n, k, rpg, res_mod=0, a_kmod=0, with_rvec=True, with_res=Tru
     res = rnd(res_mod or m, n, seed=4) if with_res else None
     groups = -(-m // rpg)
     rvec = rnd(groups, n, seed=5, scale=0.3) if with_rvec else None
-    af = a.float() if not a_kmod else a.float().repeat(1, k // a_kmod)
+    af = a.float() if not a_kmod else a.float().repeat(1, -(-k // a_kmod))[:, :k]      # the A columns repeat with period a_kmod
     ref = af @ w.float().t() + bias
     if with_res:
         ref = ref + (res.repeat(m // res_mod, 1) if res_mod else res)
@@ -67,7 +67,7 @@ def test_producer_gemm_writes_stream_copy_and_row_sums(L, shape):
 def test_producer_gemm_periodic_residual_and_planes(L):
     """The patch embedding's form: [A_hi | A_lo] against [W_hi | W_hi | W_lo], residual = the position table modulo its rows."""
     m, n, k0, period = 4 * 1024, 768, 256, 1024
-    ref, o32, o16, part = _producer(L, m, n, 3 * 2 * k0 // 2, period, res_mod=period, a_kmod=2 * k0, with_rvec=False)
+    ref, o32, o16, part = _producer(L, m, n, 3 * k0, period, res_mod=period, a_kmod=2 * k0, with_rvec=False)
     assert rel_err(o32, ref) < 1e-3
     assert torch.equal(o16, o32.half())
     assert rel_err(part[..., 0].sum(1), o32.sum(1)) < 1e-5
@@ -81,12 +81,23 @@ def test_producer_gemm_without_group_vector_or_residual(L):
 
 
 def test_producer_results_do_not_depend_on_the_batch(L):
-    """Partial sums are per row in a fixed order: a row's statistics are the same in a 2-image and a 4-image launch."""
-    _, o32a, _, pa = _producer(L, 2 * 4096, 768, 768, 4096)
-    _, o32b, _, pb = _producer(L, 4 * 4096, 768, 768, 4096)
-    # (same seeds: the first rows of the larger problem are NOT the smaller problem's rows - compare a launch with itself instead)
-    _, o32c, _, pc = _producer(L, 2 * 4096, 768, 768, 4096)
-    assert torch.equal(pa, pc) and torch.equal(o32a, o32c)
+    """Rows are independent and the partial sums have a fixed order: the first two images of a four-image launch come out bit-identical
+    to a two-image launch of the same rows (also with groups that do not end on tile edges: two groups inside one tile)."""
+    for rpg, n, k in ((4096, 768, 768), (901, 768, 768)):
+        m4, m2 = 4 * rpg, 2 * rpg
+        a = rnd(m4, k, seed=41).half()
+        w = (rnd(n, k, seed=42) / math.sqrt(k)).half()
+        bias, res, rvec = rnd(n, seed=43), rnd(m4, n, seed=44), rnd(4, n, seed=45, scale=0.3)
+        outs = []
+        for m in (m4, m2):
+            o32 = res[:m].clone()
+            o16 = torch.zeros(m, n, device="cuda", dtype=torch.float16)
+            part = torch.zeros(m, n // 64, 2, device="cuda")
+            L.gemm(a[:m], w, bias=bias, res=o32, out32=o32, out16=o16, nstat_out=part, rvec=rvec[: m // rpg], rvec_rpg=rpg)
+            torch.cuda.synchronize()
+            outs.append((o32, o16, part))
+        for big, small in zip(outs[0], outs[1]):
+            assert torch.equal(big[:m2], small)
 
 
 @pytest.mark.parametrize("m,e,eps", [(8192, 768, 1e-6), (2703, 768, 1e-12), (1000, 1024, 1e-6)])

@@ -25,10 +25,11 @@ pytestmark = pytest.mark.gpu
 NAMES = ("cfg2_sam_b_1024_1w1s", "cfg1_mae_b_480_1w1s")
 
 
-def seed_errors(name: str, seed: int, precise="auto"):
+def seed_errors(name: str, seed: int, precise="auto", norm_fold=True):
     case = CASES[name]
     cfg = case["cfg"]
     lam = Lam(cfg, seed=seed, precise=precise).cuda()
+    lam.norm_fold = norm_fold
     ep = dict(case["episode"])
     ep["seed"] = seed
     batch = make_episode(**ep)
@@ -61,10 +62,11 @@ def test_default_numerics_hold_1e3_over_seeds(name, seed):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     precise = "auto"
+    fold = "--no-fold" not in sys.argv[1:]          # the LayerNorm kernels instead of the folded form (LamEngine.norm_fold)
     for a in sys.argv[1:]:
         if a.startswith("--precise="):
             precise = tuple(g for g in a.split("=", 1)[1].split(",") if g)
-    print("precise =", precise)
+    print("precise =", precise, "norm_fold =", fold)
     for nm in NAMES:
         for sd in [int(s) for s in args] or [101, 202, 303]:
-            print(nm, sd, seed_errors(nm, sd, precise), flush=True)
+            print(nm, sd, seed_errors(nm, sd, precise, fold), flush=True)
