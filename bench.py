@@ -104,7 +104,7 @@ class KernelTimer:
                  "attn_small_bwd", "bilinear_bwd", "bilinear_bwd_set", "bilinear_rows", "bilinear_rows_bwd_set", "classify_bwd", "row_broadcast", "focal_loss", "adamw_step", "colsum_acc",
                  "attn_fwd_lse", "attn_bwd", "head_transpose", "cast", "gelu_bwd16", "axpy", "transpose16", "colmean16", "layernorm_g", "add_rowvec", "add_rowvec_split", "qk_fp8", "attn_fwd_fp8", "attn_fwd_cs", "colsum_fold", "gelu_fwd16",
                  "attn_fwd_relpos_lse", "attn_bwd_relpos", "relpos_bwd", "layernorm_bwd_res", "transpose_many", "attn_fwd_rows", "gemm_tn16",
-                 "norm_finalize", "norm_stats"]
+                 "norm_finalize", "norm_stats", "conv3x3_split"]
         for n in names:
             fn = getattr(L, n)
             self.saved[n] = fn

@@ -133,6 +133,13 @@ int la_gemm(const void* A, int lda, const void* W, int ldw, int M, int N, int K,
 int la_conv3x3_f32(const float* in, int B, int H, int W, int Cin, const float* wt, const float* bias, int Cout, float* out32,
                    void* stream);
 
+/* The same convolution for Cin == Cout == 32 (the D = 256 mask decoder's spatial convolutions, mask_decoder.py:236-255) in SPLIT precision on the
+ * 16-bit MFMA: input pixels and weights enter as fp16 plane pairs (hi = rn16(x), lo = rn16(x - hi)), three products per k-step
+ * (A_hi W_hi + A_lo W_hi + A_hi W_lo, ~22 mantissa bits: the accuracy class of LA_F16X2, 1e-6 relative), the 10 x 34 halo of an 8 x 32
+ * pixel tile staged once in LDS.  Same arguments and layouts as la_conv3x3_f32; la_conv3x3_split_ok says whether the channel counts are taken. */
+int la_conv3x3_split_ok(int Cin, int Cout);
+int la_conv3x3_split(const float* in, int B, int H, int W, int Cin, const float* wt, const float* bias, int Cout, float* out32, void* stream);
+
 /* Row LayerNorm over the last dim (biased variance):  y = LN(x [+ x2]) * gamma + beta  [-> GELU].
  * x, x2 fp32 [rows, E] (ldx).  Outputs (each optional): out32 fp32, out16, out16_pe = y + pe[(row % pe_mod)]
  * (pe fp32 [pe_mod, E]).  window > 0: rows are (b, y, x) tokens on an H x W grid and the 16-bit outputs are written

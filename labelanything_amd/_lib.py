@@ -65,7 +65,7 @@ EXPORTS = [
     "la_gemm_tn", "la_gemm_tn16", "la_gemm_fused_act_ok", "la_colsum_acc", "la_layernorm_bwd", "la_layernorm_bwd_res", "la_transpose_many", "la_act_fwd", "la_act_bwd", "la_attn_small_lse", "la_attn_small_bwd", "la_bilinear_bwd", "la_bilinear_bwd_set", "la_bilinear_bwd_set_ok", "la_bilinear_rows", "la_bilinear_rows_bwd_set",
     "la_classify_bwd", "la_row_broadcast", "la_twoway_t2i", "la_twoway_i2t", "la_gemm_variant", "la_attn_fwd_lse", "la_head_transpose", "la_attn_bwd", "la_cast", "la_gelu_bwd16", "la_axpy", "la_transpose16", "la_qk_fp8", "la_attn_fwd_fp8", "la_colmean16", "la_layernorm_g", "la_add_rowvec", "la_add_rowvec_split", "la_attn_fwd_cs", "la_attn_fwd_rows", "la_colsum_fold", "la_gelu_fwd16", "la_gemm_tn_db",
     "la_attn_fwd_relpos_lse", "la_attn_bwd_relpos", "la_relpos_bwd", "la_twoway_pe_layout",
-    "la_norm_finalize", "la_norm_stats",
+    "la_norm_finalize", "la_norm_stats", "la_conv3x3_split", "la_conv3x3_split_ok",
 ]
 
 
@@ -385,6 +385,22 @@ def conv3x3_f32(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out3
     _dev(x32)
     _check(lib().la_conv3x3_f32(_ptr(x32), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(cin), _ptr(wt), _ptr(bias), C.c_int(cout),
                                 _ptr(out32), _stream()), "la_conv3x3_f32")
+
+
+def conv3x3_split_ok(cin: int, cout: int) -> bool:
+    return bool(lib().la_conv3x3_split_ok(C.c_int(cin), C.c_int(cout)))
+
+
+def conv3x3_split(x32, b: int, h: int, w: int, cin: int, wt, bias, cout: int, out32) -> None:
+    """la_conv3x3_f32's convolution for 32 -> 32 channels as three fp16 MFMA products on plane pairs (fp32-class accuracy, ~3x the rate)."""
+    _dev(x32)
+    for t_, n_ in ((x32, b * h * w * cin), (wt, cout * 9 * cin), (out32, b * h * w * cout)):
+        if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.numel() < n_:
+            raise RuntimeError("conv3x3_split: contiguous fp32 input [b*h*w, cin], weight [cout, 9*cin], output [b*h*w, cout]")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() < cout):
+        raise RuntimeError("conv3x3_split: bias must be fp32 [cout]")
+    _check(lib().la_conv3x3_split(_ptr(x32), C.c_int(b), C.c_int(h), C.c_int(w), C.c_int(cin), _ptr(wt), _ptr(bias), C.c_int(cout),
+                                  _ptr(out32), _stream()), "la_conv3x3_split")
 
 
 # ---- backward kernels (training step, csrc/train.hip) ------------------------------------------------------------------------

@@ -150,8 +150,8 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
       biasB[jp][0] += r0.x; biasB[jp][1] += r0.y; biasB[jp][2] += r0.z; biasB[jp][3] += r0.w;
       biasB[jp][4] += r1.x; biasB[jp][5] += r1.y; biasB[jp][6] += r1.z; biasB[jp][7] += r1.w;
     }
-    if (PROD && e.rvec) {
-      const float* rv = e.rvec + (size_t)(row0 / e.rvec_rpg) * N + col0 + jp * 64 + cg * 8;
+    if (PROD && e.rvec) {      // (a wave that lies entirely beyond M in the ragged last row tile: clamped to the last group, nothing of it is stored)
+      const float* rv = e.rvec + (size_t)min(row0 / e.rvec_rpg, (M - 1) / e.rvec_rpg) * N + col0 + jp * 64 + cg * 8;
       const float4 r0 = *reinterpret_cast<const float4*>(rv), r1 = *reinterpret_cast<const float4*>(rv + 4);
       bias[jp][0] += r0.x; bias[jp][1] += r0.y; bias[jp][2] += r0.z; bias[jp][3] += r0.w;
       bias[jp][4] += r1.x; bias[jp][5] += r1.y; bias[jp][6] += r1.z; bias[jp][7] += r1.w;

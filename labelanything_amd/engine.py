@@ -158,6 +158,7 @@ class LamEngine:
         # attention without V^T copies / window buffers (la_attn_fwd_rows) wherever its forms cover the block: plain attention, the 64 x 64
         # rel-pos grid, 16-slot windows; False keeps the V^T epilogue + window scatter path (A/B, and what the other geometries still use)
         self.attn_rows = True
+        self.conv_split = True             # the mask decoder's 32-channel spatial convolutions on la_conv3x3_split (A/B: False = la_conv3x3_f32)
         # LayerNorm folded into its neighbour GEMMs (round 6; LaGemmEpilogue.nstat_out / nstat_in): the residual GEMMs (patch embedding, proj,
         # lin2) also write the 16-bit copy of the stream and the partial sums of every row, q | k | v and lin1 run on gamma-folded weights
         # and normalise the product in their epilogue - no LayerNorm pass over the stream (24 launches, 10.4 ms of a 131 ms cfg2 step).
@@ -1323,7 +1324,10 @@ class LamEngine:
             for i in range(cfg.spatial_convs):
                 if implicit:      # fp32 implicit GEMM: no im2col buffer (feat16 IS fp32 here)
                     nxt = self.f32("md.feat32b" if i % 2 == 0 else "md.feat32", (b * npix, cf))
-                    L.conv3x3_f32(feat16, b, 4 * g, 4 * g, cf, p[f"{md}.sc{i}.w"], w[f"{md}.spatial_convs.{3 * i}.bias"], cf, nxt)
+                    # (32 -> 32 channels, the D = 256 decoder: three fp16 products on plane pairs - fp32-class accuracy at ~3x the rate of
+                    # the exact-fp32 MFMA, which bounds la_conv3x3_f32; other widths keep that kernel)
+                    conv = L.conv3x3_split if (self.conv_split and L.conv3x3_split_ok(cf, cf)) else L.conv3x3_f32
+                    conv(feat16, b, 4 * g, 4 * g, cf, p[f"{md}.sc{i}.w"], w[f"{md}.spatial_convs.{3 * i}.bias"], cf, nxt)
                     feat32 = nxt
                 else:
                     L.im2col_3x3(feat16, b, 4 * g, 4 * g, cf, col)

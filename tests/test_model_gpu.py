@@ -485,6 +485,7 @@ def test_attention_rows_path_matches_the_v_transposed_path(name):
     for rows in (True, False):
         lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
         lam.selected_rows = gold.get("selected_rows")
+        lam.norm_fold = False              # (the folded-LayerNorm block stack exists for the rows path only: compare like with like)
         lam.engine().attn_rows = rows
         outs.append(lam(batch)["logits"].float().clone())
         del lam
@@ -492,3 +493,27 @@ def test_attention_rows_path_matches_the_v_transposed_path(name):
     err = rel_err(outs[0], outs[1])
     print(f"[attn_rows {name}] logits, rows path vs V^T path: {err:.3e}")
     assert err <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["cfg2_sam_b_1024_1w1s", "cfg1_mae_b_480_1w1s"])
+def test_folded_layernorm_block_stack_against_the_layernorm_kernels(name):
+    """LamEngine.norm_fold (round 6, the default of the wide fp16 encoders): norm1 / norm2 folded into the GEMMs on both sides
+    (image_encoder.py:181-197).  Same mathematics, another realisation of the 16-bit roundings (rn16(W diag(gamma)) instead of rn16(W),
+    rn16(x) instead of rn16(LayerNorm(x))): both forms hold the 1e-3 tolerance against the reference fixture on their own
+    (test_episode_matches_reference_fixture runs the default; this test runs the other one) and they differ from each other by less than
+    the sum of their errors."""
+    case = CASES[name]
+    gold, _ = load_golden(name)
+    batch = make_episode(**case["episode"])
+    ref_logits = reference_logits(case, gold, batch)
+    outs = []
+    for fold in (True, False):
+        lam = Lam(case["cfg"], seed=case["weight_seed"]).cuda()
+        lam.norm_fold = fold
+        outs.append(lam(batch)["logits"].float().clone())
+        assert lam.engine().norm_fold == fold
+        del lam
+        torch.cuda.empty_cache()
+    e_fold, e_plain, e_between = rel_err(outs[0], ref_logits), rel_err(outs[1], ref_logits), rel_err(outs[0], outs[1])
+    print(f"[norm_fold {name}] logits vs reference: folded {e_fold:.3e}, LayerNorm kernels {e_plain:.3e}; folded vs LayerNorm kernels {e_between:.3e}")
+    assert e_fold <= 1e-3 and e_plain <= 1e-3 and 0 < e_between <= 2e-3

@@ -1094,3 +1094,26 @@ def test_bilinear_on_nhwc_rows_forward_and_backward(L, shape):
     torch.cuda.synchronize()
     gref = xd.grad.float().view(n, c, h * w).permute(0, 2, 1).reshape(n * h * w, c)
     assert rel_err(xr.grad, gref) < 3e-5
+
+
+@pytest.mark.parametrize("bhw", [(2, 64, 64), (1, 37, 53), (3, 8, 32), (1, 256, 256)])
+def test_conv3x3_split_precision_matches_torch_and_the_fp32_kernel(L, bhw):
+    """la_conv3x3_split (mask_decoder.py:236-255 spatial convolutions at 32 channels): three fp16 products on plane pairs against
+    F.conv2d in fp64 and against the exact-fp32 implicit GEMM it replaces in the inference engine."""
+    b, h, w = bhw
+    c = 32
+    x = rnd(b * h * w, c, seed=61)
+    wt = rnd(c, c, 3, 3, seed=62) / math.sqrt(9 * c)
+    bias = rnd(c, seed=63) * 0.1
+    wk = wt.permute(0, 2, 3, 1).flatten(1).contiguous()                 # [cout, (ky, kx, cin)]
+    ref = F.conv2d(x.view(b, h, w, c).permute(0, 3, 1, 2).double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(b * h * w, c)
+    out = torch.full((b * h * w, c), float("nan"), device="cuda")
+    out32 = torch.empty_like(out)
+    assert L.conv3x3_split_ok(c, c) and not L.conv3x3_split_ok(64, 64)
+    L.conv3x3_split(x, b, h, w, c, wk, bias, c, out)
+    L.conv3x3_f32(x, b, h, w, c, wk, bias, c, out32)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    e_split, e_f32 = float((out.double() - ref).abs().max()) / scale, float((out32.double() - ref).abs().max()) / scale
+    print(f"[conv3x3 {bhw}] split precision {e_split:.2e}, exact fp32 {e_f32:.2e}")
+    assert e_split < 2e-6 and e_f32 < 2e-6

@@ -8,6 +8,7 @@ OUT=gpurun_out/pmc_$R
 mkdir -p $OUT
 SUM=gpurun_out/${R}_pmc_summary.txt
 : > $SUM
+# (round 6: the folded-LayerNorm forms at the model's 96-image shapes and the product's attention kernels: PMC_SHAPES="qkv_n lin1_n proj_p lin2_p attn_rows attn_win")
 for w in ${PMC_SHAPES:-lin1 lin2 qk v2 attn}; do
   i=0
   for pmc in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
