@@ -105,7 +105,10 @@ typedef struct LaGemmEpilogue {
    *   (+ rvec[row / rvec_rpg][col], a per-group fp32 vector [groups, N]: the token-mean correction of the block, added to the stream HERE
    *   instead of being carried as a pending vector) and out16 = its 16-bit rounding, every epilogue round leaves the partial row sums of its 64
    *   columns: nstat_out[(row * (N / 64) + col / 64) * 2 + {0, 1}] = sum x, sum x^2 over those columns (fp32, fixed order: deterministic).
-   *   la_norm_finalize turns the N / 64 partials of a row into (mean, rstd).
+   *   la_norm_finalize turns the N / 64 partials of a row into (mean, rstd).  out16 saturates at the fp16 range (it is an MFMA operand; an
+   *   un-normalised stream has no range guarantee).  aux16 != NULL (producer only): the lo plane rn16(x - out16) of the same rows - with
+   *   out16 / aux16 pointing at the two halves of [rows, 2 N] rows the stream leaves the block stack as an LA_F16X2 operand (the SAM neck's
+   *   1 x 1 convolution) without a pass of its own.
    * CONSUMER (the GEMM behind the LayerNorm; out16 only, act NONE or GELU): nstat_in != NULL - A is the UN-normalised 16-bit stream, W the
    *   16-bit rounding of W diag(gamma), and the epilogue applies the normalisation to the product:
    *     out = act( rstd[row] * (acc - mean[row] * ncol[col]) + bias[col] ),   ncol[col] = sum_k W16[col][k],  bias = b + W beta

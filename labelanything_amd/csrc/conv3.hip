@@ -63,17 +63,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_split_kernel(const float* __re
     const int ty0 = (t_ / ntx) * C3_TH, tx0 = (t_ % ntx) * C3_TW;
     // ---- halo: 10 x 34 pixels x 32 channels, split into the two planes on the way into LDS (zero outside the image) ----------------
     const float* img = in + (size_t)b * H * W * 32;
-    for (int i = tid; i < C3_HR * C3_HC * 8; i += 256) {
-      const int pix = i >> 3, c4 = i & 7;
-      const int hy = pix / C3_HC, hx = pix % C3_HC;
-      const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const float4*>(img + ((size_t)y * W + x) * 32 + c4 * 4);
-      uint2 hi, lo;
-      split4(v, hi, lo);
-      const int off = hy * C3_AROW + hx * 64 + ((((c4 >> 1) ^ (hx >> 2)) & 3) << 4) + (c4 & 1) * 8;
-      *reinterpret_cast<uint2*>(a_hi + off) = hi;
-      *reinterpret_cast<uint2*>(a_lo + off) = lo;
+    // (2720 float4 per tile = 10.6 per thread: two batches of six requests in flight per thread - a rolled loop issued them one at a time)
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+      float4 v[6];
+      int off[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int i = tid + (bt * 6 + u) * 256;
+        const int pix = i >> 3, c4 = i & 7;
+        const int hy = pix / C3_HC, hx = pix % C3_HC;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        off[u] = i < C3_HR * C3_HC * 8 ? hy * C3_AROW + hx * 64 + ((((c4 >> 1) ^ (hx >> 2)) & 3) << 4) + (c4 & 1) * 8 : -1;
+        if (off[u] >= 0 && y >= 0 && y < H && x >= 0 && x < W) v[u] = *reinterpret_cast<const float4*>(img + ((size_t)y * W + x) * 32 + c4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        uint2 hi, lo;
+        split4(v[u], hi, lo);
+        if (off[u] >= 0) {
+          *reinterpret_cast<uint2*>(a_hi + off[u]) = hi;
+          *reinterpret_cast<uint2*>(a_lo + off[u]) = lo;
+        }
+      }
     }
     __syncthreads();
 

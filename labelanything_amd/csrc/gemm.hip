@@ -2141,7 +2141,7 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LA_CHECK_ARG(epi->act != LA_ACT_GELU_BWD || epi->aux16, "la_gemm: LA_ACT_GELU_BWD needs aux16 (the saved pre-activation)");
-  if (epi->aux16) {
+  if (epi->aux16 && !epi->nstat_out) {
     // the training forms of the MLP's GELU (see LaGemmEpilogue.aux16): the direct epilogue of the persistent four-wave kernel only
     LA_CHECK_ARG(epi->act == LA_ACT_GELU || epi->act == LA_ACT_GELU_BWD, "la_gemm: aux16 goes with LA_ACT_GELU (written) or LA_ACT_GELU_BWD (read)");
     LA_CHECK_ARG(dt != LA_F32 && la_gemm_fused_act_ok(M, N, K) && la::fast_ok(A, lda, W, ldw, M, N, K, *epi),
@@ -2169,9 +2169,9 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                      la::fast_ok(A, lda, W, ldw, M, N, K, *epi) && (la::g_gemm_variant & 0xff) == 2,
                  "la_gemm: nstat_out / nstat_in need fp16 operands, N %% 256 == 0, K %% 64 == 0, K >= 128, 16-byte aligned rows (M=%d N=%d K=%d)", M,
                  N, K);
-    LA_CHECK_ARG(!epi->vt && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && epi->ksplit == 0 && !epi->aux16 &&
-                     !(epi->nstat_out && epi->nstat_in),
-                 "la_gemm: nstat_out / nstat_in take no row maps / V^T / ksplit / aux16, and not both at once");
+    LA_CHECK_ARG(!epi->vt && epi->map == LA_MAP_NONE && epi->amap == LA_MAP_NONE && epi->ksplit == 0 && !(epi->nstat_out && epi->nstat_in) &&
+                     (!epi->aux16 || (epi->nstat_out && (epi->ldaux % 8) == 0 && epi->ldaux >= N && (reinterpret_cast<uintptr_t>(epi->aux16) & 15) == 0)),
+                 "la_gemm: nstat_out / nstat_in take no row maps / V^T / ksplit, not both at once; aux16 only with nstat_out (the lo plane, 16-byte aligned rows)");
     const int gm = la::tile_group_m(N >= 2560 ? 8 : 2);
     if (epi->nstat_in) {
       LA_CHECK_ARG(epi->ncol && epi->out16 && !epi->out32 && !epi->res && !epi->rvec && (epi->act == LA_ACT_NONE || epi->act == LA_ACT_GELU) &&

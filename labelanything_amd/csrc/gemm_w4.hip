@@ -253,7 +253,25 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
         float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
         *reinterpret_cast<float4*>(op) = o0;
         *reinterpret_cast<float4*>(op + 4) = o1;
-        if (out16) {
+        if (PROD) {
+          // the 16-bit copy is an MFMA operand of the next GEMM: it SATURATES at the fp16 range instead of turning into inf (an un-normalised
+          // stream has no range guarantee; SAM checkpoints stay three orders of magnitude below).  aux16 (optional): the lo plane
+          // rn16(x - hi) beside it - [hi | lo] rows, the LA_F16X2 operand of the SAM neck's 1 x 1 convolution, without a pass of its own
+          constexpr float HMAX = 65504.0f;
+          float c[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+          for (int t = 0; t < 8; ++t) c[t] = __builtin_amdgcn_fmed3f(c[t], -HMAX, HMAX);
+          uint4 pk;
+          pk.x = pack2<T>(c[0], c[1]); pk.y = pack2<T>(c[2], c[3]); pk.z = pack2<T>(c[4], c[5]); pk.w = pack2<T>(c[6], c[7]);
+          *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
+          if (aux16) {
+            const T* h = reinterpret_cast<const T*>(&pk);
+            uint4 lo;
+            lo.x = pack2<T>(c[0] - (float)h[0], c[1] - (float)h[1]); lo.y = pack2<T>(c[2] - (float)h[2], c[3] - (float)h[3]);
+            lo.z = pack2<T>(c[4] - (float)h[4], c[5] - (float)h[5]); lo.w = pack2<T>(c[6] - (float)h[6], c[7] - (float)h[7]);
+            *reinterpret_cast<uint4*>(aux16 + (size_t)(row + s_) * e.ldaux + col) = lo;
+          }
+        } else if (out16) {
           uint4 pk;
           pk.x = pack2<T>(o0.x, o0.y); pk.y = pack2<T>(o0.z, o0.w); pk.z = pack2<T>(o1.x, o1.y); pk.w = pack2<T>(o1.z, o1.w);
           *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;

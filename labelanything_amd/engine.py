@@ -822,6 +822,8 @@ class LamEngine:
             have_mr = True
         nwy = (g + ws - 1) // ws
         vm, pm = "vmean" in self.precise, "projmean" in self.precise
+        split_neck = self.cfg.use_vit_sam_neck and (pre + ".neck.0.ws") in p
+        xs = None
         for i in range(spec.depth):
             bp = f"{pre}.blocks.{i}"
             is_global = i in spec.global_idx
@@ -847,15 +849,18 @@ class LamEngine:
             L.norm_finalize(part, rows, e, 1e-6, mr)
             hbuf = self.buf("enc.mlp", (rows, spec.mlp))
             L.gemm(x16, p[bp + ".lin1.wn"], bias=p[bp + ".lin1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[bp + ".lin1.cn"])
-            L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=x16, nstat_out=part,
-                   a_kmod=self.kmod.get(bp + ".lin2.w", 0))
-        last16 = x16               # (the last lin2 launch left the 16-bit rounding of the finished stream)
+            if i == spec.depth - 1 and split_neck:
+                # the stream leaves the stack as fp16 plane pairs [hi | lo] - the operand of the neck's 1 x 1 convolution (three fp16
+                # products) - straight from the last residual epilogue (LaGemmEpilogue.aux16 = the lo plane): no la_add_rowvec_split pass
+                xs = self.buf("enc.res_split", (rows, 2 * e), torch.float16)
+                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=xs[:, :e], aux16=xs[:, e:], nstat_out=part,
+                       a_kmod=self.kmod.get(bp + ".lin2.w", 0))
+            else:
+                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=x16, nstat_out=part,
+                       a_kmod=self.kmod.get(bp + ".lin2.w", 0))
+        last16 = x16               # (the last lin2 launch left the 16-bit rounding of the finished stream - unless it wrote the plane pairs)
         if not self.cfg.use_vit_sam_neck:
             return (res, last16, e) if not want_last_block else ((res, last16, e), res)
-        xs = None
-        if (pre + ".neck.0.ws") in p:
-            xs = self.buf("enc.res_split", (rows, 2 * e), torch.float16)
-            L.add_rowvec_split(res, None, hw, xs)
         out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck", x32=res, xs=xs)
         if want_last_block:
             return (out, None, spec.out_chans), res

@@ -210,3 +210,32 @@ def test_model_registry_has_every_on_path_reference_name(tmp_path):
     assert torch.equal(enc2.state_dict()["pos_embed"], sd["pos_embed"] + 1)
     with pytest.raises(RuntimeError):
         M.build_encoder("sam_tiny", checkpoint=ck)                   # prefixed keys without use_sam_checkpoint: strict load fails
+
+
+def test_folded_layernorm_algebra_is_exact():
+    """The identity behind LamEngine.norm_fold (image_encoder.py:181-197: Linear(LayerNorm(x))), in float64 on the CPU: with
+    W' = W diag(gamma), c = row sums of W', b' = b + W beta and the row statistics (mean, rstd) of x,
+        rstd (x W'^T - mean c) + b'  ==  LayerNorm(x) W^T + b
+    - what the consumer GEMM's epilogue evaluates from the un-normalised operand - and the partial-sum form of the statistics
+    (sum x, sum x^2 per 64-column slot, as the producer epilogue leaves them) reproduces mean and rstd."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    m, k, n, eps = 37, 768, 96, 1e-6
+    x = (torch.randn(m, k, generator=g, dtype=torch.float64) * (0.5 + torch.rand(m, 1, generator=g, dtype=torch.float64) * 4)
+         + torch.randn(m, 1, generator=g, dtype=torch.float64))
+    gamma = 1 + 0.1 * torch.randn(k, generator=g, dtype=torch.float64)
+    beta = 0.05 * torch.randn(k, generator=g, dtype=torch.float64)
+    w = torch.randn(n, k, generator=g, dtype=torch.float64) / k ** 0.5
+    b = 0.02 * torch.randn(n, generator=g, dtype=torch.float64)
+    ref = F.linear(F.layer_norm(x, (k,), gamma, beta, eps), w, b)
+    part = torch.stack([x.view(m, k // 64, 64).sum(2), (x * x).view(m, k // 64, 64).sum(2)], dim=2)
+    mean = part[..., 0].sum(1, keepdim=True) / k
+    rstd = (part[..., 1].sum(1, keepdim=True) / k - mean * mean + eps).rsqrt()
+    wf = w * gamma
+    out = rstd * (x @ wf.t() - mean * wf.sum(1)) + (b + w @ beta)
+    assert float((out - ref).abs().max()) < 1e-11
+    # the token-mean correction of a single-plane weight in the folded form multiplies the normalised rows BEFORE gamma
+    z = (x - mean) * rstd
+    lo = wf - wf.half().double()
+    assert float((F.linear(z, lo) - (ref - (rstd * (x @ wf.half().double().t() - mean * wf.half().double().sum(1)) + (b + w @ beta)))).abs().max()) < 1e-11

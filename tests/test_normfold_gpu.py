@@ -209,3 +209,27 @@ def test_fold_forms_refuse_what_the_direct_epilogue_cannot_do(L):
         L.gemm(a, w, out16=o16, nstat_out=torch.empty(512, 4, 2, device="cuda"))       # producer needs out32
     with pytest.raises(RuntimeError):
         L.gemm(a.bfloat16(), w.bfloat16(), out16=o16.bfloat16(), nstat_in=torch.zeros(512, 2, device="cuda"), ncol=torch.zeros(256, device="cuda"))
+
+
+def test_producer_gemm_leaves_plane_pairs_and_saturates(L):
+    """aux16 with nstat_out: [hi | lo] rows of what went to the stream (the LA_F16X2 operand of the SAM neck's 1 x 1 convolution); the
+    16-bit copy saturates at the fp16 range instead of becoming inf."""
+    m, n, k = 1024, 768, 768
+    a = rnd(m, k, seed=51).half()
+    w = (rnd(n, k, seed=52) / math.sqrt(k)).half()
+    res = rnd(m, n, seed=53)
+    res[5, 7] = 3.0e5
+    res[9, 700] = -7.0e4
+    o32 = res.clone()
+    xs = torch.zeros(m, 2 * n, device="cuda", dtype=torch.float16)
+    part = torch.empty(m, n // 64, 2, device="cuda")
+    L.gemm(a, w, res=o32, out32=o32, out16=xs[:, :n], aux16=xs[:, n:], nstat_out=part)
+    torch.cuda.synchronize()
+    ref = res + a.float() @ w.float().t()
+    assert rel_err(o32, ref) < 1e-3
+    clamped = o32.clamp(-65504.0, 65504.0)
+    hi = clamped.half()
+    assert torch.equal(xs[:, :n], hi) and torch.isfinite(xs.float()).all()
+    assert torch.equal(xs[:, n:], (clamped - hi.float()).half())
+    inr = o32.abs() < 6e4
+    assert float(((xs[:, :n].float() + xs[:, n:].float()) - o32)[inr].abs().max()) < 2e-6 * float(o32[inr].abs().max()) + 1e-7
