@@ -139,7 +139,9 @@ int la_conv3x3_f32(const float* in, int B, int H, int W, int Cin, const float* w
 /* The same convolution for Cin == Cout == 32 (the D = 256 mask decoder's spatial convolutions, mask_decoder.py:236-255) in SPLIT precision on the
  * 16-bit MFMA: input pixels and weights enter as fp16 plane pairs (hi = rn16(x), lo = rn16(x - hi)), three products per k-step
  * (A_hi W_hi + A_lo W_hi + A_hi W_lo, ~22 mantissa bits: the accuracy class of LA_F16X2, 1e-6 relative), the 10 x 34 halo of an 8 x 32
- * pixel tile staged once in LDS.  Same arguments and layouts as la_conv3x3_f32; la_conv3x3_split_ok says whether the channel counts are taken. */
+ * pixel tile staged once in LDS.  Same arguments and layouts as la_conv3x3_f32; la_conv3x3_split_ok says whether the channel counts are taken.
+ * For ACTIVATIONS (magnitudes around one): an fp16 plane pair resolves nothing below 6e-8 and saturates at 65504 - gradient maps (1e-8 ...
+ * 1e-5 entries under a mean-reduced objective) keep la_conv3x3_f32. */
 int la_conv3x3_split_ok(int Cin, int Cout);
 int la_conv3x3_split(const float* in, int B, int H, int W, int Cin, const float* wt, const float* bias, int Cout, float* out32, void* stream);
 

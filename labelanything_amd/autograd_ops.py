@@ -357,10 +357,15 @@ def mean_rows(x: Tensor, groups: int, rep: int) -> Tensor:
     return _MeanRows.apply(x, groups, rep)
 
 
-def _conv3x3_raw(x: Tensor, wk: Tensor, b: Optional[Tensor], bsz: int, h: int, wd: int, cin: int, cout: int) -> Tensor:
-    """x [B*H*W, cin], wk [cout, (ky, kx, cin)]: implicit GEMM when cin % 32 == 0, im2col + la_gemm otherwise."""
+def _conv3x3_raw(x: Tensor, wk: Tensor, b: Optional[Tensor], bsz: int, h: int, wd: int, cin: int, cout: int, split: bool = False) -> Tensor:
+    """x [B*H*W, cin], wk [cout, (ky, kx, cin)]: implicit GEMM when cin % 32 == 0, im2col + la_gemm otherwise.  split: the operand is an
+    ACTIVATION (O(1) magnitudes) - 32 -> 32 channels may run as three fp16 products on plane pairs (la_conv3x3_split, 4e-7 of fp64 at 3.5x
+    the rate of the exact-fp32 MFMA).  Gradients never take that path: fp16 planes bottom out at 6e-8, and the mean-reduced focal
+    objective's d loss / d feature entries are 1e-8 ... 1e-5 (measured: 7e-3 ... 2e-2 on the upstream parameter gradients when they did)."""
     y = x.new_empty(x.shape[0], cout)
-    if cin % 32 == 0:
+    if split and L.conv3x3_split_ok(cin, cout) and x.is_contiguous() and wk.is_contiguous():
+        L.conv3x3_split(x, bsz, h, wd, cin, wk, b, cout, y)
+    elif cin % 32 == 0:
         L.conv3x3_f32(x, bsz, h, wd, cin, wk, b, cout, y)
     else:
         col = x.new_empty(x.shape[0], 9 * cin)
@@ -377,7 +382,7 @@ class _Conv3x3(Function):
         x = _c(x)
         cout, cin = w.shape[0], w.shape[1]
         wk = _c(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin))              # [Cout, (ky, kx, cin)]
-        y = _conv3x3_raw(x, wk, b, bsz, h, wd, cin, cout)
+        y = _conv3x3_raw(x, wk, b, bsz, h, wd, cin, cout, split=True)
         ctx.save_for_backward(x, w)
         ctx.dims = (bsz, h, wd, b is not None)
         return y

@@ -393,12 +393,14 @@ __global__ __launch_bounds__(256) void norm_finalize_kernel(const float* __restr
     const size_t row = base + r0 + tid;
     float2 v;
     if (part != nullptr) {
-      const float2* pp = reinterpret_cast<const float2*>(part) + row * nslots;
+      // (slot pairs as float4: nslots = E / 64 is even for every E the producer epilogue takes - N % 256 == 0; slots still added in index order)
+      const float4* pp = reinterpret_cast<const float4*>(part) + row * (nslots >> 1);
       float s1 = 0.f, s2 = 0.f;
-      for (int j = 0; j < nslots; ++j) {
-        const float2 t = pp[j];
-        s1 += t.x;
-        s2 += t.y;
+#pragma unroll 4
+      for (int j = 0; j < (nslots >> 1); ++j) {
+        const float4 t = pp[j];
+        s1 = (s1 + t.x) + t.z;
+        s2 = (s2 + t.y) + t.w;
       }
       const float mean = s1 / (float)E;
       const float var = fmaxf(s2 / (float)E - mean * mean, 0.f);
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
 
 extern "C" int la_norm_finalize(const float* part, int M, int nslots, int E, float eps, float* mr, const void* x16, int ld16, int rows_per_group,
                                 float* cs_part, int dt, void* stream) {
-  LA_CHECK_ARG(mr && M > 0 && E > 0 && (E % 8) == 0 && E <= 2048 && (part == nullptr || nslots > 0), "la_norm_finalize: bad arguments (E %% 8, E <= 2048)");
+  LA_CHECK_ARG(mr && M > 0 && E > 0 && (E % 8) == 0 && E <= 2048 && (part == nullptr || (nslots > 0 && (nslots % 2) == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0)),
+               "la_norm_finalize: bad arguments (E %% 8, E <= 2048, an even number of 16-byte aligned slots)");
   LA_CHECK_ARG(part != nullptr || cs_part != nullptr, "la_norm_finalize: nothing to do (no partial sums and no column sums)");
   LA_CHECK_ARG(cs_part == nullptr || (x16 && rows_per_group > 0 && (M % rows_per_group) == 0 && (ld16 % 8) == 0 && (dt == LA_F16 || dt == LA_BF16)),
                "la_norm_finalize: column sums need x16 (16-bit, ld %% 8) and M %% rows_per_group == 0");
