@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include "la_common.h"
 #ifndef LA_ATTN_ABL
+#ifndef LA_ATTN_DMA_RUN
+#define LA_ATTN_DMA_RUN 1   // K / V tile sources as running 32-bit offsets (0: the per-tile clamp + multiply-add form, tools/attn_ab.sh A/B)
+#endif
 #define LA_ATTN_ABL 0       // measurement ablations of attn_fwd_kernel (results wrong): 1 no exp, 2 no S MFMAs, 4 no PV MFMAs, 8 no staging / barrier
 #endif
 #ifndef LA_ATTN_X
@@ -230,6 +233,18 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     vsrc[i] = VROW ? qkv + (size_t)b * T_ * E3 + voff[i] : vt + ((size_t)bh * HDT + row) * a.Tpad + chunk * 8;
   }
   const unsigned lds0 = lds_addr_of(smem);
+  // plain / global modes: the lane's K (and V) chunk of tile j is 64 rows behind tile j - 1's - RUNNING pointers (one 64-bit add per piece
+  // and tile) instead of clamp + 64-bit multiply-add per piece (22 -> 8 vector instructions per tile beside ~150 of softmax; dma() is
+  // called for j = 0, 1, 2, ... in order).  Only a tile that reaches beyond the last row takes the clamped form.
+  // (as 32-bit byte offsets from the image's q | k | v block, a wave-uniform base: dma16s - one address register per piece)
+  const T* img_base = qkv + (size_t)b * T_ * E3;
+  unsigned krun[2], vrun[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    krun[i] = (unsigned)(((size_t)krow[i] * E3 + koff[i]) * sizeof(T));
+    vrun[i] = (unsigned)(((size_t)krow[i] * E3 + voff[i]) * sizeof(T));
+  }
+  const unsigned tile_step = (unsigned)((size_t)64 * E3 * sizeof(T));
   auto dma = [&](int j, int stage) {
     const unsigned sk = lds0 + stage * KVS;
     const unsigned sv = sk + NH * SUB;
@@ -238,7 +253,27 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
       int key = 0;
       const T* kp = nullptr;
       const T* vp = nullptr;
-      if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
+      if (MODE != 5 && !LA_ATTN_DMA_RUN) {      // (A/B build: clamp + 64-bit multiply-add per piece, the form before round 6)
+        key = min(j * 64 + krow[i], T_ - 1);
+        kp = ksrc[i] + (size_t)key * E3;
+        if (VROW) vp = vsrc[i] + (size_t)key * E3;
+      } else if (MODE != 5) {
+        unsigned ko = krun[i], vo = vrun[i];
+        if (j * 64 + 64 > T_) {          // (wave-uniform: the last, ragged tile) rows beyond T - 1 re-read row T - 1, masked later
+          const unsigned back = (unsigned)max(j * 64 + krow[i] - (T_ - 1), 0) * (unsigned)(E3 * sizeof(T));
+          ko -= back;
+          vo -= back;
+        }
+        krun[i] += tile_step;
+        vrun[i] += tile_step;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+          dma16s(img_base, ko + hh * 128, sk + hh * SUB + (i * 4 + wave) * 1024);
+          if (VROW) dma16s(img_base, vo + hh * 128, sv + hh * SUB + (i * 4 + wave) * 1024);
+          else dma16(vsrc[i] + (size_t)hh * 64 * a.Tpad + j * 64, sv + hh * SUB + (i * 4 + wave) * 1024);
+        }
+        continue;
+      } else if (MODE == 5) {   // slot -> token of the ws x ws window (padded slots read a clamped, later masked, row)
         const int slot = j * 64 + krow[i];
         const int ty = min(slot >> 4, a.G - 1), tx = min(slot & 15, a.G - 1);
         key = ty * a.G + tx;
@@ -248,10 +283,8 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
           kp = rp + koff[i];
           vp = rp + voff[i];
         }
-      } else {
-        key = min(j * 64 + krow[i], T_ - 1);
       }
-      if (!img_order) {
+      if (MODE == 5 && !img_order) {
         kp = ksrc[i] + (size_t)key * E3;
         if (VROW) vp = vsrc[i] + (size_t)key * E3;
       }
