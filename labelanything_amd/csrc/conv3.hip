@@ -142,8 +142,11 @@ extern "C" int la_conv3x3_split(const float* in, int B, int H, int W, int Cin, c
   LA_CHECK_ARG(tiles < (1l << 31), "la_conv3x3_split: too many tiles");
   static unsigned long long attr_mask = 0;
   la::ensure_dyn_lds(reinterpret_cast<const void*>(la::conv3x3_split_kernel), la::C3_LDS, attr_mask);
-  int dev = 0, ncu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  static int ncu_of[64] = {0};                        // per device: a process may drive several GPUs
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& ncu = ncu_of[dev & 63];
+  if (ncu == 0 && (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)) ncu = 256;
   const long grid = tiles < 2l * ncu ? tiles : 2l * ncu;      // persistent: two workgroups per CU walk the tiles (weights stay in registers)
   hipLaunchKernelGGL(la::conv3x3_split_kernel, dim3((unsigned)grid), dim3(256), la::C3_LDS, reinterpret_cast<hipStream_t>(stream), in, B, H, W, wt,
                      bias, out32, (int)tiles);

@@ -631,7 +631,8 @@ class LamEngine:
         ea = heads * hdp                # width of the q / k / v / attention-output blocks (== e unless the heads are padded)
         w, p = self.w32, self.p
         images = images.contiguous()
-        if self.norm_fold and self.attn_rows and ws <= 16 and (g == 64 or not spec.global_idx):
+        # (the producer epilogue adds the per-image correction to groups of whole row tiles or of >= 128 rows: smaller grids keep the kernels)
+        if self.norm_fold and self.attn_rows and ws <= 16 and (g == 64 or not spec.global_idx) and (hw % 256 == 0 or hw >= 128):
             return self._sam_encoder_fold(images, want_last_block)
         a, akw = self.patches("enc.patchA", images, rows, spec.patch)
         res = self.f32("enc.res", (rows, e))
@@ -924,7 +925,7 @@ class LamEngine:
         qkv = self.buf("hf.qkv", (rows, 3 * ea))
         fp8 = self.attn_fp8 and hdp == 64          # (the fp8 QK^T kernel keeps its V^T operand)
         rows_path = self.attn_rows and not fp8     # no V^T copy: la_attn_fwd_rows
-        if self.norm_fold and rows_path:
+        if self.norm_fold and rows_path and t >= 128:       # (per-image groups of the producer epilogue: >= 128 rows)
             return self._hf_fold_blocks(res, bn, t, hw, e, heads, hdp, ea, spec, qkv)
         vt = None if rows_path else self.buf("hf.vt", (bn * heads, hdp, tpad), zero=True)
         ao = self.buf("hf.ao", (rows, ea))

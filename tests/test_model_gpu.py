@@ -517,3 +517,22 @@ def test_folded_layernorm_block_stack_against_the_layernorm_kernels(name):
     e_fold, e_plain, e_between = rel_err(outs[0], ref_logits), rel_err(outs[1], ref_logits), rel_err(outs[0], outs[1])
     print(f"[norm_fold {name}] logits vs reference: folded {e_fold:.3e}, LayerNorm kernels {e_plain:.3e}; folded vs LayerNorm kernels {e_between:.3e}")
     assert e_fold <= 1e-3 and e_plain <= 1e-3 and 0 < e_between <= 2e-3
+
+
+@pytest.mark.parametrize("size,folded", [(224, True), (96, False)])
+def test_wide_hf_encoder_fold_dispatch_by_grid_size(size, folded):
+    """A ViT-B-wide HF stack (two layers) at 224 px (197 tokens per image: the folded form with per-image groups that end inside row tiles,
+    three images in one launch) and at 96 px (37 tokens: below the 128 rows a group of the producer epilogue needs - the engine keeps the
+    LayerNorm kernels instead of failing): both against the oracle."""
+    from labelanything_amd.config import EncoderSpec, LamConfig, register_encoder
+    register_encoder("hf_wide2", EncoderSpec("hf", dim=768, depth=2, heads=12, mlp=3072, img_size=224))
+    cfg = LamConfig(encoder="hf_wide2", image_size=size, image_embed_dim=768, embed_dim=64, spatial_convs=3, custom_preprocess=False)
+    calls = []
+    from labelanything_amd import _lib as L
+    orig = L.norm_finalize
+    L.norm_finalize = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        assert _encoder_vs_oracle(cfg, 3, 31) <= 1e-3
+    finally:
+        L.norm_finalize = orig
+    assert bool(calls) == folded
