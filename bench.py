@@ -415,6 +415,24 @@ def main():
                                   "vendor GEMM without any epilogue reaches 1.54 PFLOP/s = 0.61 on the same 8192^3 product, la_gemm 1.32"),
                     # split-precision weights ([W_hi | W_lo]) issue two MFMA passes for one algorithmic product
                     "mfma_issued_tflops": round(g[4] / g[1] / 1e12, 1)}
+            # round 6: with LamEngine.norm_fold the encoder's LayerNorm passes live in these launches' epilogues (16-bit copy of the stream,
+            # row sums, normalisation of the product) - the same MFMA work over a longer time.  A second instrumented step with the
+            # LayerNorm kernels puts the two accountings side by side on this box (outside the timed region, like the first)
+            if not train and getattr(lam._engine, "norm_fold", False):
+                lam.norm_fold = False
+                lam(batch)                                   # (the other launch sequence once untimed: arena buffers, packed weights in cache)
+                with KernelTimer() as kt3:
+                    lam(batch)
+                lam.norm_fold = True
+                lam.engine()                                 # (re-syncs the engine's switch: the line below reports the timed configuration)
+                a3 = kt3.summary()
+                g3 = a3.get("gemm")
+                ln_ms = lambda ag: round(sum(v[1] for n, v in ag.items() if n in ("layernorm_g", "norm_finalize", "norm_stats", "add_rowvec", "add_rowvec_split")) * 1e3, 3)
+                roof["norm_fold"] = {
+                    "note": "these launches also carry the encoder's LayerNorm since round 6 (LamEngine.norm_fold): same MFMA work, longer epilogues, no LayerNorm pass",
+                    "folded": {"la_gemm_ms": round(g[1] * 1e3, 3), "layernorm_side_ms": ln_ms(agg), "kernel_ms_per_step": round(tot * 1e3, 3)},
+                    "layernorm_kernels": {"la_gemm_ms": round(g3[1] * 1e3, 3), "layernorm_side_ms": ln_ms(a3), "kernel_ms_per_step": round(sum(v[1] for v in a3.values()) * 1e3, 3),
+                                          "la_gemm_tflops": round(g3[2] / g3[1] / 1e12, 1), "la_gemm_frac": round(g3[2] / g3[1] / 1e12 / PEAK_MFMA_TFLOPS, 4)}}
 
         top = max(agg.items(), key=lambda kv: kv[1][1])
         if top[0].startswith("twoway_") and (not g or top[1][1] > g[1]):
