@@ -108,7 +108,9 @@ typedef struct LaGemmEpilogue {
    *   la_norm_finalize turns the N / 64 partials of a row into (mean, rstd).  out16 saturates at the fp16 range (it is an MFMA operand; an
    *   un-normalised stream has no range guarantee).  aux16 != NULL (producer only): the lo plane rn16(x - out16) of the same rows - with
    *   out16 / aux16 pointing at the two halves of [rows, 2 N] rows the stream leaves the block stack as an LA_F16X2 operand (the SAM neck's
-   *   1 x 1 convolution) without a pass of its own.
+   *   1 x 1 convolution) without a pass of its own.  With out32 == NULL and res == NULL the STREAM ITSELF is that pair of planes, updated in
+   *   place: out16 / aux16 are read as the residual (hi + lo, ~22 mantissa bits per value: 25 read-modify-writes cost 1e-6) and written
+   *   back - same bytes per row as the fp32 read-modify-write, and the hi plane is the next GEMM's operand at no extra bytes.
    * CONSUMER (the GEMM behind the LayerNorm; out16 only, act NONE or GELU): nstat_in != NULL - A is the UN-normalised 16-bit stream, W the
    *   16-bit rounding of W diag(gamma), and the epilogue applies the normalisation to the product:
    *     out = act( rstd[row] * (acc - mean[row] * ncol[col]) + bias[col] ),   ncol[col] = sum_k W16[col][k],  bias = b + W beta

@@ -2179,6 +2179,15 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                    "la_gemm: nstat_in writes out16 only (act NONE / GELU), needs ncol, one weight plane");
       if (epi->act == LA_ACT_GELU) la::launch_t256w_fused<la::f16_t, 9>(A, lda, W, ldw, M, N, K, *epi, gm, st);
       else la::launch_t256w_fused<la::f16_t, 8>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    } else if (epi->nstat_out && !epi->out32 && !epi->res) {
+      // the stream as fp16 plane pairs, read-modify-written in place: out16 = hi plane, aux16 = lo plane (see LaGemmEpilogue.nstat_out)
+      LA_CHECK_ARG(epi->out16 && epi->aux16 && epi->act == LA_ACT_NONE && (epi->ld16 % 8) == 0 && (epi->ldaux % 8) == 0 && epi->ld16 >= N &&
+                       epi->ldaux >= N && al16(epi->out16) && al16(epi->aux16) && (reinterpret_cast<uintptr_t>(epi->nstat_out) & 7) == 0 && epi->res_mod == 0,
+                   "la_gemm: nstat_out without out32 / res updates a plane-pair stream in place: out16 (hi) and aux16 (lo), 16-byte aligned rows");
+      LA_CHECK_ARG(!epi->rvec || (epi->rvec_rpg > 0 && al16(epi->rvec) && ((epi->rvec_rpg % 256) == 0 || epi->rvec_rpg >= 128)),
+                   "la_gemm: rvec needs a 16-byte aligned vector and groups of whole 256-row tiles or of at least 128 rows (rvec_rpg=%d)", epi->rvec_rpg);
+      if (epi->rvec && (epi->rvec_rpg % 256) != 0) la::launch_t256w_fused<la::f16_t, 12>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+      else la::launch_t256w_fused<la::f16_t, 11>(A, lda, W, ldw, M, N, K, *epi, gm, st);
     } else {
       LA_CHECK_ARG(epi->nstat_out && epi->out32 && epi->out16 && epi->act == LA_ACT_NONE && (epi->ld16 % 8) == 0 && epi->ld16 >= N &&
                        (epi->ld32 % 4) == 0 && epi->ld32 >= N && al16(epi->out16) && al16(epi->out32) && (!epi->res || (epi->ldr % 4) == 0) &&

@@ -127,12 +127,17 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   // round, + the per-group vector rvec (7: every row of the tile in one group - the vector joins the bias; 10: groups of >= 128 rows that
   // do not end on tile edges - the wave's 128 rows lie in at most two groups: two bias sets, selected per row).
   // EPI 8 / 9: EPI 1 / 2 as the CONSUMER side (nstat_in): the normalisation applied to the product.
-  constexpr bool PROD = EPI == 7 || EPI == 10;
+  // EPI 11 / 12: EPI 7 / 10 on a stream that is itself a pair of fp16 planes [hi | lo] (out16 / aux16, same bytes as fp32): the residual
+  // is read from the two planes IN PLACE and written back as planes - the hi plane IS the next GEMM's operand, so the 16-bit copy costs no
+  // extra bytes (a producer epilogue is bound by HBM round trips: + 2 E bytes per row were + 20 % on proj, + 8 % on lin2).
+  constexpr bool RESP = EPI == 11 || EPI == 12;
+  constexpr bool TWOG = EPI == 10 || EPI == 12;
+  constexpr bool PROD = EPI == 7 || EPI == 10 || RESP;
   constexpr bool RES = EPI == 3 || PROD;
   constexpr bool NORM = EPI == 8 || EPI == 9;
   constexpr bool GELU = EPI == 2 || EPI == 5 || EPI == 9;
   float bias[2][8];
-  float biasB[2][8];      // (EPI 10 only)
+  float biasB[2][8];      // (two-group forms only)
   float ncol[2][8];
 #pragma unroll
   for (int jp = 0; jp < 2; ++jp) {
@@ -141,7 +146,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     const float4 b1 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col0 + jp * 64 + cg * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     bias[jp][0] = b0.x; bias[jp][1] = b0.y; bias[jp][2] = b0.z; bias[jp][3] = b0.w;
     bias[jp][4] = b1.x; bias[jp][5] = b1.y; bias[jp][6] = b1.z; bias[jp][7] = b1.w;
-    if (EPI == 10) {      // a second copy for the rows of the NEXT group (selected per row: a group's rows never see another group's vector)
+    if (TWOG) {      // a second copy for the rows of the NEXT group (selected per row: a group's rows never see another group's vector)
 #pragma unroll
       for (int t = 0; t < 8; ++t) biasB[jp][t] = bias[jp][t];
       const int gB = min(row0 / e.rvec_rpg + 1, (M - 1) / e.rvec_rpg);
@@ -179,7 +184,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
     ldmr(0);
     ldmr(1);
   }
-  const int rowB = EPI == 10 ? (row0 / e.rvec_rpg + 1) * e.rvec_rpg : 0;      // first row of the next group
+  const int rowB = TWOG ? (row0 / e.rvec_rpg + 1) * e.rvec_rpg : 0;      // first row of the next group
   const int nslots = N >> 6;      // PROD: one partial per row and 64-column round (nothing carried from round to round: registers)
   T* out16 = reinterpret_cast<T*>(e.out16);
   auto wr = [&](auto ic, auto jpc) {
@@ -205,6 +210,15 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
   const int rrow0 = e.res_mod > 0 ? row0 % e.res_mod : row0;
   auto ldres = [&](int i, int jp, float4 (&res)[4][2]) {
     const int row = rrow0 + i * 32 + rq * 4, col = col0 + jp * 64 + cg * 8;
+    if constexpr (RESP) {      // res[s][0] = the 8 hi halves, res[s][1] = the 8 lo halves of the row segment (16 bytes each, as raw bits)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const bool ok = row0 + i * 32 + rq * 4 + s_ < M;
+        res[s_][0] = ok ? *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(e.out16) + (size_t)(row + s_) * e.ld16 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        res[s_][1] = ok ? *reinterpret_cast<const float4*>(reinterpret_cast<const T*>(e.aux16) + (size_t)(row + s_) * e.ldaux + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
@@ -229,7 +243,23 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
         float4 o0, o1;
-        if (EPI == 10) {
+        if constexpr (RESP) {
+          // (words unpacked with bit operations: a pointer into the register array would send it to scratch memory)
+          const uint32_t hw_[4] = {__builtin_bit_cast(uint32_t, res[s_][0].x), __builtin_bit_cast(uint32_t, res[s_][0].y),
+                                   __builtin_bit_cast(uint32_t, res[s_][0].z), __builtin_bit_cast(uint32_t, res[s_][0].w)};
+          const uint32_t lw_[4] = {__builtin_bit_cast(uint32_t, res[s_][1].x), __builtin_bit_cast(uint32_t, res[s_][1].y),
+                                   __builtin_bit_cast(uint32_t, res[s_][1].z), __builtin_bit_cast(uint32_t, res[s_][1].w)};
+          const bool nb = TWOG && row + s_ >= rowB;
+          float c[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float hv = (t & 1) ? unpack_hi<T>(hw_[t >> 1]) : unpack_lo<T>(hw_[t >> 1]);
+            const float lv = (t & 1) ? unpack_hi<T>(lw_[t >> 1]) : unpack_lo<T>(lw_[t >> 1]);
+            c[t] = r[t][s_] + (nb ? biasB[jp][t] : bias[jp][t]) + (hv + lv);
+          }
+          o0 = make_float4(c[0], c[1], c[2], c[3]);
+          o1 = make_float4(c[4], c[5], c[6], c[7]);
+        } else if (EPI == 10) {
           const bool nb = row + s_ >= rowB;
           o0.x = r[0][s_] + (nb ? biasB[jp][0] : bias[jp][0]) + res[s_][0].x; o0.y = r[1][s_] + (nb ? biasB[jp][1] : bias[jp][1]) + res[s_][0].y;
           o0.z = r[2][s_] + (nb ? biasB[jp][2] : bias[jp][2]) + res[s_][0].z; o0.w = r[3][s_] + (nb ? biasB[jp][3] : bias[jp][3]) + res[s_][0].w;
@@ -250,9 +280,11 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
           if (cg == 0 && row + s_ < M) *reinterpret_cast<float2*>(e.nstat_out + ((size_t)(row + s_) * nslots + (col >> 6)) * 2) = make_float2(a, b);
         }
         if (row + s_ >= M) continue;
-        float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
-        *reinterpret_cast<float4*>(op) = o0;
-        *reinterpret_cast<float4*>(op + 4) = o1;
+        if constexpr (!RESP) {
+          float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
+          *reinterpret_cast<float4*>(op) = o0;
+          *reinterpret_cast<float4*>(op + 4) = o1;
+        }
         if (PROD) {
           // the 16-bit copy is an MFMA operand of the next GEMM: it SATURATES at the fp16 range instead of turning into inf (an un-normalised
           // stream has no range guarantee; SAM checkpoints stay three orders of magnitude below).  aux16 (optional): the lo plane
@@ -265,10 +297,9 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
           pk.x = pack2<T>(c[0], c[1]); pk.y = pack2<T>(c[2], c[3]); pk.z = pack2<T>(c[4], c[5]); pk.w = pack2<T>(c[6], c[7]);
           *reinterpret_cast<uint4*>(out16 + (size_t)(row + s_) * e.ld16 + col) = pk;
           if (aux16) {
-            const T* h = reinterpret_cast<const T*>(&pk);
             uint4 lo;
-            lo.x = pack2<T>(c[0] - (float)h[0], c[1] - (float)h[1]); lo.y = pack2<T>(c[2] - (float)h[2], c[3] - (float)h[3]);
-            lo.z = pack2<T>(c[4] - (float)h[4], c[5] - (float)h[5]); lo.w = pack2<T>(c[6] - (float)h[6], c[7] - (float)h[7]);
+            lo.x = pack2<T>(c[0] - unpack_lo<T>(pk.x), c[1] - unpack_hi<T>(pk.x)); lo.y = pack2<T>(c[2] - unpack_lo<T>(pk.y), c[3] - unpack_hi<T>(pk.y));
+            lo.z = pack2<T>(c[4] - unpack_lo<T>(pk.z), c[5] - unpack_hi<T>(pk.z)); lo.w = pack2<T>(c[6] - unpack_lo<T>(pk.w), c[7] - unpack_hi<T>(pk.w));
             *reinterpret_cast<uint4*>(aux16 + (size_t)(row + s_) * e.ldaux + col) = lo;
           }
         } else if (out16) {
@@ -462,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void gemm_t256w_kernel(const T* __restrict_
                                                              int K, LaGemmEpilogue e, int gm, int stg) {
   constexpr int BK_ = 64;
   constexpr unsigned REG = 32768;                     // one operand of one k-tile
-  constexpr int SEAM = (EPI == 3 || EPI == 5 || EPI == 7 || EPI == 10) ? 47 : 32;      // epilogue stores per wave that the first two waits of a tile may leave outstanding
+  constexpr int SEAM = (EPI == 3 || EPI == 5 || EPI == 7 || EPI >= 10) ? 47 : 32;      // epilogue stores per wave that the first two waits of a tile may leave outstanding
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef LA_DEBUG
@@ -762,6 +793,8 @@ template void launch_t256w_fused<f16_t, 7>(const void*, int, const void*, int, i
 template void launch_t256w_fused<f16_t, 10>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 template void launch_t256w_fused<f16_t, 8>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 template void launch_t256w_fused<f16_t, 9>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 11>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
+template void launch_t256w_fused<f16_t, 12>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);
 
 #define LA_W4_INST(T, EPI) \
   template void launch_t256w<T, EPI>(const void*, int, const void*, int, int, int, int, const LaGemmEpilogue&, int, hipStream_t);

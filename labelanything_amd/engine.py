@@ -795,10 +795,21 @@ class LamEngine:
         L.gemm(bar, wm, out32=dr)
         return dr
 
+    def _planes_to_f32(self, xs: Tensor, name: str) -> Tensor:
+        """hi + lo of a plane-pair stream as an fp32 matrix (the callers that leave the folded path: final LayerNorm, un-split necks)."""
+        e = xs.shape[1] // 2
+        out = self.f32(name, (xs.shape[0], e))
+        out.copy_(xs[:, :e])
+        out.add_(xs[:, e:])
+        return out
+
     def _sam_encoder_fold(self, images: Tensor, want_last_block: bool = False):
         """sam_encoder without LayerNorm passes (image_encoder.py:110-131,179-197): every residual GEMM is the PRODUCER of the next
-        LayerNorm's input (fp32 stream + 16-bit copy + partial row sums), q | k | v and lin1 are its CONSUMERS (gamma-folded weights,
-        normalisation in the epilogue); the token-mean correction of a block joins the stream in the proj epilogue."""
+        LayerNorm's input, q | k | v and lin1 are its CONSUMERS (gamma-folded weights, normalisation in the epilogue); the token-mean
+        correction of a block joins the stream in the proj epilogue.  The residual stream itself is a pair of fp16 planes [hi | lo]
+        (same bytes as fp32, ~22 mantissa bits): the producers read-modify-write it in place and the hi plane IS the consumers' operand -
+        no separate 16-bit copy (a producer epilogue is bound by HBM round trips: the copy's 2 E bytes per row were + 20 % on proj,
+        + 8 % on lin2) - and the neck's 1 x 1 convolution takes the pair as it stands."""
         spec: EncoderSpec = self.cfg.encoder_spec
         pre = "image_encoder"
         bn, _, s, _ = images.shape
@@ -810,21 +821,21 @@ class LamEngine:
         ea = heads * hdp
         w, p = self.w32, self.p
         a, akw = self.patches("enc.patchA", images, rows, spec.patch)
-        res = self.f32("enc.res", (rows, e))
-        x16 = self.buf("enc.x16", (rows, e))
+        xs = self.buf("enc.xs", (rows, 2 * e), torch.float16)          # the stream: [hi | lo]
+        hi, lo = xs[:, :e], xs[:, e:]
         part, mr = self._fold_bufs("enc", rows, e)
         have_mr = False
+        res32 = self.f32("enc.res", (rows, e))                          # (the patch embedding's fp32 output; not touched by the blocks)
         if hw % 256 == 0:
-            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, out16=x16,
-                   nstat_out=part, **akw)
-        else:       # (a position table that is not whole row tiles: the stream's statistics from a pass of their own, once)
-            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res, **akw)
-            L.norm_stats(res, 1e-6, x16, mr)
+            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res32, out16=hi,
+                   aux16=lo, nstat_out=part, **akw)
+        else:       # (a position table that is not whole row tiles: planes and statistics from a pass each, once)
+            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res32, **akw)
+            L.add_rowvec_split(res32, None, hw, xs)
+            L.norm_stats(res32, 1e-6, self.buf("enc.x16", (rows, e)), mr)
             have_mr = True
         nwy = (g + ws - 1) // ws
         vm, pm = "vmean" in self.precise, "projmean" in self.precise
-        split_neck = self.cfg.use_vit_sam_neck and (pre + ".neck.0.ws") in p
-        xs = None
         for i in range(spec.depth):
             bp = f"{pre}.blocks.{i}"
             is_global = i in spec.global_idx
@@ -832,10 +843,10 @@ class LamEngine:
             xpart = self.f32("mean.xpart", (bn * L.ln_cs_chunks(hw) * e,)) if vm else None
             opart = self.f32("mean.opart", (bn * max(o_chunks, _ceil(hw, 128) // 128) * ea,)) if pm else None
             if vm or not have_mr:
-                L.norm_finalize(None if have_mr else part, rows, e, 1e-6, mr, x16=x16 if vm else None, rpg=hw, cs_part=xpart)
+                L.norm_finalize(None if have_mr else part, rows, e, 1e-6, mr, x16=hi if vm else None, rpg=hw, cs_part=xpart)
             have_mr = False
             qkv = self.buf("enc.qkv.r", (rows, 3 * ea))
-            L.gemm(x16, p[bp + ".qkv.wn"], bias=p[bp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[bp + ".qkv.cn"])
+            L.gemm(hi, p[bp + ".qkv.wn"], bias=p[bp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[bp + ".qkv.cn"])
             ao = self.buf("enc.ao.r", (rows, ea))
             fused_o = opart is not None and is_global
             if is_global:
@@ -845,24 +856,22 @@ class LamEngine:
                 L.attn_fwd_rows(qkv, ao, bn * nwy * nwy, heads, ws * ws, _ceil(16 * ws, 64), ws, ea, scale, L.ATTN_RELPOS_WIN16,
                                 tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"], img_hw=(g, g), padrow=p[bp + ".qkv.pad16"])
             dr = self._fold_mean(bp, xpart, opart, bn, hw, o_chunks if fused_o else 0, e, ea, ao)
-            L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], res=res, out32=res, out16=x16, nstat_out=part, rvec=dr,
+            L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], out16=hi, aux16=lo, nstat_out=part, rvec=dr,
                    rvec_rpg=hw if dr is not None else 0, a_kmod=self.kmod.get(bp + ".proj.w", 0))
             L.norm_finalize(part, rows, e, 1e-6, mr)
             hbuf = self.buf("enc.mlp", (rows, spec.mlp))
-            L.gemm(x16, p[bp + ".lin1.wn"], bias=p[bp + ".lin1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[bp + ".lin1.cn"])
-            if i == spec.depth - 1 and split_neck:
-                # the stream leaves the stack as fp16 plane pairs [hi | lo] - the operand of the neck's 1 x 1 convolution (three fp16
-                # products) - straight from the last residual epilogue (LaGemmEpilogue.aux16 = the lo plane): no la_add_rowvec_split pass
-                xs = self.buf("enc.res_split", (rows, 2 * e), torch.float16)
-                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=xs[:, :e], aux16=xs[:, e:], nstat_out=part,
-                       a_kmod=self.kmod.get(bp + ".lin2.w", 0))
-            else:
-                L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], res=res, out32=res, out16=x16, nstat_out=part,
-                       a_kmod=self.kmod.get(bp + ".lin2.w", 0))
-        last16 = x16               # (the last lin2 launch left the 16-bit rounding of the finished stream - unless it wrote the plane pairs)
+            L.gemm(hi, p[bp + ".lin1.wn"], bias=p[bp + ".lin1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[bp + ".lin1.cn"])
+            L.gemm(hbuf, p[bp + ".lin2.w"], bias=w[bp + ".mlp.lin2.bias"], out16=hi, aux16=lo, nstat_out=part,
+                   a_kmod=self.kmod.get(bp + ".lin2.w", 0))
+        split_neck = self.cfg.use_vit_sam_neck and (pre + ".neck.0.ws") in p
+        res = None
+        if want_last_block or not split_neck:
+            res = self._planes_to_f32(xs, "enc.res")
         if not self.cfg.use_vit_sam_neck:
+            last16 = self.buf("enc.last16", (rows, e))
+            last16.copy_(hi)
             return (res, last16, e) if not want_last_block else ((res, last16, e), res)
-        out = self.conv_neck(pre + ".neck", last16, bn, g, "enc.neck", x32=res, xs=xs)
+        out = self.conv_neck(pre + ".neck", hi, bn, g, "enc.neck", x32=res, xs=xs if split_neck else None)
         if want_last_block:
             return (out, None, spec.out_chans), res
         return out, None, spec.out_chans
@@ -976,14 +985,16 @@ class LamEngine:
 
     def _hf_fold_blocks(self, res: Tensor, bn: int, t: int, hw: int, e: int, heads: int, hdp: int, ea: int, spec, qkv: Tensor):
         """The HF block stack without LayerNorm passes (transformers ViTLayer: layernorm_before / layernorm_after folded into the q | k | v
-        and fc1 GEMMs; eps 1e-12): see _sam_encoder_fold.  The stream enters through a row map (CLS gap), so the first statistics come
-        from one pass over it (la_norm_stats); the final ``layernorm`` is the LayerNorm kernel."""
+        and fc1 GEMMs; eps 1e-12) on a plane-pair stream: see _sam_encoder_fold.  The stream enters through a row map (CLS gap), so its
+        planes and first statistics come from one pass each; the final ``layernorm`` is the LayerNorm kernel on hi + lo."""
         pre = "image_encoder"
         rows = bn * t
         w, p = self.w32, self.p
-        x16 = self.buf("hf.x16", (rows, e))
+        xs = self.buf("hf.xs", (rows, 2 * e), torch.float16)
+        hi, lo = xs[:, :e], xs[:, e:]
         part, mr = self._fold_bufs("hf", rows, e)
-        L.norm_stats(res, 1e-12, x16, mr)
+        L.add_rowvec_split(res, None, t, xs)
+        L.norm_stats(res, 1e-12, self.buf("hf.x16", (rows, e)), mr)
         have_mr = True
         ao = self.buf("hf.ao", (rows, ea))
         hbuf = self.buf("hf.mlp", (rows, spec.mlp))
@@ -996,17 +1007,18 @@ class LamEngine:
         for i in range(spec.depth):
             lp = f"{pre}.encoder.layer.{i}"
             if vm or not have_mr:
-                L.norm_finalize(None if have_mr else part, rows, e, 1e-12, mr, x16=x16 if vm else None, rpg=t, cs_part=xpart)
+                L.norm_finalize(None if have_mr else part, rows, e, 1e-12, mr, x16=hi if vm else None, rpg=t, cs_part=xpart)
             have_mr = False
-            L.gemm(x16, p[lp + ".qkv.wn"], bias=p[lp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[lp + ".qkv.cn"])
+            L.gemm(hi, p[lp + ".qkv.wn"], bias=p[lp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[lp + ".qkv.cn"])
             L.attn_fwd_rows(qkv, ao, bn, heads, t, tpad, 0, ea, scale, L.ATTN_PLAIN, cspart=opart)
             dr = self._fold_mean(lp, xpart, opart, bn, t, o_chunks, e, ea, ao)
-            L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], res=res, out32=res, out16=x16, nstat_out=part, rvec=dr,
+            L.gemm(ao, p[lp + ".o.w"], bias=w[lp + ".attention.output.dense.bias"], out16=hi, aux16=lo, nstat_out=part, rvec=dr,
                    rvec_rpg=t if dr is not None else 0, a_kmod=self.kmod.get(lp + ".o.w", 0))
             L.norm_finalize(part, rows, e, 1e-12, mr)
-            L.gemm(x16, p[lp + ".fc1.wn"], bias=p[lp + ".fc1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[lp + ".fc1.cn"])
-            L.gemm(hbuf, p[lp + ".fc2.w"], bias=w[lp + ".output.dense.bias"], res=res, out32=res, out16=x16, nstat_out=part,
+            L.gemm(hi, p[lp + ".fc1.wn"], bias=p[lp + ".fc1.bn"], out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=p[lp + ".fc1.cn"])
+            L.gemm(hbuf, p[lp + ".fc2.w"], bias=w[lp + ".output.dense.bias"], out16=hi, aux16=lo, nstat_out=part,
                    a_kmod=self.kmod.get(lp + ".fc2.w", 0))
+        res = self._planes_to_f32(xs, "hf.res")
         fin = self.f32("hf.final", (rows, e))
         fin16 = self.buf("hf.final16", (rows, e))
         self.ln(res, pre + ".layernorm", 1e-12, out32=fin, out16=fin16)

@@ -233,3 +233,40 @@ def test_producer_gemm_leaves_plane_pairs_and_saturates(L):
     assert torch.equal(xs[:, n:], (clamped - hi.float()).half())
     inr = o32.abs() < 6e4
     assert float(((xs[:, :n].float() + xs[:, n:].float()) - o32)[inr].abs().max()) < 2e-6 * float(o32[inr].abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("shape", [(8192, 768, 768, 4096), (2 * 4096, 768, 3072, 4096), (3 * 901, 768, 768, 901), (640, 256, 128, 128)])
+def test_producer_gemm_on_a_plane_pair_stream_in_place(L, shape):
+    """out32 / res absent: the stream is [hi | lo] fp16 planes (out16 / aux16), read as the residual and written back in place; the
+    hi plane is the next GEMM's operand.  Against fp32 arithmetic on hi + lo."""
+    m, n, k, rpg = shape
+    a = rnd(m, k, seed=71).half()
+    w = (rnd(n, k, seed=72) / math.sqrt(k)).half()
+    bias = rnd(n, seed=73)
+    rvec = rnd(-(-m // rpg), n, seed=74, scale=0.3)
+    x0 = rnd(m, n, seed=75) * 3.0
+    xs = torch.empty(m, 2 * n, device="cuda", dtype=torch.float16)
+    xs[:, :n] = x0.half()
+    xs[:, n:] = (x0 - x0.half().float()).half()
+    before = xs[:, :n].float() + xs[:, n:].float()
+    ref = before + a.float() @ w.float().t() + bias + rvec.repeat_interleave(rpg, dim=0)[:m]
+    part = torch.full((m, n // 64, 2), float("nan"), device="cuda")
+    L.gemm(a, w, bias=bias, out16=xs[:, :n], aux16=xs[:, n:], nstat_out=part, rvec=rvec, rvec_rpg=rpg)
+    torch.cuda.synchronize()
+    got = xs[:, :n].float() + xs[:, n:].float()
+    assert rel_err(got, ref) < 1e-3                      # (the product's fp16 operands; the pair itself resolves 2^-22)
+    assert float((got - ref).abs().max()) < 3e-3 * float(ref.abs().max()) / 8
+    hi = xs[:, :n]
+    # hi is the 16-bit rounding of the pair's value - the consumers' operand (up to the rare double rounding: lo = rn16(x - hi) can land
+    # exactly on half an ulp of hi)
+    assert float((hi != (hi.float() + xs[:, n:].float()).half()).float().mean()) < 1e-3
+    assert float((hi.float() - got).abs().max()) <= 2.0 ** -11 * float(got.abs().max())
+    assert rel_err(part[..., 0].sum(1), got.sum(1)) < 1e-5
+    assert rel_err(part[..., 1].sum(1), (got * got).sum(1)) < 1e-5
+    # twenty more read-modify-writes of a zero product leave the pair where it is (no drift: hi + lo is re-split exactly)
+    z = torch.zeros_like(a)
+    snap = got.clone()
+    for _ in range(20):
+        L.gemm(z, w, out16=xs[:, :n], aux16=xs[:, n:], nstat_out=part)
+    torch.cuda.synchronize()
+    assert float(((xs[:, :n].float() + xs[:, n:].float()) - snap).abs().max()) <= 1e-6 * float(snap.abs().max())

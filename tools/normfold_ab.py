@@ -30,6 +30,8 @@ o16 = torch.empty(M, E, device="cuda", dtype=torch.float16)
 qkv = torch.empty(M, 3 * E, device="cuda", dtype=torch.float16)
 hbuf = torch.empty(M, MLP, device="cuda", dtype=torch.float16)
 part = torch.empty(M, E // 64, 2, device="cuda")
+xs = torch.zeros(M, 2 * E, device="cuda", dtype=torch.float16)
+xs[:, :E] = x16
 mr = torch.zeros(-(-M // 256) * 256, 2, device="cuda")
 mr[:, 1] = 1.0
 rvec = rn(-(-M // RPG), E, scale=0.1)
@@ -44,10 +46,13 @@ CASES = {
     "proj  plain (EPI 3)": lambda: L.gemm(x16, w_proj, bias=b1, res=stream, out32=stream),
     "proj  producer": lambda: L.gemm(x16, w_proj, bias=b1, res=stream, out32=stream, out16=o16, nstat_out=part, rvec=rvec, rvec_rpg=RPG),
     "proj  producer, no rvec": lambda: L.gemm(x16, w_proj, bias=b1, res=stream, out32=stream, out16=o16, nstat_out=part),
+    "proj  producer, plane-pair stream in place": lambda: L.gemm(x16, w_proj, bias=b1, out16=xs[:, :E], aux16=xs[:, E:], nstat_out=part, rvec=rvec, rvec_rpg=RPG),
     "lin2  plain (EPI 3)": lambda: L.gemm(h16, w_l2, bias=b1, res=stream, out32=stream),
     "lin2  producer": lambda: L.gemm(h16, w_l2, bias=b1, res=stream, out32=stream, out16=o16, nstat_out=part),
+    "lin2  producer, plane-pair stream in place": lambda: L.gemm(h16, w_l2, bias=b1, out16=xs[:, :E], aux16=xs[:, E:], nstat_out=part),
     "qkv   plain (EPI 1)": lambda: L.gemm(x16, w_qkv, bias=b3, out16=qkv),
     "qkv   consumer": lambda: L.gemm(x16, w_qkv, bias=b3, out16=qkv, nstat_in=mr, ncol=c3),
+    "qkv   consumer, operand = hi plane (row stride 2 E)": lambda: L.gemm(xs[:, :E], w_qkv, bias=b3, out16=qkv, nstat_in=mr, ncol=c3),
     "lin1  plain (EPI 2)": lambda: L.gemm(x16, w_l1, bias=bm, out16=hbuf, act=L.ACT_GELU),
     "lin1  consumer": lambda: L.gemm(x16, w_l1, bias=bm, out16=hbuf, act=L.ACT_GELU, nstat_in=mr, ncol=cm),
     "layernorm_g (replaced)": lambda: L.layernorm_g(stream, rvec, RPG, gam, bet, 1e-6, out16=o16),
