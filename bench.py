@@ -129,6 +129,10 @@ class KernelTimer:
                                                               + 4 * (kw.get("res") is not None and kw.get("res_mod", 0) == 0))
                     if kw.get("vt") is not None:
                         nbytes += esz * m * (n - kw.get("vt_col0", 0))
+                    if kw.get("aux16") is not None and kw.get("nstat_out") is not None:
+                        nbytes += esz * m * n                    # the lo plane written beside out16 (round 6: plane-pair stream)
+                        if kw.get("out32") is None and kw.get("res") is None:
+                            nbytes += 2 * esz * m * n            # ... and both planes read as the residual (in-place read-modify-write)
                 elif _n in ("gemm_tn", "gemm_tn16"):
                     flops = issued = 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1]
                 elif _n == "attn_fwd":
