@@ -2179,6 +2179,14 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
                    "la_gemm: nstat_in writes out16 only (act NONE / GELU), needs ncol, one weight plane");
       if (epi->act == LA_ACT_GELU) la::launch_t256w_fused<la::f16_t, 9>(A, lda, W, ldw, M, N, K, *epi, gm, st);
       else la::launch_t256w_fused<la::f16_t, 8>(A, lda, W, ldw, M, N, K, *epi, gm, st);
+    } else if (epi->nstat_out && !epi->out32 && epi->res && epi->aux16) {
+      // fp32 residual in (the position table of the patch embedding), plane pairs out, no fp32 matrix at all
+      LA_CHECK_ARG(epi->out16 && epi->act == LA_ACT_NONE && (epi->ld16 % 8) == 0 && epi->ld16 >= N && al16(epi->out16) && (epi->ldr % 4) == 0 &&
+                       (reinterpret_cast<uintptr_t>(epi->nstat_out) & 7) == 0 && !epi->rvec,
+                   "la_gemm: nstat_out with a residual and no out32 writes plane pairs only (out16 + aux16), no group vector");
+      LA_CHECK_ARG(epi->res_mod == 0 || ((epi->res_mod % 256) == 0 && (M % 256) == 0),
+                   "la_gemm: nstat_out with a periodic residual needs res_mod %% 256 == 0 and M %% 256 == 0 (res_mod=%d M=%d)", epi->res_mod, M);
+      la::launch_t256w_fused<la::f16_t, 7>(A, lda, W, ldw, M, N, K, *epi, gm, st);
     } else if (epi->nstat_out && !epi->out32 && !epi->res) {
       // the stream as fp16 plane pairs, read-modify-written in place: out16 = hi plane, aux16 = lo plane (see LaGemmEpilogue.nstat_out)
       LA_CHECK_ARG(epi->out16 && epi->aux16 && epi->act == LA_ACT_NONE && (epi->ld16 % 8) == 0 && (epi->ldaux % 8) == 0 && epi->ld16 >= N &&

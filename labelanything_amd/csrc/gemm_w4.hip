@@ -280,7 +280,7 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
           if (cg == 0 && row + s_ < M) *reinterpret_cast<float2*>(e.nstat_out + ((size_t)(row + s_) * nslots + (col >> 6)) * 2) = make_float2(a, b);
         }
         if (row + s_ >= M) continue;
-        if constexpr (!RESP) {
+        if (!RESP && (!PROD || e.out32 != nullptr)) {      // (a producer that leaves plane pairs may skip the fp32 matrix: the patch embedding)
           float* op = e.out32 + (size_t)(row + s_) * e.ld32 + col;
           *reinterpret_cast<float4*>(op) = o0;
           *reinterpret_cast<float4*>(op + 4) = o1;

@@ -825,11 +825,11 @@ class LamEngine:
         hi, lo = xs[:, :e], xs[:, e:]
         part, mr = self._fold_bufs("enc", rows, e)
         have_mr = False
-        res32 = self.f32("enc.res", (rows, e))                          # (the patch embedding's fp32 output; not touched by the blocks)
-        if hw % 256 == 0:
-            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res32, out16=hi,
-                   aux16=lo, nstat_out=part, **akw)
+        if hw % 256 == 0:      # (plane pairs straight from the patch embedding's epilogue: no fp32 matrix is written at all)
+            L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out16=hi, aux16=lo,
+                   nstat_out=part, **akw)
         else:       # (a position table that is not whole row tiles: planes and statistics from a pass each, once)
+            res32 = self.f32("enc.res", (rows, e))
             L.gemm(a, p[pre + ".patch.w"], bias=w[pre + ".patch_embed.proj.bias"], res=p[pre + ".pos"], res_mod=hw, out32=res32, **akw)
             L.add_rowvec_split(res32, None, hw, xs)
             L.norm_stats(res32, 1e-6, self.buf("enc.x16", (rows, e)), mr)

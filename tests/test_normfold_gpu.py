@@ -71,6 +71,15 @@ def test_producer_gemm_periodic_residual_and_planes(L):
     assert rel_err(o32, ref) < 1e-3
     assert torch.equal(o16, o32.half())
     assert rel_err(part[..., 0].sum(1), o32.sum(1)) < 1e-5
+    # the engine's form: plane pairs only (out16 = hi, aux16 = lo of one [rows, 2 N] buffer), no fp32 matrix at all
+    a = rnd(m, 2 * k0, seed=1).half()
+    w = (rnd(n, 3 * k0, seed=2) / math.sqrt(3 * k0)).half()
+    xs = torch.zeros(m, 2 * n, device="cuda", dtype=torch.float16)
+    part2 = torch.zeros_like(part)
+    L.gemm(a, w, bias=rnd(n, seed=3), res=rnd(period, n, seed=4), res_mod=period, out16=xs[:, :n], aux16=xs[:, n:], nstat_out=part2, a_kmod=2 * k0)
+    torch.cuda.synchronize()
+    assert torch.equal(xs[:, :n], o16) and torch.equal(part2, part)
+    assert float((xs[:, :n].float() + xs[:, n:].float() - o32).abs().max()) <= 2e-6 * float(o32.abs().max())
 
 
 def test_producer_gemm_without_group_vector_or_residual(L):
