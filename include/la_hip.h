@@ -30,7 +30,7 @@ extern "C" {
 enum { LA_F16 = 0, LA_BF16 = 1, LA_F32 = 2, LA_F16X2 = 3 };
 enum { LA_ACT_NONE = 0, LA_ACT_GELU = 1, LA_ACT_RELU = 2, LA_ACT_GELU_BWD = 3 /* la_gemm only, see LaGemmEpilogue.aux16 */ };
 /* output row mappings of la_gemm (see LaGemmEpilogue.map) */
-enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3, LA_MAP_WINDOW_PART = 4 };
+enum { LA_MAP_NONE = 0, LA_MAP_GROUP = 1, LA_MAP_WINDOW_MERGE = 2, LA_MAP_CONVT2X2 = 3, LA_MAP_WINDOW_PART = 4, LA_MAP_CONV3X3 = 5 /* amap only */ };
 /* la_attn_fwd modes */
 /* LA_ATTN_RELPOS_WIN16: SAM window attention with the keys held in a 16-wide padded slot order (see la_attn_fwd) */
 enum { LA_ATTN_PLAIN = 0, LA_ATTN_RELPOS = 1, LA_ATTN_RELPOS_WIN16 = 2 };
@@ -60,6 +60,13 @@ int la_gemm_variant(int v);
  *                          GEMM row m reads A[amap(m)] and writes row m.  With LA_MAP_WINDOW_PART the proj GEMM of a SAM
  *                          window block walks the H x W tokens only and gathers its input from the window-ordered
  *                          attention output, so neither window GEMM touches the 16 % padded tokens.
+ *  amap LA_MAP_CONV3X3 (round 6; p0 = padded row width W + 2, p1 = channels C per plane, C % 64 == 0, p2 = lda = 2 C): an IMPLICIT 3 x 3 / pad 1
+ *                          convolution on a zero-bordered NHWC map of fp16 plane pairs - A rows are the pixels of [B, H + 2, W + 2] maps
+ *                          ([hi (C) | lo (C)] per pixel, W + 3 zero rows in front of and behind the buffer), GEMM row m = padded pixel m
+ *                          (border rows compute values nobody reads), K = 27 C against W = [W_hi | W_hi | W_lo] in (ky, kx, c) order:
+ *                          k-tile k0 reads plane (k0 % 18 C) / 9 C, tap t = (k0 % 9 C) / C at row offset (t / 3 - 1) p0 + (t % 3 - 1) -
+ *                          a wave-uniform shift of the source base per k-tile, no im2col buffer (the SAM neck's second convolution,
+ *                          image_encoder.py:100-106: 3.6 GB written and read again for a 0.4 GB map).
  *  a_kmod > 0 (16-bit operands, a_kmod % 64 == 0, K % a_kmod == 0): the A columns REPEAT with period a_kmod while W runs over all
  *                          K columns, i.e. C = A[:, :a_kmod] . (W[:, 0:a_kmod] + W[:, a_kmod:2 a_kmod] + ...)^T accumulated in fp32 with
  *                          every partial product formed separately.  With W = [W_hi | W_lo] (W_hi = the 16-bit rounding of an fp32
@@ -150,7 +157,9 @@ int la_conv3x3_split(const float* in, int B, int H, int W, int Cin, const float*
 /* Row LayerNorm over the last dim (biased variance):  y = LN(x [+ x2]) * gamma + beta  [-> GELU].
  * x, x2 fp32 [rows, E] (ldx).  Outputs (each optional): out32 fp32, out16, out16_pe = y + pe[(row % pe_mod)]
  * (pe fp32 [pe_mod, E]).  window > 0: rows are (b, y, x) tokens on an H x W grid and the 16-bit outputs are written
- * in window-partitioned order (pad rows are left untouched: the caller zero-fills them once)
+ * in window-partitioned order (pad rows are left untouched: the caller zero-fills them once); window == -1: the 16-bit outputs go to the
+ * interior of zero-bordered [B, H + 2, W + 2] maps (row (b (H + 2) + y + 1)(W + 2) + x + 1: the operand layout of LA_MAP_CONV3X3, borders
+ * untouched); window == -2: the INPUT rows are read from that layout, outputs in plain (b, y, x) order
  * (image_encoder.py:179-187,258-279; nn.LayerNorm; LayerNorm2d common.py:42-54 in NHWC). */
 int la_layernorm(const float* x, const float* x2, int ldx, int rows, int E, const float* gamma, const float* beta,
                  float eps, int gelu, float* out32, void* out16, void* out16_pe, const float* pe, int pe_mod,

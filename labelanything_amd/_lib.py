@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libla_hip.so")      # the one product library; n
 
 LA_F16, LA_BF16, LA_F32, LA_F16X2 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD = 0, 1, 2, 3
-MAP_NONE, MAP_GROUP, MAP_WINDOW_MERGE, MAP_CONVT2X2, MAP_WINDOW_PART = 0, 1, 2, 3, 4
+MAP_NONE, MAP_GROUP, MAP_WINDOW_MERGE, MAP_CONVT2X2, MAP_WINDOW_PART, MAP_CONV3X3 = 0, 1, 2, 3, 4, 5
 ATTN_PLAIN, ATTN_RELPOS, ATTN_RELPOS_WIN16 = 0, 1, 2
 
 _DT = {torch.float16: LA_F16, torch.bfloat16: LA_BF16, torch.float32: LA_F32}
@@ -201,6 +201,16 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, *, x2=None, gelu=False, 
               out16_pe=None, pe=None, pe_mod=0, window=0, H=0, W=0, dt=LA_F16) -> None:
     _dev(x)
     rows, e = x.shape[0], x.shape[1]
+    if window < 0:
+        # padded-map forms (LA_MAP_CONV3X3 operand layout): -1 writes the 16-bit output into the interior of [B, H + 2, W + 2] maps, -2 reads
+        # the input rows from that layout; ``rows`` counts the UN-padded pixels either way
+        o = out32 if out32 is not None else out16
+        if window == -2:
+            rows = o.shape[0]
+            if x.shape[0] < (rows // (H * W)) * (H + 2) * (W + 2):
+                raise RuntimeError("layernorm(window=-2): x must hold the padded maps [B * (H + 2) * (W + 2), E]")
+        elif out16 is None or out16.shape[0] < (rows // (H * W)) * (H + 2) * (W + 2):
+            raise RuntimeError("layernorm(window=-1): out16 must hold the padded maps [B * (H + 2) * (W + 2), ...]")
     rc = lib().la_layernorm(_ptr(x), _ptr(x2), C.c_int(x.stride(0)), C.c_int(rows), C.c_int(e), _ptr(gamma), _ptr(beta),
                             C.c_float(eps), C.c_int(int(gelu)), _ptr(out32), _ptr(out16), _ptr(out16_pe), _ptr(pe),
                             C.c_int(pe_mod), C.c_int(window), C.c_int(H), C.c_int(W), C.c_int(dt), _stream())

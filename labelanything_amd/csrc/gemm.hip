@@ -2136,9 +2136,11 @@ extern "C" int la_gemm(const void* A, int lda, const void* W, int ldw, int M, in
   LA_CHECK_ARG(epi->a_kmod == 0 || (dt != LA_F32 && epi->a_kmod > 0 && (epi->a_kmod % 64) == 0 && epi->a_kmod <= K && lda >= epi->a_kmod && M > 32),
                "la_gemm: a_kmod=%d must be a multiple of 64, <= K=%d and <= lda=%d (16-bit operands, M > 32)", epi->a_kmod, K, lda);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32, "la_gemm: bad dtype %d", dt);
-  LA_CHECK_ARG(epi->amap == LA_MAP_NONE || (epi->amap == LA_MAP_WINDOW_PART && epi->map == LA_MAP_NONE && dt != LA_F32),
-               "la_gemm: amap must be LA_MAP_NONE or LA_MAP_WINDOW_PART (16-bit operands, no output map), got amap=%d map=%d dt=%d",
-               epi->amap, epi->map, dt);
+  LA_CHECK_ARG(epi->amap == LA_MAP_NONE || (epi->amap == LA_MAP_WINDOW_PART && epi->map == LA_MAP_NONE && dt != LA_F32) ||
+                   (epi->amap == LA_MAP_CONV3X3 && epi->map == LA_MAP_NONE && dt == LA_F16 && epi->a_kmod == 0 && epi->p1 > 0 && (epi->p1 % 64) == 0 &&
+                    K == 27 * epi->p1 && epi->p2 == lda && lda == 2 * epi->p1 && epi->p0 > 2 && (N % 256) == 0 && !epi->vt && epi->ksplit == 0 && M > 512),
+               "la_gemm: amap must be LA_MAP_NONE, LA_MAP_WINDOW_PART (16-bit operands, no output map) or LA_MAP_CONV3X3 (fp16 plane pairs, p0 = padded "
+               "width, p1 = C %% 64 == 0, p2 = lda = 2 C, K = 27 C, N %% 256 == 0), got amap=%d map=%d dt=%d", epi->amap, epi->map, dt);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LA_CHECK_ARG(epi->act != LA_ACT_GELU_BWD || epi->aux16, "la_gemm: LA_ACT_GELU_BWD needs aux16 (the saved pre-activation)");
   if (epi->aux16 && !epi->nstat_out) {

@@ -48,11 +48,19 @@ __device__ __forceinline__ int map_row(const RowMap& m, int row) {
 
 // k offset of the A operand for k-tile start k0: with a_kmod > 0 the A columns repeat with that period while W keeps running
 // (W = [W_hi | W_lo] against one A: split-precision weights, LaGemmEpilogue.a_kmod)
-__device__ __forceinline__ int a_koff(const LaGemmEpilogue& e, int k0) { return e.a_kmod > 0 ? k0 % e.a_kmod : k0; }
+// amap LA_MAP_CONV3X3: the k-tile's (plane, tap, channel block) as a wave-uniform element offset from the centre pixel's row - an implicit
+// 3 x 3 convolution on a zero-bordered map of plane pairs (p0 = padded row width, p1 = C, p2 = lda)
+__device__ __forceinline__ int a_koff(const LaGemmEpilogue& e, int k0) {
+  if (e.amap == LA_MAP_CONV3X3) {
+    const int C = e.p1, kk = k0 % (18 * C), plane = kk / (9 * C), rem = kk % (9 * C), tap = rem / C;
+    return ((tap / 3 - 1) * e.p0 + (tap % 3 - 1)) * e.p2 + plane * C + rem % C;
+  }
+  return e.a_kmod > 0 ? k0 % e.a_kmod : k0;
+}
 
 // source row of GEMM row m (LaGemmEpilogue.amap)
 __device__ __forceinline__ int a_row(const LaGemmEpilogue& e, int m) {
-  if (e.amap == LA_MAP_NONE) return m;
+  if (e.amap == LA_MAP_NONE || e.amap == LA_MAP_CONV3X3) return m;
   return map_row(RowMap{e.amap, e.p0, e.p1, e.p2, e.p3, e.p4}, m);
 }
 

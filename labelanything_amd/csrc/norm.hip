@@ -66,7 +66,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
   for (int row = row_begin; row < row_end; row += row_step) {
     float4 v[NVT];
-    const float4* xp = reinterpret_cast<const float4*>(a.x + (size_t)row * a.ldx);
+    // window == -1 / -2: the 16-bit outputs / the input rows live in the interior of zero-bordered [B, H + 2, W + 2] maps (LA_MAP_CONV3X3)
+    int prow = row;
+    if (a.window < 0) {
+      const int x = row % a.W, y = (row / a.W) % a.H, b = row / (a.W * a.H);
+      prow = (b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1;
+    }
+    const float4* xp = reinterpret_cast<const float4*>(a.x + (size_t)(a.window == -2 ? prow : row) * a.ldx);
     const float4* yp = a.x2 ? reinterpret_cast<const float4*>(a.x2 + (a.x2_group > 0 ? (size_t)(row / a.x2_group) * a.E : (size_t)row * a.ldx))
                             : nullptr;
     float s = 0.f;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     q = LPR == 64 ? wave_sum_dpp(q) : wave_sum(q, LPR);
     const float rstd = 1.0f / sqrtf(q / (float)a.E + a.eps);
 
-    int drow = row;
+    int drow = a.window == -1 ? prow : row;
     if (a.window > 0) {  // (b, y, x) -> window-partitioned row
       const int ws = a.window;
       const int x = row % a.W, y = (row / a.W) % a.H, b = row / (a.W * a.H);
@@ -214,7 +220,9 @@ static int ln_impl(const char* name, const float* x, const float* x2, int x2_gro
                ldx);
   LA_CHECK_ARG(out32 || out16 || out16_pe, "%s: no output", name);
   LA_CHECK_ARG(!out16_pe || pe, "%s: out16_pe needs pe", name);
-  LA_CHECK_ARG(window == 0 || (H > 0 && W > 0 && rows % (H * W) == 0), "%s: bad window geometry", name);
+  LA_CHECK_ARG(window == 0 || (window >= -2 && H > 0 && W > 0 && rows % (H * W) == 0), "%s: bad window geometry", name);
+  LA_CHECK_ARG(window >= 0 || (!cs_part && !out16_pe && x2_group == 0 && (window == -1 ? (out16 && !out32) : true)),
+               "%s: the padded-map forms (window -1 / -2) take no column sums / pe output / per-group vector; -1 writes out16 only", name);
   LA_CHECK_ARG(dt == LA_F16 || dt == LA_BF16 || dt == LA_F32 || dt == LA_F16X2, "%s: bad dtype %d", name, dt);
   LA_CHECK_ARG(x2_group >= 0 && (x2_group == 0 || x2), "%s: x2_group needs x2", name);
   LA_CHECK_ARG(!cs_part || (cs_rpg > 0 && rows % cs_rpg == 0 && out16 && dt != LA_F16X2), "%s: column sums need rows %% rows_per_group == 0 and a plain 16-bit output", name);

@@ -158,6 +158,7 @@ class LamEngine:
         # attention without V^T copies / window buffers (la_attn_fwd_rows) wherever its forms cover the block: plain attention, the 64 x 64
         # rel-pos grid, 16-slot windows; False keeps the V^T epilogue + window scatter path (A/B, and what the other geometries still use)
         self.attn_rows = True
+        self.conv_implicit = True          # the necks' 3 x 3 convolution as an implicit GEMM on zero-bordered plane-pair maps (A/B: False = im2col + GEMM)
         self.conv_split = True             # the mask decoder's 32-channel spatial convolutions on la_conv3x3_split (A/B: False = la_conv3x3_f32)
         # LayerNorm folded into its neighbour GEMMs (round 6; LaGemmEpilogue.nstat_out / nstat_in): the residual GEMMs (patch embedding, proj,
         # lin2) also write the 16-bit copy of the stream and the partial sums of every row, q | k | v and lin1 run on gamma-folded weights
@@ -581,6 +582,20 @@ class LamEngine:
             if (pre + ".2.ws") not in self.p:
                 a1 = self.f32(tag + ".n1f", (rows, cout))
                 L.layernorm(a, self.w32[pre + ".1.weight"], self.w32[pre + ".1.bias"], 1e-6, out32=a1, dt=L.LA_F32)
+            if (pre + ".2.ws") in self.p and self.conv_implicit and cout % 64 == 0 and cout % 256 == 0 and rows > 512:
+                # IMPLICIT 3 x 3 convolution (round 6): the LayerNorm writes its plane pairs into the interior of zero-bordered
+                # [bn, g + 2, g + 2] maps, the GEMM's k-tiles read the nine taps as wave-uniform shifts of its source base
+                # (LA_MAP_CONV3X3) - no im2col buffer (18 x the map written and read again: 1.1 ms + most of the 1.2 ms GEMM's traffic) - and
+                # the last LayerNorm gathers the interior rows.  Border rows of the product are computed and never read.
+                gp = g + 2
+                mp, guard = bn * gp * gp, gp + 1
+                a1p = self.arena.get(tag + ".n1p", (mp + 2 * guard, 2 * cout), torch.float16, True)      # zero once: borders and guard rows stay zero
+                L.layernorm(a, self.w32[pre + ".1.weight"], self.w32[pre + ".1.bias"], 1e-6, out16=a1p[guard:], dt=L.LA_F16X2, window=-1, H=g, W=g)
+                a2p = self.f32(tag + ".n2p", (mp, cout))
+                L.gemm(a1p[guard:guard + mp], self.p[pre + ".2.ws"], out32=a2p, amap=L.MAP_CONV3X3, p=(gp, cout, 2 * cout, 0, 0))
+                out = self.f32(tag + ".out", (rows, cout))
+                L.layernorm(a2p, self.w32[pre + ".3.weight"], self.w32[pre + ".3.bias"], 1e-6, out32=out, dt=L.LA_F32, window=-2, H=g, W=g)
+                return out
             if (pre + ".2.ws") in self.p:
                 a1s = self.buf(tag + ".n1s", (rows, 2 * cout), torch.float16)
                 L.layernorm(a, self.w32[pre + ".1.weight"], self.w32[pre + ".1.bias"], 1e-6, out16=a1s, dt=L.LA_F16X2)

@@ -1117,3 +1117,48 @@ def test_conv3x3_split_precision_matches_torch_and_the_fp32_kernel(L, bhw):
     e_split, e_f32 = float((out.double() - ref).abs().max()) / scale, float((out32.double() - ref).abs().max()) / scale
     print(f"[conv3x3 {bhw}] split precision {e_split:.2e}, exact fp32 {e_f32:.2e}")
     assert e_split < 2e-6 and e_f32 < 2e-6
+
+
+@pytest.mark.parametrize("bhw", [(2, 64, 64), (3, 30, 30), (1, 24, 40)])
+def test_implicit_3x3_convolution_on_padded_plane_pairs_equals_im2col(L, bhw):
+    """LA_MAP_CONV3X3 (the SAM / LAM neck's second convolution, image_encoder.py:100-106): LayerNorm into zero-bordered plane-pair maps
+    (window=-1), the GEMM's k-tiles reading the nine taps as shifts of its source base, LayerNorm gathering the interior (window=-2) -
+    against LayerNorm -> im2col -> GEMM -> LayerNorm on the same operands: the same products in the same order, bit for bit."""
+    b, h, w = bhw
+    c = 256
+    rows = b * h * w
+    x = rnd(rows, c, seed=81) * 2.0
+    g1, b1 = 1.0 + 0.1 * rnd(c, seed=82), 0.05 * rnd(c, seed=83)
+    g3, b3 = 1.0 + 0.1 * rnd(c, seed=84), 0.05 * rnd(c, seed=85)
+    wt = rnd(c, 9 * c, seed=86) / math.sqrt(9 * c)
+    hi = wt.half()
+    ws = torch.cat([hi, hi, (wt - hi.float()).half()], dim=1).contiguous()
+    # reference path: plain plane pairs -> im2col -> GEMM (a_kmod) -> LayerNorm
+    a1s = torch.empty(rows, 2 * c, device="cuda", dtype=torch.float16)
+    L.layernorm(x, g1, b1, 1e-6, out16=a1s, dt=L.LA_F16X2)
+    col = torch.empty(rows, 18 * c, device="cuda", dtype=torch.float16)
+    L.im2col_3x3(a1s, b, h, w, c, col, split=True)
+    y_ref = torch.empty(rows, c, device="cuda")
+    L.gemm(col, ws, out32=y_ref, a_kmod=18 * c)
+    out_ref = torch.empty(rows, c, device="cuda")
+    L.layernorm(y_ref, g3, b3, 1e-6, out32=out_ref, dt=L.LA_F32)
+    # implicit path
+    hp, wp = h + 2, w + 2
+    mp, guard = b * hp * wp, wp + 1
+    a1p = torch.zeros(mp + 2 * guard, 2 * c, device="cuda", dtype=torch.float16)
+    L.layernorm(x, g1, b1, 1e-6, out16=a1p[guard:], dt=L.LA_F16X2, window=-1, H=h, W=w)
+    inner = a1p[guard:guard + mp].view(b, hp, wp, 2 * c)
+    assert torch.equal(inner[:, 1:-1, 1:-1].reshape(rows, 2 * c), a1s)
+    assert float(inner[:, 0].abs().max()) == 0 and float(inner[:, :, 0].abs().max()) == 0 and float(a1p[:guard].abs().max()) == 0
+    y_p = torch.full((mp, c), float("nan"), device="cuda")
+    L.gemm(a1p[guard:guard + mp], ws, out32=y_p, amap=L.MAP_CONV3X3, p=(wp, c, 2 * c, 0, 0))
+    out = torch.empty(rows, c, device="cuda")
+    L.layernorm(y_p, g3, b3, 1e-6, out32=out, dt=L.LA_F32, window=-2, H=h, W=w)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_p).all()
+    assert torch.equal(y_p.view(b, hp, wp, c)[:, 1:-1, 1:-1].reshape(rows, c), y_ref)
+    assert torch.equal(out, out_ref)
+    # and against the convolution itself in fp64
+    z = F.layer_norm(x.double(), (c,), g1.double(), b1.double(), 1e-6).view(b, h, w, c).permute(0, 3, 1, 2)
+    ref = F.conv2d(z, wt.double().view(c, 3, 3, c).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(rows, c)
+    assert rel_err(y_ref, ref) < 5e-6
