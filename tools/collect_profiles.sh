@@ -39,6 +39,7 @@ timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --precise patc
 # round 6: the LayerNorm kernels instead of the folded form (same box A/B of the headline and of cfg1), the folded GEMM forms against the plain epilogues
 timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --no-norm-fold > $OUT/${R}_bench_cfg2_no_norm_fold.json 2>> $OUT/bench.stderr
 timeout 600 python bench.py --workload cfg1 --no-cpu-baseline --no-eager-baseline --no-norm-fold > $OUT/${R}_bench_cfg1_no_norm_fold.json 2>> $OUT/bench.stderr
+timeout 600 python bench.py --no-cpu-baseline --no-eager-baseline --no-conv-implicit > $OUT/${R}_bench_cfg2_no_conv_implicit.json 2>> $OUT/bench.stderr
 timeout 300 python tools/normfold_ab.py > $OUT/${R}_normfold_ab.log 2>&1
 timeout 600 python tools/attn_fp8_report.py > $OUT/${R}_attn_fp8.log 2>&1
 timeout 600 python tools/gemm_ab.py > $OUT/${R}_gemm_ab.log 2>&1
