@@ -59,7 +59,64 @@ def run(name, m, n, k, npl, epi):
     return bad
 
 
+def run_fold(name, m, n, k, form, rpg=4096):
+    """Round 6: the folded-LayerNorm epilogues park the next tile's DMA offsets in an LDS region that is only dead between two barriers of
+    the stream (gemm_w4.hip STASH) and keep statistics / plane pairs in rings - the same screen: many launches, L2 thrash in between,
+    every result bit for bit against the first and within tolerance of fp32 arithmetic."""
+    dt = torch.float16
+    a = (torch.randn(m, k, device="cuda") * 0.5).to(dt)
+    w = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(dt)
+    bias = torch.randn(n, device="cuda") * 0.1
+    prod = a.float() @ w.float().t() + bias
+    mpad = -(-m // 256) * 256
+    mr = torch.zeros(mpad, 2, device="cuda")
+    mr[:m, 0] = torch.randn(m, device="cuda") * 0.1
+    mr[:m, 1] = torch.rand(m, device="cuda") + 0.5
+    ncol = w.float().sum(1).contiguous()
+    rvec = torch.randn(-(-m // rpg), n, device="cuda") * 0.1
+    x0 = torch.randn(m, n, device="cuda")
+    first = None
+    bad = 0
+    for it in range(iters):
+        part = torch.zeros(m, n // 64, 2, device="cuda")
+        if form == "consumer":
+            out = torch.zeros(m, n, device="cuda", dtype=dt)
+            L.gemm(a, w, bias=bias, out16=out, act=L.ACT_GELU, nstat_in=mr, ncol=ncol)
+            got = (out,)
+            want = torch.nn.functional.gelu(mr[:m, 1:2] * (prod - bias - mr[:m, 0:1] * ncol) + bias)
+        elif form == "producer":
+            res = x0.clone()
+            o16 = torch.zeros(m, n, device="cuda", dtype=dt)
+            L.gemm(a, w, bias=bias, res=res, out32=res, out16=o16, nstat_out=part, rvec=rvec, rvec_rpg=rpg)
+            got = (res, o16, part)
+            want = x0 + prod + rvec.repeat_interleave(rpg, dim=0)[:m]
+        else:                                   # plane-pair stream in place
+            xs = torch.empty(m, 2 * n, device="cuda", dtype=dt)
+            xs[:, :n] = x0.to(dt)
+            xs[:, n:] = (x0 - x0.to(dt).float()).to(dt)
+            L.gemm(a, w, bias=bias, out16=xs[:, :n], aux16=xs[:, n:], nstat_out=part, rvec=rvec, rvec_rpg=rpg)
+            got = (xs, part)
+            want = x0 + prod + rvec.repeat_interleave(rpg, dim=0)[:m]
+        if it & 1:
+            trash.add_(1.0)
+        torch.cuda.synchronize()
+        val = got[0].float() if form != "planes" else got[0][:, :n].float() + got[0][:, n:].float()
+        err = float((val - want).abs().max() / want.abs().max())
+        if first is None:
+            first = tuple(t.clone() for t in got)
+        same = all(bool(torch.equal(x, y)) for x, y in zip(got, first))
+        if err > 2e-3 or not same:
+            bad += 1
+            print(f"  {name} iteration {it}: err {err:.2e} bit-identical-to-first {same}", flush=True)
+    print(f"{name:28s} {m}x{n}x{k} {form:9s}: {iters} launches, {bad} bad", flush=True)
+    return bad
+
+
 total = 0
+for fargs in [("lin1 consumer", 256 * 64 + 77, 3072, 768, "consumer"), ("proj producer (fp32 stream)", 256 * 60, 768, 768, "producer"),
+              ("proj producer (planes)", 256 * 171 + 100, 768, 768, "planes", 901), ("lin2 producer (planes)", 256 * 96, 768, 3072, "planes"),
+              ("short K producer (planes)", 256 * 40, 768, 128, "planes")]:
+    total += run_fold(*fargs)
 for args in [("qk (one plane)", 256 * 90 + 41, 1536, 768, 1, "plain"), ("lin1", 256 * 64, 3072, 768, 1, "gelu"),
              ("lin2", 256 * 171 + 100, 768, 3072, 1, "res"), ("v (two planes)", 256 * 45, 768, 768, 2, "plain"),
              ("proj (two planes)", 256 * 43 + 7, 768, 768, 2, "res"), ("short K", 256 * 40, 3328, 256, 1, "plain")]:
