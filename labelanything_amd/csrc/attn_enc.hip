@@ -23,6 +23,12 @@
 #endif
 #define LA_ATTN_ABL 0       // measurement ablations of attn_fwd_kernel (results wrong): 1 no exp, 2 no S MFMAs, 4 no PV MFMAs, 8 no staging / barrier
 #endif
+#ifndef LA_WIN_ROT
+#define LA_WIN_ROT 1        // SAM windows: rotate the wave -> query tile assignment with the (window, head) (0: fixed, A/B)
+#endif
+#ifndef LA_WIN_HALF
+#define LA_WIN_HALF 1       // SAM windows: the last key tile runs its lower 32 slots only when the upper 32 are padding (0: full tile, A/B)
+#endif
 #ifndef LA_ATTN_X
 #define LA_ATTN_X 0         // timing experiments (results wrong beyond tile 0): 2 no maximum pass after the first tile, 4 exp2 of the bare score, 8 no row sums
 #endif
@@ -123,6 +129,22 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+#ifdef LA_DEBUG
+// phase timeline of the window instance of attn_fwd_kernel (MODE 5): s_memtime of the workgroup in the MIDDLE of the launch (steady state),
+// [wave][i]; tools/win_phases.py
+__device__ unsigned long long g_win_stamps[4 * 16];
+#define WIN_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    if (MODE == 5 && blockIdx.x == gridDim.x / 2) {                                                   \
+      unsigned long long t_;                                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+      if ((threadIdx.x & 63) == 0) g_win_stamps[(threadIdx.x >> 6) * 16 + (i)] = t_;                   \
+    }                                                                                                 \
+  } while (0)
+#else
+#define WIN_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {
   const void* qkv;
@@ -143,7 +165,24 @@ struct AttnArgs {
   // token = the qkv bias) and its output row does not exist.
   int imgH, imgW;
   const void* padrow;
+  // WIN16: divisors of the index arithmetic as multiply-high constants (set_win_magic).  A window workgroup lives ~15 us, and the ~10
+  // run-time integer divisions on its way to the first load (float-reciprocal sequences of ~20 dependent instructions each, through
+  // v_readfirstlane for the wave-uniform ones) were a fifth of that (profiles/r06_window_phases.log).
+  int nwx, nwin;                                   // windows per image row / per image (image order)
+  unsigned mg_heads, mg_nwin, mg_nwx, mg_G;
 };
+
+// n / d for 0 <= n, n * d < 2^32, with magic = ceil(2^32 / d) from the host (d == 1: magic unused): one s_mul_hi_u32 / v_mul_hi_u32
+__device__ __forceinline__ int udiv_magic(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+static inline unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+static inline void set_win_magic(AttnArgs& a) {
+  a.nwx = a.imgH > 0 ? (a.imgW + a.G - 1) / a.G : 1;
+  a.nwin = a.imgH > 0 ? a.nwx * ((a.imgH + a.G - 1) / a.G) : 1;
+  a.mg_heads = magic_of(a.heads);
+  a.mg_nwin = magic_of(a.nwin);
+  a.mg_nwx = magic_of(a.nwx);
+  a.mg_G = magic_of(a.G);
+}
 
 // MODE 0: no bias.  MODE 1: rel-pos, generic G (LDS tables filled from la_relpos_terms output).
 // MODE 2: rel-pos, G == 64 (tile == key row), terms from la_relpos_terms.  MODE 4: same with the terms computed in-kernel.
@@ -161,6 +200,7 @@ template <typename T, int MODE, int NH, bool VROW = false>
 __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2)) void attn_fwd_kernel(AttnArgs a) {
   constexpr int HDT = 64 * NH, KS = 4 * NH, SUB = 64 * 64 * 2, KVS = KV_STAGE * NH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  WIN_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int BH = a.B * a.heads;
@@ -170,7 +210,17 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   int bh, qblk;
   {
     const int nq = (a.T + 127) / 128;
-    if ((BH & 7) == 0) {
+    if (MODE == 5) {             // (windows: T <= 256 = one or two query blocks - shifts and multiply-highs, no run-time division)
+      const bool two = nq == 2;
+      if ((BH & 7) == 0) {
+        const int idx = blockIdx.x >> 3;
+        qblk = two ? (idx & 1) : 0;
+        bh = ((two ? idx >> 1 : idx) << 3) + (blockIdx.x & 7);
+      } else {
+        qblk = (int)blockIdx.x >= BH;
+        bh = blockIdx.x - (qblk ? BH : 0);
+      }
+    } else if ((BH & 7) == 0) {
       const int idx = blockIdx.x >> 3;
       qblk = idx % nq;
       bh = (idx / nq) * 8 + (blockIdx.x & 7);
@@ -179,11 +229,14 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
       qblk = blockIdx.x / BH;
     }
   }
-  const int h = bh % a.heads, b = bh / a.heads;
+  const int b = MODE == 5 ? udiv_magic(bh, a.heads, a.mg_heads) : bh / a.heads;
+  const int h = bh - b * a.heads;
   const int T_ = a.T, E3 = 3 * a.E;
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
   const T* vt = reinterpret_cast<const T*>(a.vt);
-  const int q0 = qblk * 128 + wave * 32;
+  // (windows: wave w works on query tile (w + bh) % 4 of the block - T = 196 leaves the second block's fourth tile empty, and a fixed
+  // assignment puts that hole on the same SIMD every time)
+  const int q0 = qblk * 128 + ((MODE == 5 && LA_WIN_ROT) ? ((wave + bh) & 3) : wave) * 32;
   const int q = q0 + fr;
   const int qc = min(q, T_ - 1);
   const float inv_scale = 1.0f / a.scale;
@@ -192,19 +245,21 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   const bool img_order = MODE == 5 && VROW && a.imgH > 0;
   int wimg = 0, wy0 = 0, wx0 = 0;
   if (img_order) {
-    const int nwx = (a.imgW + a.G - 1) / a.G, nwy = (a.imgH + a.G - 1) / a.G;
-    wimg = b / (nwx * nwy);
-    const int w_ = b % (nwx * nwy);
-    wy0 = (w_ / nwx) * a.G;
-    wx0 = (w_ % nwx) * a.G;
+    wimg = udiv_magic(b, a.nwin, a.mg_nwin);
+    const int w_ = b - wimg * a.nwin;
+    const int wy = udiv_magic(w_, a.nwx, a.mg_nwx);
+    wy0 = wy * a.G;
+    wx0 = (w_ - wy * a.nwx) * a.G;
   }
+  // windows: the lane's query as window coordinates
+  const int qy5 = MODE == 5 ? udiv_magic(qc, a.G, a.mg_G) : 0, qx5 = qc - qy5 * a.G;
   // row of window token (ty, tx) in the image-order buffers, or -1 beyond the image
   auto img_row = [&](int ty, int tx) -> long {
     const int y = wy0 + ty, x = wx0 + tx;
     return (y < a.imgH && x < a.imgW) ? ((long)wimg * a.imgH + y) * a.imgW + x : -1;
   };
   long qrow = (long)b * T_ + qc;                       // row of this lane's query in qkv / out
-  if (img_order) qrow = img_row(qc / a.G, qc % a.G);
+  if (img_order) qrow = img_row(qy5, qx5);
   const T* padrow = reinterpret_cast<const T*>(a.padrow);
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q][ks*16 + fh*8 .. +8] -----------------
@@ -301,7 +356,11 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   // that kernel's time were the per-workgroup prologue chain (loads -> table MFMAs -> LDS -> first tile) - the stages and the bias
   // tables do not overlap in LDS
   const int ntiles = (MODE == 5) ? ((16 * a.G + 63) >> 6) : ((T_ + 63) >> 6);
+  // windows: the last tile's upper 32 key slots are all padding (G = 14: key rows 14 / 15) - their scores carry NEG_BIG, exp2 gives exactly 0,
+  // so the tile runs its lower half only and no bit changes
+  const bool half_last = MODE == 5 && LA_WIN_HALF && ((16 * a.G) & 63) != 0 && ((16 * a.G) & 63) <= 32;
   dma(0, 0);
+  WIN_STAMP(1);
 
   // ---- bias staging ---------------------------------------------------------------------------------
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * KVS);
@@ -348,7 +407,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #pragma unroll
     for (int r = 0; r < 16; ++r) my_bh[fr * 33 + (r & 3) + 8 * (r >> 2) + 4 * fh] = uw[r] * inv_scale;
     __builtin_amdgcn_wave_barrier();
-    const int qx = qc % G;
+    const int qx = qx5;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int kw = 8 * (i >> 2) + 4 * fh + (i & 3);
@@ -450,6 +509,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int dd = 0; dd < 2; ++dd) vtr[dd] = (unsigned)((8 * fh + j) * 128 + ((4 * (dd ^ jb) + 2 * gd + (c >> 1)) << 4) + (c & 1) * 8);
   }
 
+  WIN_STAMP(2);
   dma_wait<0>();
   // MODE 4: relh[q][j] = Uh[63 - j][q], Uh[i][q] = Rh[y + i] . q; half hf covers tiles j in [32 hf, 32 hf + 32) = rows
   // i in [32 (1 - hf), +32): my_bh[q][j & 31]
@@ -468,6 +528,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   };
   if (MODE == 4) fill_relh_half(0);
   __syncthreads();
+  WIN_STAMP(3);
   // a wave whose 32 query rows all lie beyond T (T = 901: three of the 32 waves of an image-head) only helps staging the tiles
   const bool idle_wave = q0 >= T_;
   for (int j = 0; j < ntiles; ++j) {
@@ -487,16 +548,18 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     // (no per-tile initialisation pass); the per-row scalar relh[q][tile] is folded into the softmax constants below.
     f32x16 s[2];
     float rh = 0.f;
+    const bool half = MODE == 5 && half_last && j == ntiles - 1;      // (wave-uniform)
     if (MODE == 2) rh = my_bh[fr * 65 + j];
     if (MODE == 4) rh = my_bh[fr * 33 + (j & 31)];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (MODE == 5 && t == 1 && half) continue;
       const uint4 kf0 = *reinterpret_cast<const uint4*>(sk + swz_off(t * 32 + fr, fh));
       if (MODE == 2 || MODE == 4) {
         s[t] = Half16<T>::mfma32(kf0, qf[0], rw[t]);
       } else if (MODE == 5) {
         f32x16 z;
-        const int qy = qc / a.G;
+        const int qy = qy5;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int kh = 4 * j + 2 * t + hh;
@@ -517,6 +580,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     for (int ks = 1; ks < KS; ++ks) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+        if (MODE == 5 && t == 1 && half) continue;
         const uint4 kf = *reinterpret_cast<const uint4*>(sk + (ks >> 2) * SUB + swz_off(t * 32 + fr, (ks & 3) * 2 + fh));
         s[t] = Half16<T>::mfma32(kf, qf[ks], s[t]);
       }
@@ -565,9 +629,11 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #endif
     float mx = s[0][0];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (MODE == 5 && t == 1 && half) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    }
     mx = xhalf_max(mx) + rh;
     if (!__all((mx - m_run) * c2 <= RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
@@ -585,7 +651,8 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     const float mc = (rh - m_run) * c2;
     float psum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (MODE == 5 && t == 1 && half) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // (scalar FMAs on purpose: v_pk_fma_f32 does not overlap with another wave's MFMA stream at all, v_fma_f32 partly, v_exp_f32
@@ -604,12 +671,14 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         psum += p;
 #endif
       }
+    }
     l_run += psum;
 
     // ---- P^T fragments: lane (q, fh) needs keys ks*16 + fh*8 .. +8 -------------------------------------------
     uint4 pf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (MODE == 5 && ks >= 2 && half) continue;
       const int t = ks >> 1, g0 = (ks & 1) * 8;  // register group base (4 regs per group)
       const uint32_t x0 = pack2<T>(s[t][g0 + 0], s[t][g0 + 1]);
       const uint32_t x1 = pack2<T>(s[t][g0 + 2], s[t][g0 + 3]);
@@ -627,6 +696,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (MODE == 5 && ks >= 2 && half) continue;
 #pragma unroll
       for (int d = 0; d < 2 * NH; ++d) {
         uint4 vf;
@@ -647,9 +717,11 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
 #endif
 
 #if !(LA_ATTN_ABL & 8)
+    if (j < 4) WIN_STAMP(8 + j);      // (the tile's own work is done; what follows is the wait for the next tile + the barrier)
     dma_wait<0>();     // next tile (issued before this tile's MFMAs) has landed for this wave ...
     __syncthreads();   // ... and for all waves; orders the stage swap
 #endif
+    if (j < 4) WIN_STAMP(4 + j);
   }
 
   // ---- normalise and store: lane holds O[q][d*32 + 8*g + 4*fh + 0..3] ---------------------------------------
@@ -668,6 +740,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
         *reinterpret_cast<uint2*>(op + d * 32 + 8 * g4 + 4 * fh) = v;
       }
   }
+  WIN_STAMP(12);
   if (a.cspart != nullptr) {
     // column sums of the block's stored rows: DPP sums over the 16-lane rows (a lane is a query), the 4 rows x 4 waves of a column
     // meet in LDS (the K / V^T stages are idle: the key loop ended with a barrier) and are added in a fixed order
@@ -675,7 +748,7 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
     if (MODE == 5 && a.csH > 0 && !img_order) {
       const int nwx = (a.csW + a.G - 1) / a.G, nwy = (a.csH + a.G - 1) / a.G;
       const int w = b % (nwx * nwy);
-      valid = valid && (w / nwx) * a.G + qc / a.G < a.csH && (w % nwx) * a.G + qc % a.G < a.csW;
+      valid = valid && (w / nwx) * a.G + qy5 < a.csH && (w % nwx) * a.G + qx5 < a.csW;
     }
     float* red = reinterpret_cast<float*>(smem);
     constexpr int NR = 2 * NH * 16;
@@ -1079,6 +1152,13 @@ extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, cons
                               const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, float* cspart, int csH,
                               int csW, int dt, void* stream);
 
+#ifdef LA_DEBUG
+extern "C" int la_dbg_win_stamps(unsigned long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(la::g_win_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
 extern "C" int la_attn_fwd(const void* qkv, const void* vt, void* out16, const float* relh, const float* relw, const void* tabh,
                            const void* tabw, int B, int heads, int T, int Tpad, int G, int E, float scale, int mode, int dt, void* stream) {
   return la_attn_fwd_cs(qkv, vt, out16, relh, relw, tabh, tabw, B, heads, T, Tpad, G, E, scale, mode, nullptr, 0, 0, dt, stream);
@@ -1102,6 +1182,7 @@ extern "C" int la_attn_fwd_cs(const void* qkv, const void* vt, void* out16, cons
     LA_CHECK_ARG(tabh && tabw && G > 0 && G <= 16 && G * G == T && Tpad >= 16 * G,
                  "la_attn_fwd: WIN16 needs the tables, T == G*G, G <= 16 and Tpad >= 16*G (T=%d G=%d Tpad=%d)", T, G, Tpad);
     const size_t lds = kv + 4 * 32 * 33 * sizeof(float);
+    la::set_win_magic(a);
     if (dt == LA_F16) la::launch_attn<la::f16_t, 5>(a, lds, st);
     else la::launch_attn<la::bf16_t, 5>(a, lds, st);
   } else if (mode == LA_ATTN_RELPOS) {
@@ -1170,6 +1251,7 @@ extern "C" int la_attn_fwd_rows(const void* qkv, void* out16, const void* tabh, 
       a.imgW = imgW;
       a.padrow = padrow;
     }
+    la::set_win_magic(a);
     const size_t lds = 4 * 32 * 33 * sizeof(float);
     if (dt == LA_F16) la::launch_attn<la::f16_t, 5, true>(a, lds, st);
     else la::launch_attn<la::bf16_t, 5, true>(a, lds, st);

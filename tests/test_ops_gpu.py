@@ -950,14 +950,15 @@ def test_attention_without_a_transposed_v_copy_is_bit_identical(L, dt, shape):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("geom", [(2, 64, 64, 14), (1, 20, 27, 8), (3, 14, 14, 14)])
+@pytest.mark.parametrize("geom", [(2, 64, 64, 14), (1, 20, 27, 8), (3, 14, 14, 14), (4, 64, 64, 14, 4), (8, 64, 64, 14, 12), (5, 33, 50, 14, 6)])
 def test_window_attention_addressed_in_image_order(L, dt, geom):
     """la_attn_fwd_rows, LA_ATTN_RELPOS_WIN16 with an image grid: window_partition / window_unpartition (image_encoder.py:258-304) as address
     arithmetic.  Reference: the windows cut out explicitly - tokens beyond the image are the pad row, as pad-after-norm makes them - and run
     through la_attn_fwd on window buffers; every real token's output must be equal bit for bit, and the column sums fold to the image's
-    token means."""
-    nimg, ih, iw, gg = geom
-    heads, hd = 2, 64
+    token means.  Without column sums asked for, 64-wide heads run attn_win_stream_kernel (persistent workgroups walk the (window, head,
+    query block) items as one tile stream; the larger geometries give a workgroup 2 / 7 / 2 items): equal bit for bit as well."""
+    nimg, ih, iw, gg = geom[:4]
+    heads, hd = (geom[4] if len(geom) > 4 else 2), 64
     e = heads * hd
     t = gg * gg
     nwy, nwx = -(-ih // gg), -(-iw // gg)
@@ -992,6 +993,10 @@ def test_window_attention_addressed_in_image_order(L, dt, geom):
     L.colsum_fold(part, nimg, nwy * nwx * nq, e, 1.0 / (ih * iw), bar)
     want = out.float().view(nimg, ih * iw, e).mean(1)
     assert float((bar - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max()))
+    out2 = torch.full_like(out, float("nan"))
+    L.attn_fwd_rows(qkv, out2, b, heads, t, tpad, gg, e, 0.125, L.ATTN_RELPOS_WIN16, tabh=tabh, tabw=tabw, img_hw=(ih, iw), padrow=padrow)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("with_v", [True, False])
