@@ -377,28 +377,26 @@ __device__ __forceinline__ void epilogue_w4(char* slab, f32x16 (&acc)[2][4][2], 
           LA_W4_STEP(v[t][sp] = v[t][sp] * p[t])
 #undef LA_W4_STEP
         }
-        if (GELU) {
+        if (GELU) {        // x Phi(clamp(x)), Phi(c) = 0.5 + c R(c^2): gelu_erf_pk's arithmetic, 14 instructions per pair
           f32x2 u[8], tt[8], p[8];
 #define LA_W4_STEP(expr)                          \
   _Pragma("unroll") for (int t = 0; t < 8; ++t) { \
     expr;                                         \
   }                                               \
   __builtin_amdgcn_sched_barrier(0);
-          LA_W4_STEP(u[t] = v[t][sp] * 0.70710678118654752440f)
-          LA_W4_STEP(u[t].x = __builtin_amdgcn_fmed3f(u[t].x, -3.0f, 3.0f); u[t].y = __builtin_amdgcn_fmed3f(u[t].y, -3.0f, 3.0f))
+          LA_W4_STEP(u[t].x = __builtin_amdgcn_fmed3f(v[t][sp].x, -GELU_CLAMP, GELU_CLAMP); u[t].y = __builtin_amdgcn_fmed3f(v[t][sp].y, -GELU_CLAMP, GELU_CLAMP))
           LA_W4_STEP(tt[t] = u[t] * u[t])
-          LA_W4_STEP(p[t] = tt[t] * -3.753537037e-09f + 1.995845196e-07f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + -4.771217391e-06f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + 6.851813669e-05f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + -6.692335592e-04f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + 4.784903489e-03f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + -2.622046508e-02f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.123065501e-01f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + -3.759292066e-01f)
-          LA_W4_STEP(p[t] = p[t] * tt[t] + 1.128377676e+00f)
-          LA_W4_STEP(tt[t] = v[t][sp] * 0.5f)
-          LA_W4_STEP(p[t] = p[t] * u[t])
-          LA_W4_STEP(v[t][sp] = tt[t] * p[t] + tt[t])
+          LA_W4_STEP(p[t] = tt[t] * GELU_R9 + GELU_R8)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R7)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R6)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R5)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R4)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R3)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R2)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R1)
+          LA_W4_STEP(p[t] = p[t] * tt[t] + GELU_R0)
+          LA_W4_STEP(p[t] = p[t] * u[t] + 0.5f)
+          LA_W4_STEP(v[t][sp] = v[t][sp] * p[t])
 #undef LA_W4_STEP
         }
       }

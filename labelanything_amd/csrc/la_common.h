@@ -97,26 +97,32 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 }
 
 // Two GELUs at once on the packed-fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32), for epilogues that are VALU-bound and round the result to
-// 16 bit: erf(u) = u P(u^2) on |u| <= 3 with P a degree-9 minimax polynomial (|erf error| < 3e-5 inside, 2.2e-5 = 1 - erf(3) beyond
-// the clamp), i.e. |GELU error| < 0.5 |x| 3e-5 <= 6e-5 - a tenth of the fp16 rounding step of the value it is rounded to.  No
-// v_rcp / v_exp: 14 packed + 2 clamp instructions per pair (the degree 13 / 8 rational form it replaces: 22 + 2 clamps + 2 v_rcp;
-// the GELU was 10 us of VALU per 256 x 256 tile of lin1, a quarter of that launch).
+// 16 bit.  GELU(x) = x Phi(x) with Phi(c) = 0.5 + c R(c^2) on |c| <= 3 sqrt 2, R a degree-9 minimax polynomial in c^2 (Lawson iteration
+// on (Phi(c) - 0.5) / c with weight c, checked in fp32 Horner arithmetic; beyond the clamp Phi stays at Phi(+-3 sqrt 2) = 1 - 1.1e-5 /
+// 1.1e-5).  |GELU error|: 1.6e-6 on |x| <= 1, 3.1e-6 on |x| <= 2, 4.9e-6 on |x| <= 3, 1.4e-5 on |x| <= 4, 4.6e-5 beyond - in 12 packed + 2
+// clamp instructions per pair.  The form of rounds 3 - 5 (erf(u) = u P(u^2), degree 9, then 0.5 x (1 + erf): 14 + 2 instructions) had
+// 8e-6 / 2.2e-5 / 3.4e-5 / 4.9e-5 / 5.9e-5 on the same ranges; a degree-8 R (11 + 2) has 8e-6 / 1.4e-5 / 2.4e-5 / 4.7e-5 / 5.6e-5 and
+// measured 8.5e-4 on the cfg1 logits where this one measures (profiles/r06_notes.md 6).  The GELU is a quarter of the lin1 launch.
+constexpr float GELU_CLAMP = 4.2426405f;
+constexpr float GELU_R0 = 3.9893408094e-01f, GELU_R1 = -6.6454246054e-02f, GELU_R2 = 9.9263965487e-03f, GELU_R3 = -1.1587673958e-03f,
+                GELU_R4 = 1.0572972350e-04f, GELU_R5 = -7.3937967560e-06f, GELU_R6 = 3.7849368483e-07f, GELU_R7 = -1.3177804174e-08f,
+                GELU_R8 = 2.7561278625e-10f, GELU_R9 = -2.5916132844e-12f;
 __device__ __forceinline__ f32x2 gelu_erf_pk(f32x2 x) {
-  f32x2 u = x * 0.70710678118654752440f;
-  u.x = __builtin_amdgcn_fmed3f(u.x, -3.0f, 3.0f);
-  u.y = __builtin_amdgcn_fmed3f(u.y, -3.0f, 3.0f);
-  const f32x2 t = u * u;
-  f32x2 p = t * -3.753537037e-09f + 1.995845196e-07f;
-  p = p * t + -4.771217391e-06f;
-  p = p * t + 6.851813669e-05f;
-  p = p * t + -6.692335592e-04f;
-  p = p * t + 4.784903489e-03f;
-  p = p * t + -2.622046508e-02f;
-  p = p * t + 1.123065501e-01f;
-  p = p * t + -3.759292066e-01f;
-  p = p * t + 1.128377676e+00f;
-  const f32x2 hx = x * 0.5f;
-  return hx * (p * u) + hx;
+  f32x2 c;
+  c.x = __builtin_amdgcn_fmed3f(x.x, -GELU_CLAMP, GELU_CLAMP);
+  c.y = __builtin_amdgcn_fmed3f(x.y, -GELU_CLAMP, GELU_CLAMP);
+  const f32x2 t = c * c;
+  f32x2 p = t * GELU_R9 + GELU_R8;
+  p = p * t + GELU_R7;
+  p = p * t + GELU_R6;
+  p = p * t + GELU_R5;
+  p = p * t + GELU_R4;
+  p = p * t + GELU_R3;
+  p = p * t + GELU_R2;
+  p = p * t + GELU_R1;
+  p = p * t + GELU_R0;
+  p = p * c + 0.5f;
+  return x * p;
 }
 
 // ---- wave reductions (64 lanes) ----------------------------------------------------------------

@@ -1,6 +1,13 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q 2>&1 | tail -4
+cp labelanything_amd/libla_hip.so /tmp/d9.so
+for v in d9 d8 base; do
+  [ $v = d9 ] && cp /tmp/d9.so labelanything_amd/libla_hip.so || cp labelanything_amd/libla_gelu_$v.so labelanything_amd/libla_hip.so
+  echo "===== GELU $v"
+  timeout 600 python tools/parity_report.py 2>&1 | grep "precise=auto=patch+vmean+projmean+neck\] " | grep "dec=float32" | cut -c1-330
+  timeout 900 python tests/test_parity_seeds_gpu.py 11 12 13 14 15 2>&1 | grep -v amdgpu.ids | tail -12
+done
+cp /tmp/d9.so labelanything_amd/libla_hip.so
 for i in 1 2; do
-python bench.py --no-cpu-baseline --no-eager-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('fused cs', d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if k in ('attn_fwd_rows','colmean16','gemm','colsum_fold')})"
-python bench.py --no-cpu-baseline --no-eager-baseline --no-win-fused-cs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('colmean16', d['value'], d['ms_per_step'], {k:v for k,v in d['kernels_ms_per_step'].items() if k in ('attn_fwd_rows','colmean16','gemm','colsum_fold')})"
+echo "== d9"; timeout 300 python tools/normfold_ab.py 2>&1 | grep -i "lin1" | head -3
+echo "== base"; LA_TOOLS_LIB=$PWD/labelanything_amd/libla_gelu_base.so timeout 300 python tools/normfold_ab.py 2>&1 | grep -i "lin1" | head -3
 done
