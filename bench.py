@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-conv-implicit", action="store_true", help="A/B: the necks' 3 x 3 convolution as im2col + GEMM instead of the implicit GEMM on "
                     "zero-bordered plane-pair maps (LamEngine.conv_implicit, round 6)")
+    ap.add_argument("--no-win-fused-cs", action="store_true", help="A/B: the window blocks' output token means from a la_colmean16 pass instead of "
+                    "the attention epilogue's column sums (LamEngine.win_fused_cs, round 6)")
     ap.add_argument("--no-norm-fold", action="store_true", help="A/B: keep the LayerNorm kernels of the encoder blocks instead of folding them into "
                     "the neighbour GEMMs (LamEngine.norm_fold, round 6)")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape breakdown of the GEMM launches to stderr")
@@ -362,6 +364,8 @@ def main():
     lam.norm_fold = not a.no_norm_fold
     if a.no_conv_implicit:
         lam.engine().conv_implicit = False
+    if a.no_win_fused_cs:
+        lam.engine().win_fused_cs = False
     lam.use_graphs = not a.no_graphs and not train
     batch = make_inputs(a.episodes, 1234 + rank, dev, a.workload)
     if train:

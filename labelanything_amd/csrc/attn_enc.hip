@@ -742,31 +742,65 @@ __global__ __launch_bounds__(256, (((MODE == 4 || MODE == 5) && NH == 1) ? 3 : 2
   }
   WIN_STAMP(12);
   if (a.cspart != nullptr) {
-    // column sums of the block's stored rows: DPP sums over the 16-lane rows (a lane is a query), the 4 rows x 4 waves of a column
-    // meet in LDS (the K / V^T stages are idle: the key loop ended with a barrier) and are added in a fixed order
+    // Column sums of the block's stored rows ON THE MATRIX PIPE: a wave writes its 32 normalised 16-bit rows into LDS in the V tile's
+    // layout (the K / V stages are idle: the key loop ended with a barrier) and runs the P . V step on them with P = 1 -
+    // sum_k V^T[d][k] = the column sums of exactly the stored values, accumulated in fp32.  8 NH LDS writes, 4 NH transpose-read pairs and
+    // 4 NH MFMAs per wave instead of 32 NH four-step DPP sums (128 vector instructions of a window workgroup's ~1200: with the DPP form the
+    // window blocks' sums cost as much as the la_colmean16 pass they replace).  The four waves' sums meet in LDS, fixed order.
     bool valid = q < T_ && qrow >= 0;
     if (MODE == 5 && a.csH > 0 && !img_order) {
       const int nwx = (a.csW + a.G - 1) / a.G, nwy = (a.csH + a.G - 1) / a.G;
       const int w = b % (nwx * nwy);
       valid = valid && (w / nwx) * a.G + qy5 < a.csH && (w % nwx) * a.G + qx5 < a.csW;
     }
-    float* red = reinterpret_cast<float*>(smem);
-    constexpr int NR = 2 * NH * 16;
+    char* tile = smem + wave * (NH * 4096);                    // [NH sub-tiles][32 rows][128 B], chunk c of row r at slot c ^ 4 ((r >> 1) & 1)
 #pragma unroll
     for (int d = 0; d < 2 * NH; ++d)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = valid ? (float)(T)(oacc[d][r] * inv_l) : 0.f;
-        const float sr = row16_sum(v);
-        if ((lane & 15) == 0) red[(wave * NR + d * 16 + r) * 4 + (lane >> 4)] = sr;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint2 v;
+        v.x = pack2<T>(oacc[d][g4 * 4 + 0] * inv_l, oacc[d][g4 * 4 + 1] * inv_l);
+        v.y = pack2<T>(oacc[d][g4 * 4 + 2] * inv_l, oacc[d][g4 * 4 + 3] * inv_l);
+        if (!valid) v = make_uint2(0u, 0u);
+        const int c16 = 4 * (d & 1) + g4;                      // dims 32 (d & 1) + 8 g4 + 4 fh .. + 3 of the sub-tile
+        *reinterpret_cast<uint2*>(tile + (d >> 1) * 4096 + fr * 128 + ((c16 ^ (4 * ((fr >> 1) & 1))) << 4) + 8 * fh) = v;
       }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    unsigned ctr[2];
+    {
+      const int j = (lane & 15) >> 2, c = lane & 3, jb = (j >> 1) & 1, gd = (lane >> 4) & 1;
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) ctr[dd] = (unsigned)((8 * fh + j) * 128 + ((4 * (dd ^ jb) + 2 * gd + (c >> 1)) << 4) + (c & 1) * 8);
+    }
+    const uint32_t one2 = pack2<T>(1.0f, 1.0f);
+    const uint4 ones = make_uint4(one2, one2, one2, one2);
+    float* red = reinterpret_cast<float*>(smem + 4 * NH * 4096);
+#pragma unroll
+    for (int d = 0; d < 2 * NH; ++d) {
+      f32x16 cs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        const unsigned va = lds_addr_of(tile) + (d >> 1) * 4096 + ctr[d & 1] + ks * 2048;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)va);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(va + 512));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        cs = Half16<T>::mfma32(make_uint4(l2.x, l2.y, h2.x, h2.y), ones, cs);
+      }
+      if (fr == 0) {                                           // (every column of the product is the same sum) lane (0, fh): dims + 4 fh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave * HDT + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh] = cs[r];
+      }
+    }
     __syncthreads();
     if (tid < HDT) {
-      const int d = tid >> 5, rem = tid & 31, g4 = rem >> 3, ch = (rem >> 2) & 1, k = rem & 3;
-      const int r = g4 * 4 + k;
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) t += red[(w * NR + d * 16 + r) * 4 + 2 * ch] + red[(w * NR + d * 16 + r) * 4 + 2 * ch + 1];
+      for (int w = 0; w < 4; ++w) t += red[w * HDT + tid];
       const int nq = (T_ + 127) / 128;
       a.cspart[((size_t)b * nq + qblk) * a.E + h * HDT + tid] = t;
     }

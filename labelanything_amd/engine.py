@@ -158,6 +158,8 @@ class LamEngine:
         # attention without V^T copies / window buffers (la_attn_fwd_rows) wherever its forms cover the block: plain attention, the 64 x 64
         # rel-pos grid, 16-slot windows; False keeps the V^T epilogue + window scatter path (A/B, and what the other geometries still use)
         self.attn_rows = True
+        self.win_fused_cs = True           # folded SAM stack: the window blocks' token means of the attention output from the attention epilogue's column sums
+                                           # (on the matrix pipe since round 6; as the global blocks always did) instead of a la_colmean16 pass (A/B: False)
         self.conv_implicit = True          # the necks' 3 x 3 convolution as an implicit GEMM on zero-bordered plane-pair maps (A/B: False = im2col + GEMM)
         self.conv_split = True             # the mask decoder's 32-channel spatial convolutions on la_conv3x3_split (A/B: False = la_conv3x3_f32)
         # LayerNorm folded into its neighbour GEMMs (round 6; LaGemmEpilogue.nstat_out / nstat_in): the residual GEMMs (patch embedding, proj,
@@ -690,13 +692,13 @@ class LamEngine:
                 qkv = self.buf("enc.qkv.r", (rows, 3 * ea))
                 self.qkv_gemm(xin, bp + ".qkv.w", qkv, None, ea)
                 ao = self.buf("enc.ao.r", (rows, ea))
-                fused_o = opart is not None and is_global
+                fused_o = opart is not None and (is_global or self.win_fused_cs)
                 if is_global:
                     L.attn_fwd_rows(qkv, ao, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
                                     cspart=opart if fused_o else None)
                 else:
                     L.attn_fwd_rows(qkv, ao, nb, heads, t, tpad, gg, ea, scale, L.ATTN_RELPOS_WIN16, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
-                                    img_hw=(g, g), padrow=p[bp + ".qkv.pad16"])
+                                    img_hw=(g, g), padrow=p[bp + ".qkv.pad16"], cspart=opart if fused_o else None)
                 if rvec is not None:
                     self.mean_fix(bp, xpart, opart, rvec, bn, hw, o_chunks if fused_o else 0, e, ea, ao=ao)
                 self.gemm_w(ao, bp + ".proj.w", bias=w[bp + ".attn.proj.bias"], res=res, out32=res)
@@ -863,13 +865,14 @@ class LamEngine:
             qkv = self.buf("enc.qkv.r", (rows, 3 * ea))
             L.gemm(hi, p[bp + ".qkv.wn"], bias=p[bp + ".qkv.bn"], out16=qkv, nstat_in=mr, ncol=p[bp + ".qkv.cn"])
             ao = self.buf("enc.ao.r", (rows, ea))
-            fused_o = opart is not None and is_global
+            fused_o = opart is not None and (is_global or self.win_fused_cs)
             if is_global:
                 L.attn_fwd_rows(qkv, ao, bn, heads, hw, _ceil(hw, 64), g, ea, scale, L.ATTN_RELPOS, tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"],
                                 cspart=opart if fused_o else None)
             else:
                 L.attn_fwd_rows(qkv, ao, bn * nwy * nwy, heads, ws * ws, _ceil(16 * ws, 64), ws, ea, scale, L.ATTN_RELPOS_WIN16,
-                                tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"], img_hw=(g, g), padrow=p[bp + ".qkv.pad16"])
+                                tabh=p[bp + ".tabh"], tabw=p[bp + ".tabw"], img_hw=(g, g), padrow=p[bp + ".qkv.pad16"],
+                                cspart=opart if fused_o else None)
             dr = self._fold_mean(bp, xpart, opart, bn, hw, o_chunks if fused_o else 0, e, ea, ao)
             L.gemm(ao, p[bp + ".proj.w"], bias=w[bp + ".attn.proj.bias"], out16=hi, aux16=lo, nstat_out=part, rvec=dr,
                    rvec_rpg=hw if dr is not None else 0, a_kmod=self.kmod.get(bp + ".proj.w", 0))

@@ -55,6 +55,7 @@ VARIANTS=1,2 BLAS=1 timeout 400 python tools/gemm_ab.py > $OUT/${R}_gemm_ab_w4.l
 timeout 300 python tools/qkv_split_probe.py > $OUT/${R}_qkv_split_probe.log 2>&1
 timeout 200 python tools/bw_probe.py > $OUT/${R}_bw_probe.log 2>&1
 timeout 200 python tools/win96_probe.py > $OUT/${R}_window_attention_96_images.log 2>&1
+[ -f labelanything_amd/libla_hip_dbg.so ] && timeout 200 python tools/win_phases.py > $OUT/${R}_window_phases.log 2>&1
 IT=3 timeout 900 bash tools/kernel_pmc.sh attn attn_fwd python tools/attn_ab.py > /dev/null 2>&1; cp gpurun_out/pmc_attn.txt $OUT/${R}_attn_pmc.txt 2>/dev/null
 timeout 300 python tools/twoway_d512_ab.py > $OUT/${R}_twoway_d512_ab.log 2>&1
 timeout 900 python -m pytest tests/test_parity_seeds_gpu.py tests/test_encoder_train_gpu.py tests/test_sam_train_gpu.py tests/test_train_gpu.py::test_cfg3_train_step_at_full_size -m gpu -q -s > $OUT/${R}_parity_seeds.log 2>&1
